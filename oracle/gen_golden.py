@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""
+gen_golden.py -- produce tests/golden/* by running the UNMODIFIED reference
+(/root/reference/kbbq) in the build container.  TEST INFRASTRUCTURE ONLY.
+
+    python oracle/gen_golden.py            # all cases (about two minutes)
+
+The reference cannot travel to the GPU box, so its outputs are committed as
+small fixtures (data only): the 9 covariate vectors (recalibrate.py:121), the 4
+delta-Q tables (applybqsr.py:103), SHA-256 of the FASTQ text it prints plus the
+first/last records, and a few numeric tables (prior, q<->p, a gatk_delta_q
+grid).  Inputs are NOT stored: they are regenerated from (seed, shape) by
+oracle.synth(), and their SHA-256 is stored so a test can prove it feeds the
+oracle the very bytes the reference saw.
+
+Timing of the reference's own passes on this container's CPU (1 core; the
+reference is single threaded) is recorded as well: BASELINE.md section 3(1).
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import oracle as O      # noqa: E402  (own code: synthetic inputs + FASTQ writer only)
+import _shim            # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+# name -> synthetic shape.  C1 is BASELINE.json configs[0]; the others are cuts of
+# configs[2] (8 RGs via --infer-rg) and configs[4] (mixed, ascending lengths).
+CASES = {
+    'c1_10k_1rg':       dict(n=10000, seed=1, len_lo=150, len_hi=150, nrg=1, infer_rg=False, qlo=0, qhi=41),
+    'c3cut_2k_8rg':     dict(n=2000, seed=3, len_lo=150, len_hi=150, nrg=8, infer_rg=True, qlo=0, qhi=41),
+    'c5cut_2k_mixed':   dict(n=2000, seed=5, len_lo=36, len_hi=300, nrg=2, infer_rg=True, qlo=0, qhi=41),
+    'q42_500_3rg':      dict(n=500, seed=7, len_lo=100, len_hi=100, nrg=3, infer_rg=True, qlo=2, qhi=42),
+    'short_64_1rg':     dict(n=64, seed=9, len_lo=1, len_hi=17, nrg=1, infer_rg=False, qlo=0, qhi=41),
+}
+
+
+def run_case(name, c, recal, applybqsr, tmp):
+    seq, cseq, qual, meta = O.synth(0, c['n'], c['n'], c['seed'], c['len_lo'], c['len_hi'],
+                                    c['nrg'], c['qlo'], c['qhi'])
+    names = O.synth_names(0, c['n'], c['nrg'], with_rg=c['infer_rg'])
+    fa = os.path.join(tmp, name + '.fq')
+    fb = os.path.join(tmp, name + '.cor.fq')
+    O.write_fastq(fa, names, seq, qual, meta)
+    O.write_fastq(fb, names, cseq, qual, meta)
+    in_sha = [O.sha256(open(f, 'rb').read()) for f in (fa, fb)]
+
+    t0 = time.perf_counter()
+    vectors = recal.fastq_to_covariate_arrays([fa, fb], infer_rg=c['infer_rg'])
+    t1 = time.perf_counter()
+    dqs = applybqsr.get_delta_qs(*vectors)
+    t2 = time.perf_counter()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        recal.recalibrate_fastq([fa, fb], infer_rg=c['infer_rg'])
+    t3 = time.perf_counter()
+    text = buf.getvalue()
+    recs = text.split('\n')
+    bases = int((meta & 0xFFFF).sum())
+    info = dict(case=c, input_sha256=in_sha, output_sha256=O.sha256(text),
+                output_len=len(text), first_records='\n'.join(recs[:32]),
+                last_records='\n'.join(recs[-33:]), bases=bases,
+                reference_timing=dict(pass1_s=t1 - t0, solve_s=t2 - t1, end_to_end_s=t3 - t2,
+                                      pass1_bases_per_s=bases / (t1 - t0),
+                                      end_to_end_bases_per_s=bases / (t3 - t2),
+                                      cores_used=1, host_cores=os.cpu_count()))
+    keys = ['meanq', 'rg_errs', 'rg_total', 'q_errs', 'q_total', 'pos_errs', 'pos_total',
+            'dinuc_errs', 'dinuc_total']
+    arrs = {k: np.asarray(v).astype(np.int64) for k, v in zip(keys, vectors)}
+    for k, v in zip(['rgdq', 'qdq', 'posdq', 'dinucdq'], dqs):
+        arrs[k] = np.asarray(v).astype(np.int64)
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), **arrs)
+    with open(os.path.join(GOLD, name + '.json'), 'w') as fh:
+        json.dump(info, fh, indent=1)
+    print('%-18s bases=%d pass1 %.2fs solve %.2fs e2e %.2fs  out=%s' % (
+        name, bases, t1 - t0, t2 - t1, t3 - t2, info['output_sha256'][:12]), flush=True)
+
+
+def numeric_tables(utils):
+    """Small numeric goldens pinning the model's floating point (hazards H4, H5)."""
+    out = {}
+    out['prior_dist_hex'] = [float(x).hex() if np.isfinite(x) else '-inf'
+                             for x in utils.RescaledNormal.prior_dist]
+    out['prior_dist_is_float64_exact'] = bool(all(
+        (not np.isfinite(x)) or np.longdouble(float(x)) == x for x in utils.RescaledNormal.prior_dist))
+    q = np.arange(43)
+    out['q_to_p_hex'] = [float(x).hex() for x in utils.q_to_p(q)]
+    out['p_to_q_of_q_to_p'] = [int(x) for x in utils.p_to_q(utils.q_to_p(q))]
+    out['p_to_q_samples'] = dict(p=[.2, .3, .4, .1, .01, .001, 0.0, 1.0, 1e-9],
+                                 q=[int(x) for x in utils.p_to_q(np.array([.2, .3, .4, .1, .01, .001, 0.0, 1.0, 1e-9]))])
+    # gatk_delta_q grid: every prior 0..42 against a list of (errs, total) cells
+    rng = np.random.default_rng(12345)
+    cells = [(0, 0), (0, 1), (1, 1), (0, 10), (10, 10), (5, 1000), (0, 1000), (1000, 1000),
+             (10, 1000), (200, 1000), (0, 50000), (123456, 10 ** 7), (0, 10 ** 10),
+             (10 ** 10, 10 ** 10), (7 * 10 ** 8, 7 * 10 ** 9), (3, 7 * 10 ** 9),
+             (2 ** 31, 2 ** 33), (999999999, 10 ** 10)]
+    for _ in range(400):
+        t = int(10 ** rng.uniform(0, 10.3))
+        e = int(t * 10 ** (-rng.uniform(0, 4.5)))
+        cells.append((min(e, t), t))
+    errs = np.array([c[0] for c in cells], dtype=np.int64)
+    tot = np.array([c[1] for c in cells], dtype=np.int64)
+    prior = np.broadcast_to(np.arange(43)[:, None], (43, len(cells))).copy()
+    dq = utils.gatk_delta_q(prior, np.broadcast_to(errs, prior.shape).copy(),
+                            np.broadcast_to(tot, prior.shape).copy())
+    return out, dict(grid_errs=errs, grid_total=tot, grid_dq=np.asarray(dq).astype(np.int64))
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    _shim.install()
+    import scipy
+    from kbbq import recalibrate as recal            # the reference, unmodified
+    from kbbq import compare_reads as utils
+    from kbbq.gatk import applybqsr
+    assert recal.__file__.startswith('/root/reference/')
+    only = sys.argv[1:]
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, c in CASES.items():
+            if only and name not in only:
+                continue
+            run_case(name, c, recal, applybqsr, tmp)
+    if not only:
+        info, arrs = numeric_tables(utils)
+        info['versions'] = dict(numpy=np.__version__, scipy=scipy.__version__,
+                                python=sys.version.split()[0])
+        np.savez_compressed(os.path.join(GOLD, 'numeric.npz'), **arrs)
+        with open(os.path.join(GOLD, 'numeric.json'), 'w') as fh:
+            json.dump(info, fh, indent=1)
+        print('numeric tables written')
+
+
+if __name__ == '__main__':
+    main()
