@@ -1,0 +1,154 @@
+/*
+ * kbbq_hip.h -- C ABI of libkbbq_hip.so, the MI355X (gfx950) implementation of
+ * kbbq's recalibrate hot path.
+ *
+ * The reference (adamjorr/kbbq-py @ v1) is pure Python and has no FFI layer;
+ * these entry points are what a ctypes binding of its hot-path functions binds
+ * (INTEGRATION.md shows the stub).  Each entry point cites the reference code it
+ * replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C, no torch types; every function returns 0 (KBBQ_OK) or a negative
+ *     KBBQ_E_* code; kbbq_last_error() returns text for the calling thread.
+ *   - "_dev" functions take DEVICE pointers and enqueue on the context's stream
+ *     without synchronising; kernels report data errors (the reference's
+ *     IndexError / TypeError cases) through the context's status word, read
+ *     with kbbq_ctx_status() (which synchronises).
+ *   - host-pointer functions (no suffix) stage through device memory owned by
+ *     the context and synchronise before returning.
+ *   - one context per device; a context is not thread-safe.
+ *
+ * Read layout ("padded SoA"): three byte planes seq / cseq / qual, one row of
+ * `pitch` bytes per read, pitch a multiple of 16, rows 16-byte aligned.  Bytes
+ * are the FASTQ characters (qual is phred+33).  Bytes at and beyond the read
+ * length MUST be zero.  One uint32 of metadata per read:
+ *     bits  0..15  length          (<= pitch)
+ *     bits 16..30  read-group id   (first-appearance order, recalibrate.py:59-64)
+ *     bit  31      second in pair  (compare_reads.py:304-306)
+ *
+ * Count tables: ONE int64 buffer of kbbq_tables_count(R, S2) elements,
+ *     [ pos_errs[R][43][S2] | pos_total[R][43][S2] | dinuc_errs[R][43][16] | dinuc_total[R][43][16] ]
+ * i.e. the four 3-D arrays of recalibrate.py:51-54 at their final size
+ * (S2 = 2 * longest read).  q_* and rg_* are marginals of pos_* (SURVEY 7).
+ * kbbq_accumulate* ADD into the buffer, so batches, shards and ranks compose.
+ */
+#ifndef KBBQ_HIP_H
+#define KBBQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KBBQ_OK          0
+#define KBBQ_E_HIP      -1   /* HIP runtime error (no device, out of memory, ...)        */
+#define KBBQ_E_INDEX    -2   /* the reference raises IndexError on this input            */
+#define KBBQ_E_TYPE     -3   /* the reference raises TypeError (base outside ACGTN)      */
+#define KBBQ_E_ARG      -4   /* bad argument (alignment, sizes, read too long for LDS)   */
+#define KBBQ_E_RANGE    -5   /* recalibrated quality + 33 outside 0..255     */
+#define KBBQ_E_NAME     -6   /* corrected read name does not start with the read name    */
+
+#define KBBQ_NQ         43   /* maxscore + 1, recalibrate.py:36                          */
+#define KBBQ_NDINUC     16
+#define KBBQ_ABI_VERSION 1
+
+typedef struct kbbq_ctx kbbq_ctx;
+
+/* ---- library / context ------------------------------------------------ */
+int         kbbq_abi_version(void);
+const char* kbbq_last_error(void);
+int         kbbq_device_count(int* count);
+int         kbbq_ctx_create(int device, kbbq_ctx** out);
+int         kbbq_ctx_destroy(kbbq_ctx* ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the
+ * context's own stream.                                                    */
+int         kbbq_ctx_set_stream(kbbq_ctx* ctx, void* hip_stream);
+int         kbbq_ctx_sync(kbbq_ctx* ctx);
+/* Synchronise, fetch and clear the kernels' status word.  Returns KBBQ_OK or the
+ * KBBQ_E_INDEX / KBBQ_E_TYPE / KBBQ_E_RANGE the reference would have raised
+ * first (lowest read index; TypeError wins a tie, recalibrate.py:94 precedes
+ * :114).  *read_index receives that read's index within the launch (or -1).  */
+int         kbbq_ctx_status(kbbq_ctx* ctx, int64_t* read_index);
+/* Device properties the host code sizes launches with.                     */
+int         kbbq_ctx_info(kbbq_ctx* ctx, int* compute_units, int* lds_bytes, char* name, int name_len);
+
+/* ---- device memory plumbing (for callers without torch) --------------- */
+int kbbq_dev_alloc(kbbq_ctx* ctx, size_t bytes, void** dptr);
+int kbbq_dev_free(kbbq_ctx* ctx, void* dptr);
+int kbbq_dev_zero(kbbq_ctx* ctx, void* dptr, size_t bytes);                       /* async */
+int kbbq_dev_upload(kbbq_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);   /* sync */
+int kbbq_dev_download(kbbq_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* sync */
+
+/* ---- geometry ---------------------------------------------------------- */
+size_t kbbq_tables_count(int R, int S2);          /* int64 elements in a count-table buffer */
+size_t kbbq_lut_count(int R, int Qt, int S2);     /* int16 elements in an apply LUT         */
+
+/* ---- K1: error flagging + covariate binning ---------------------------
+ * Replaces the loop body of recalibrate.fastq_to_covariate_arrays
+ * (recalibrate.py:57-119) with find_corrected_sites (:13-20),
+ * fastq_cycle_covariates / fastq_dinuc_covariates (compare_reads.py:275-302).
+ * Second-in-pair cycles land on column 2*len-(i+1) (valid inputs
+ * have non-decreasing lengths, so the running maximum IS the read's length).
+ * q > 42 -> KBBQ_E_INDEX; a base outside ACGTN in a looked-up dinucleotide ->
+ * KBBQ_E_TYPE (through kbbq_ctx_status).                                    */
+int kbbq_accumulate_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_cseq,
+                        const uint8_t* d_qual, const uint32_t* d_meta,
+                        int64_t nreads, int pitch, int R, int S2, int minscore,
+                        int64_t* d_tables);
+/* Same, with a separate quality threshold for the dinucleotide context: bases with
+ * q >= minscore are counted, a context exists only where q >= dinuc_minscore.  This is
+ * the rule of ReadData / CovariateData.consume_read (read.py:336-369, covariate.py:406-425:
+ * `skips` decide what is counted -- the caller zeroes the quality byte of skipped bases
+ * and passes minscore = 0 -- while minscore only gates the context).               */
+int kbbq_accumulate_ex_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_cseq,
+                           const uint8_t* d_qual, const uint32_t* d_meta,
+                           int64_t nreads, int pitch, int R, int S2, int minscore,
+                           int dinuc_minscore, int64_t* d_tables);
+int kbbq_accumulate(kbbq_ctx* ctx, const uint8_t* seq, const uint8_t* cseq,
+                    const uint8_t* qual, const uint32_t* meta,
+                    int64_t nreads, int pitch, int R, int S2, int minscore,
+                    int64_t* pos_errs, int64_t* pos_total,
+                    int64_t* dinuc_errs, int64_t* dinuc_total);
+
+/* ---- K2: delta-Q table lookup / apply ----------------------------------
+ * Replaces compare_reads.recalibrate_fastq (compare_reads.py:320-328) as driven
+ * by recalibrate.py:141-152.  The five model arrays are folded on the host into
+ * one int16 LUT (kbbq_build_lut):
+ *     lut1[R][Qt][S2]  = meanq[rg] + rgdq[rg] + qdq[rg][q] + posdq[rg][q][cycle]
+ *     lut2[R][Qt][17]  = dinucdq[rg][q][d]     (column 16 = "no context", index -1)
+ * new_q = lut1 + lut2 for q >= minscore, q otherwise; the output byte is
+ * new_q + 33 (no clipping, compare_reads.py:327; outside 0..255 -> KBBQ_E_RANGE).
+ * Cycle -(i+1) wraps on the final S2 (Python negative index).  q >= Qt, rg >= R
+ * or a cycle beyond S2 -> KBBQ_E_INDEX.                                     */
+int kbbq_build_lut(int R, int Qt, int S2, int D,
+                   const int64_t* meanq, const int64_t* rgdq, const int64_t* qdq,
+                   const int64_t* posdq, const int64_t* dinucdq, int16_t* lut_out);
+int kbbq_apply_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_qual,
+                   const uint32_t* d_meta, int64_t nreads, int pitch,
+                   int R, int Qt, int S2, int minscore,
+                   const int16_t* d_lut, uint8_t* d_qual_out);
+int kbbq_apply(kbbq_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint32_t* meta,
+               int64_t nreads, int pitch, int R, int Qt, int S2, int D, int minscore,
+               const int64_t* meanq, const int64_t* rgdq, const int64_t* qdq,
+               const int64_t* posdq, const int64_t* dinucdq, uint8_t* qual_out);
+
+/* ---- synthetic reads (bench / tests) -----------------------
+ * Device twin of the generator documented in oracle/kbbq_oracle.c.          */
+int kbbq_synth_dev(kbbq_ctx* ctx, uint8_t* d_seq, uint8_t* d_cseq, uint8_t* d_qual,
+                   uint32_t* d_meta, int64_t first_read, int64_t nreads, int64_t total_reads,
+                   int pitch, uint64_t seed, int len_lo, int len_hi, int nrg,
+                   int qlo, int qhi, const uint32_t* thr43);
+
+/* ---- timing of the most recent kernels (bench.py roofline) -------------
+ * When enabled, every K1 / K2 launch is bracketed by HIP events on the launch
+ * stream; kbbq_ctx_kernel_ms returns the accumulated milliseconds and launch
+ * counts since the last reset (synchronises).  which: 0 = K1, 1 = K2.       */
+int kbbq_ctx_timing(kbbq_ctx* ctx, int enable);
+int kbbq_ctx_kernel_ms(kbbq_ctx* ctx, int which, double* total_ms, int64_t* launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KBBQ_HIP_H */

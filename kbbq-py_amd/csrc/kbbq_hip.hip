@@ -1,0 +1,464 @@
+// kbbq_hip.hip -- C ABI of libkbbq_hip.so (see include/kbbq_hip.h).
+// gfx950 only.  Host side: launch geometry, device staging, status decoding.
+#include "kbbq_kernels.h"
+#include "../../include/kbbq_hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(KBBQ_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                           \
+    } while (0)
+
+struct kbbq_ctx {
+    int device = 0;
+    int cus = 0;
+    int lds_bytes = 0;
+    char name[128] = {0};
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    u64* d_status = nullptr;          // [4]
+    bool timing = false;
+    // per-kernel event pairs recorded while timing is on
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
+    double ms_acc[2] = {0.0, 0.0};
+    int64_t launches[2] = {0, 0};
+};
+
+static const u64 ST_INIT[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+
+extern "C" {
+
+int kbbq_abi_version(void) { return KBBQ_ABI_VERSION; }
+const char* kbbq_last_error(void) { return g_err.c_str(); }
+
+int kbbq_device_count(int* count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(KBBQ_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return KBBQ_OK;
+}
+
+int kbbq_ctx_create(int device, kbbq_ctx** out)
+{
+    if (!out) return fail(KBBQ_E_ARG, "kbbq_ctx_create: out is NULL");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(KBBQ_E_HIP, "libkbbq_hip is built for gfx950 only; device %d is %s", device, prop.gcnArchName);
+    kbbq_ctx* c = new kbbq_ctx();
+    c->device = device;
+    c->cus = prop.multiProcessorCount;
+    c->lds_bytes = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (c->lds_bytes <= 0) c->lds_bytes = 160 * 1024;
+    snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(KBBQ_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    c->stream = c->own_stream;
+    e = hipMalloc((void**)&c->d_status, sizeof ST_INIT);
+    if (e != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return fail(KBBQ_E_HIP, "hipMalloc(status): %s", hipGetErrorString(e)); }
+    e = hipMemcpy(c->d_status, ST_INIT, sizeof ST_INIT, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(c->d_status); (void)hipStreamDestroy(c->own_stream); delete c; return fail(KBBQ_E_HIP, "hipMemcpy(status): %s", hipGetErrorString(e)); }
+    // allow the full 160 KiB of LDS as dynamic shared memory
+    (void)hipFuncSetAttribute((const void*)k1_accumulate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)k1_accumulate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)k2_apply, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipGetLastError();
+    *out = c;
+    return KBBQ_OK;
+}
+
+int kbbq_ctx_destroy(kbbq_ctx* c)
+{
+    if (!c) return KBBQ_OK;
+    (void)hipSetDevice(c->device);
+    for (int w = 0; w < 2; ++w)
+        for (auto& pr : c->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return KBBQ_OK;
+}
+
+int kbbq_ctx_set_stream(kbbq_ctx* c, void* s)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return KBBQ_OK;
+}
+
+int kbbq_ctx_sync(kbbq_ctx* c)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KBBQ_OK;
+}
+
+int kbbq_ctx_info(kbbq_ctx* c, int* cus, int* lds, char* name, int name_len)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (cus) *cus = c->cus;
+    if (lds) *lds = c->lds_bytes;
+    if (name && name_len > 0) { strncpy(name, c->name, (size_t)name_len - 1); name[name_len - 1] = 0; }
+    return KBBQ_OK;
+}
+
+int kbbq_ctx_status(kbbq_ctx* c, int64_t* read_index)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    u64 st[4];
+    HIPCHK(hipMemcpyAsync(st, c->d_status, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (read_index) *read_index = -1;
+    if (st[0] == ~0ull && st[1] == ~0ull && st[2] == ~0ull) return KBBQ_OK;
+    HIPCHK(hipMemcpyAsync(c->d_status, ST_INIT, sizeof ST_INIT, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // the reference stops at the FIRST offending read; within one read the dinucleotide
+    // lookup (TypeError, recalibrate.py:94) runs before the table indexing (IndexError, :114)
+    int code = KBBQ_E_TYPE; u64 best = st[ST_TYPE];
+    if (st[ST_INDEX] < best) { best = st[ST_INDEX]; code = KBBQ_E_INDEX; }
+    if (st[ST_RANGE] < best) { best = st[ST_RANGE]; code = KBBQ_E_RANGE; }
+    if (read_index) *read_index = (int64_t)best;
+    const char* what = code == KBBQ_E_TYPE ? "base outside ACGTN in a dinucleotide (reference: TypeError)"
+                     : code == KBBQ_E_INDEX ? "quality/read-group/cycle beyond the tables (reference: IndexError)"
+                                            : "recalibrated quality + 33 outside 0..255";
+    return fail(code, "read %lld: %s", (long long)best, what);
+}
+
+int kbbq_dev_alloc(kbbq_ctx* c, size_t bytes, void** dptr)
+{
+    if (!c || !dptr) return fail(KBBQ_E_ARG, "kbbq_dev_alloc: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMalloc(dptr, bytes ? bytes : 16));
+    return KBBQ_OK;
+}
+
+int kbbq_dev_free(kbbq_ctx* c, void* dptr)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    if (dptr) HIPCHK(hipFree(dptr));
+    return KBBQ_OK;
+}
+
+int kbbq_dev_zero(kbbq_ctx* c, void* dptr, size_t bytes)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    if (bytes) HIPCHK(hipMemsetAsync(dptr, 0, bytes, c->stream));
+    return KBBQ_OK;
+}
+
+int kbbq_dev_upload(kbbq_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KBBQ_OK;
+}
+
+int kbbq_dev_download(kbbq_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KBBQ_OK;
+}
+
+size_t kbbq_tables_count(int R, int S2)
+{
+    return 2 * (size_t)R * KQ * (size_t)S2 + 2 * (size_t)R * KQ * KND;
+}
+
+size_t kbbq_lut_count(int R, int Qt, int S2)
+{
+    size_t n = (size_t)R * Qt * ((size_t)S2 + 17);
+    return (n + 1) & ~(size_t)1;       // even: K2 stages the LUT as 32-bit words
+}
+
+int kbbq_ctx_timing(kbbq_ctx* c, int enable)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    c->timing = enable != 0;
+    return KBBQ_OK;
+}
+
+int kbbq_ctx_kernel_ms(kbbq_ctx* c, int which, double* total_ms, int64_t* launches, int reset)
+{
+    if (!c || which < 0 || which > 1) return fail(KBBQ_E_ARG, "kbbq_ctx_kernel_ms: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto& pr : c->ev[which]) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+        c->ms_acc[which] += ms;
+        c->launches[which] += 1;
+        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+    }
+    c->ev[which].clear();
+    if (total_ms) *total_ms = c->ms_acc[which];
+    if (launches) *launches = c->launches[which];
+    if (reset) { c->ms_acc[which] = 0.0; c->launches[which] = 0; }
+    return KBBQ_OK;
+}
+
+} // extern "C"
+
+// ---- launch helpers ---------------------------------------------------
+static int check_planes(const char* fn, int64_t nreads, int pitch, const void* a, const void* b, const void* c)
+{
+    if (nreads < 0) return fail(KBBQ_E_ARG, "%s: nreads < 0", fn);
+    if (pitch <= 0 || (pitch & 15) || pitch > 65536) return fail(KBBQ_E_ARG, "%s: pitch must be a positive multiple of 16 (<= 65536), got %d", fn, pitch);
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) return fail(KBBQ_E_ARG, "%s: planes must be 16-byte aligned", fn);
+    return KBBQ_OK;
+}
+
+static u32 magic_for(int cpr) { return cpr <= 1 ? 0u : (u32)(((1ull << 32) + (u64)cpr - 1) / (u64)cpr); }
+
+struct Timed {
+    kbbq_ctx* c; int which; hipEvent_t a = nullptr, b = nullptr;
+    Timed(kbbq_ctx* c_, int w) : c(c_), which(w)
+    {
+        if (c->timing && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+            (void)hipEventRecord(a, c->stream);
+        else a = b = nullptr;
+    }
+    ~Timed()
+    {
+        if (a && b) { (void)hipEventRecord(b, c->stream); c->ev[which].push_back({a, b}); }
+    }
+};
+
+extern "C" {
+
+int kbbq_accumulate_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq,
+                        const uint8_t* d_qual, const uint32_t* d_meta,
+                        int64_t nreads, int pitch, int R, int S2, int minscore, int64_t* d_tables)
+{
+    return kbbq_accumulate_ex_dev(c, d_seq, d_cseq, d_qual, d_meta, nreads, pitch, R, S2,
+                                  minscore, minscore, d_tables);
+}
+
+int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq,
+                           const uint8_t* d_qual, const uint32_t* d_meta,
+                           int64_t nreads, int pitch, int R, int S2, int minscore,
+                           int dinuc_minscore, int64_t* d_tables)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    int rc = check_planes("kbbq_accumulate_dev", nreads, pitch, d_seq, d_cseq, d_qual);
+    if (rc) return rc;
+    if (R <= 0 || R > 32767) return fail(KBBQ_E_ARG, "kbbq_accumulate_dev: R out of range (%d)", R);
+    if (S2 <= 0 || (S2 & 1)) return fail(KBBQ_E_ARG, "kbbq_accumulate_dev: S2 must be positive and even (%d)", S2);
+    if (minscore < 0 || minscore > KQ - 1) return fail(KBBQ_E_ARG, "kbbq_accumulate_dev: minscore out of range (%d)", minscore);
+    if (dinuc_minscore < 0 || dinuc_minscore > 222) return fail(KBBQ_E_ARG, "kbbq_accumulate_dev: dinuc_minscore out of range (%d)", dinuc_minscore);
+    if (nreads == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+
+    K1Params p;
+    p.seq = d_seq; p.cseq = d_cseq; p.qual = d_qual; p.meta = d_meta;
+    p.nreads = nreads; p.pitch = pitch; p.cpr = pitch / 16; p.cpr_magic = magic_for(p.cpr);
+    p.R = R; p.S2 = S2; p.minscore = dinuc_minscore;   // the TypeError rule follows the dinucleotide threshold
+    p.qlo = 33u + (u32)minscore; p.dlo = 33u + (u32)dinuc_minscore;
+    p.pos_stride = S2 | 1;                         // odd row stride spreads q rows over the banks
+    p.tables = reinterpret_cast<u64*>(d_tables); p.status = c->d_status;
+    const size_t lds = ((size_t)(((KQ * p.pos_stride) + 1) & ~1)) * 4 + (size_t)KQ * KND * 8;
+    if (lds > (size_t)c->lds_bytes)
+        return fail(KBBQ_E_ARG, "kbbq_accumulate_dev: reads of %d bases need %zu B of LDS (> %d)", S2 / 2, lds, c->lds_bytes);
+    int per_cu = std::min<int>((int)(c->lds_bytes / lds), 2048 / K1_THREADS);
+    per_cu = std::max(per_cu, 1);
+    const int64_t nblocks = (nreads + 63) / 64;
+    const int64_t iters = (nblocks + (K1_THREADS / 64) - 1) / (K1_THREADS / 64);
+    int gx = (int)std::min<int64_t>(iters, std::max(1, c->cus * per_cu / R));
+    dim3 grid((unsigned)gx, (unsigned)R, 1), block(K1_THREADS, 1, 1);
+    {
+        Timed t(c, 0);
+        if (dinuc_minscore > minscore) hipLaunchKernelGGL(k1_accumulate<true>, grid, block, lds, c->stream, p);
+        else hipLaunchKernelGGL(k1_accumulate<false>, grid, block, lds, c->stream, p);
+    }
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta,
+                   int64_t nreads, int pitch, int R, int Qt, int S2, int minscore,
+                   const int16_t* d_lut, uint8_t* d_out)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    int rc = check_planes("kbbq_apply_dev", nreads, pitch, d_seq, d_qual, d_out);
+    if (rc) return rc;
+    if (R <= 0 || Qt <= 0 || Qt > 223 || S2 <= 0) return fail(KBBQ_E_ARG, "kbbq_apply_dev: bad table shape R=%d Qt=%d S2=%d", R, Qt, S2);
+    if (minscore < 0) return fail(KBBQ_E_ARG, "kbbq_apply_dev: minscore < 0");
+    if (nreads == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+
+    K2Params p;
+    p.seq = d_seq; p.qual = d_qual; p.meta = d_meta; p.nreads = nreads; p.pitch = pitch;
+    p.cpr = pitch / 16; p.cpr_magic = magic_for(p.cpr);
+    p.R = R; p.Qt = Qt; p.S2 = S2; p.minscore = minscore; p.qlo = 33u + (u32)minscore;
+    p.lut = d_lut; p.lut_count = (int)kbbq_lut_count(R, Qt, S2);
+    p.out = d_out; p.status = c->d_status;
+    const size_t lut_bytes = (size_t)p.lut_count * 2;
+    // keep at least 2 workgroups per CU when staging the LUT in LDS
+    p.lut_in_lds = lut_bytes <= (size_t)c->lds_bytes / 2 ? 1 : 0;
+    const size_t lds = p.lut_in_lds ? lut_bytes : 0;
+    int per_cu = p.lut_in_lds ? std::min<int>((int)(c->lds_bytes / std::max<size_t>(lds, 1)), 2048 / K2_THREADS) : 2048 / K2_THREADS;
+    per_cu = std::max(per_cu, 1);
+    const int64_t nblocks = (nreads + 63) / 64;
+    const int64_t want = (nblocks + (K2_THREADS / 64) - 1) / (K2_THREADS / 64);
+    int gx = (int)std::min<int64_t>(want, (int64_t)c->cus * per_cu);
+    dim3 grid((unsigned)std::max(gx, 1), 1, 1), block(K2_THREADS, 1, 1);
+    {
+        Timed t(c, 1);
+        hipLaunchKernelGGL(k2_apply, grid, block, lds, c->stream, p);
+    }
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+int kbbq_build_lut(int R, int Qt, int S2, int D, const int64_t* meanq, const int64_t* rgdq,
+                   const int64_t* qdq, const int64_t* posdq, const int64_t* dinucdq, int16_t* out)
+{
+    // D = 17 is what get_delta_qs returns (applybqsr.py:98-101); D = 16 is accepted because the
+    // reference's own apply test passes an unpadded table (index -1 then aliases column 15)
+    if (R <= 0 || Qt <= 0 || S2 <= 0 || D < 16 || D > 17)
+        return fail(KBBQ_E_ARG, "kbbq_build_lut: bad shape R=%d Qt=%d S2=%d D=%d", R, Qt, S2, D);
+    int16_t* l1 = out;
+    int16_t* l2 = out + (size_t)R * Qt * S2;
+    for (int r = 0; r < R; ++r)
+        for (int q = 0; q < Qt; ++q) {
+            const size_t cell = (size_t)r * Qt + q;
+            const int64_t base = meanq[r] + rgdq[r] + qdq[cell];
+            for (int s = 0; s < S2; ++s) {
+                const int64_t v = base + posdq[cell * S2 + s];
+                if (v < -32768 || v > 32767) return fail(KBBQ_E_RANGE, "kbbq_build_lut: value %lld does not fit the LUT", (long long)v);
+                l1[cell * S2 + s] = (int16_t)v;
+            }
+            // Python index d (0..15) and -1 on a D-column table: column 16 of the LUT is "index -1"
+            for (int d = 0; d < 17; ++d) {
+                int64_t v;
+                if (d < 16) v = dinucdq[cell * D + d];
+                else v = dinucdq[cell * D + (D - 1)];
+                if (v < -32768 || v > 32767) return fail(KBBQ_E_RANGE, "kbbq_build_lut: value %lld does not fit the LUT", (long long)v);
+                l2[cell * 17 + d] = (int16_t)v;
+            }
+        }
+    if (kbbq_lut_count(R, Qt, S2) > (size_t)R * Qt * ((size_t)S2 + 17)) out[kbbq_lut_count(R, Qt, S2) - 1] = 0;
+    return KBBQ_OK;
+}
+
+int kbbq_synth_dev(kbbq_ctx* c, uint8_t* d_seq, uint8_t* d_cseq, uint8_t* d_qual, uint32_t* d_meta,
+                   int64_t first, int64_t nreads, int64_t total, int pitch, uint64_t seed,
+                   int len_lo, int len_hi, int nrg, int qlo, int qhi, const uint32_t* thr43)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    int rc = check_planes("kbbq_synth_dev", nreads, pitch, d_seq, d_cseq, d_qual);
+    if (rc) return rc;
+    if (len_lo < 0 || len_hi < len_lo || len_hi > pitch || nrg <= 0 || nrg > 32767 || qlo < 0 || qhi < qlo || qhi >= KQ || total <= 0)
+        return fail(KBBQ_E_ARG, "kbbq_synth_dev: bad shape");
+    if (nreads == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    KSParams p;
+    p.seq = d_seq; p.cseq = d_cseq; p.qual = d_qual; p.meta = d_meta;
+    p.first = first; p.nreads = nreads; p.total = total; p.pitch = pitch; p.cpr = pitch / 16;
+    p.seed = seed; p.len_lo = len_lo; p.len_hi = len_hi; p.nrg = nrg; p.qlo = qlo; p.qhi = qhi;
+    memcpy(p.thr, thr43, sizeof p.thr);
+    const int64_t nchunks = nreads * p.cpr;
+    int gx = (int)std::min<int64_t>((nchunks + 255) / 256, (int64_t)c->cus * 8);
+    hipLaunchKernelGGL(ks_synth, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+// ---- host-buffer entry points: stage, run, fetch -------------------------
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+};
+
+int kbbq_accumulate(kbbq_ctx* c, const uint8_t* seq, const uint8_t* cseq, const uint8_t* qual,
+                    const uint32_t* meta, int64_t nreads, int pitch, int R, int S2, int minscore,
+                    int64_t* pos_errs, int64_t* pos_total, int64_t* dinuc_errs, int64_t* dinuc_total)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (nreads < 0 || pitch <= 0 || (pitch & 15)) return fail(KBBQ_E_ARG, "kbbq_accumulate: bad nreads/pitch");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t plane = (size_t)nreads * pitch;
+    const size_t npos = (size_t)R * KQ * S2, ndn = (size_t)R * KQ * KND;
+    DevBuf ds, dc, dq, dm, dt;
+    HIPCHK(ds.alloc(plane)); HIPCHK(dc.alloc(plane)); HIPCHK(dq.alloc(plane));
+    HIPCHK(dm.alloc((size_t)nreads * 4)); HIPCHK(dt.alloc(kbbq_tables_count(R, S2) * 8));
+    HIPCHK(hipMemcpyAsync(ds.p, seq, plane, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dc.p, cseq, plane, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dq.p, qual, plane, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dm.p, meta, (size_t)nreads * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(dt.p, 0, kbbq_tables_count(R, S2) * 8, c->stream));
+    int rc = kbbq_accumulate_dev(c, (const uint8_t*)ds.p, (const uint8_t*)dc.p, (const uint8_t*)dq.p,
+                                 (const uint32_t*)dm.p, nreads, pitch, R, S2, minscore, (int64_t*)dt.p);
+    if (rc) return rc;
+    rc = kbbq_ctx_status(c, nullptr);
+    if (rc) return rc;
+    std::vector<int64_t> h(kbbq_tables_count(R, S2));
+    HIPCHK(hipMemcpyAsync(h.data(), dt.p, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < npos; ++i) { pos_errs[i] += h[i]; pos_total[i] += h[npos + i]; }
+    for (size_t i = 0; i < ndn; ++i) { dinuc_errs[i] += h[2 * npos + i]; dinuc_total[i] += h[2 * npos + ndn + i]; }
+    return KBBQ_OK;
+}
+
+int kbbq_apply(kbbq_ctx* c, const uint8_t* seq, const uint8_t* qual, const uint32_t* meta,
+               int64_t nreads, int pitch, int R, int Qt, int S2, int D, int minscore,
+               const int64_t* meanq, const int64_t* rgdq, const int64_t* qdq,
+               const int64_t* posdq, const int64_t* dinucdq, uint8_t* qual_out)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (nreads < 0 || pitch <= 0 || (pitch & 15)) return fail(KBBQ_E_ARG, "kbbq_apply: bad nreads/pitch");
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<int16_t> lut(kbbq_lut_count(R, Qt, S2));
+    int rc = kbbq_build_lut(R, Qt, S2, D, meanq, rgdq, qdq, posdq, dinucdq, lut.data());
+    if (rc) return rc;
+    const size_t plane = (size_t)nreads * pitch;
+    DevBuf ds, dq, dm, dl, dout;
+    HIPCHK(ds.alloc(plane)); HIPCHK(dq.alloc(plane)); HIPCHK(dout.alloc(plane));
+    HIPCHK(dm.alloc((size_t)nreads * 4)); HIPCHK(dl.alloc(lut.size() * 2));
+    HIPCHK(hipMemcpyAsync(ds.p, seq, plane, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dq.p, qual, plane, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dm.p, meta, (size_t)nreads * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dl.p, lut.data(), lut.size() * 2, hipMemcpyHostToDevice, c->stream));
+    rc = kbbq_apply_dev(c, (const uint8_t*)ds.p, (const uint8_t*)dq.p, (const uint32_t*)dm.p, nreads, pitch,
+                        R, Qt, S2, minscore, (const int16_t*)dl.p, (uint8_t*)dout.p);
+    if (rc) return rc;
+    rc = kbbq_ctx_status(c, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(qual_out, dout.p, plane, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KBBQ_OK;
+}
+
+} // extern "C"

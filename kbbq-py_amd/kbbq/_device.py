@@ -1,0 +1,155 @@
+"""
+Device plumbing for the hot path: contexts, device-resident read batches and
+count tables.  PyTorch provides device memory, streams and (in parallel.py) the
+RCCL process group; every computation is a libkbbq_hip kernel reached through
+the C ABI (kbbq._native).  No CPU fallback exists.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native as N
+
+MINSCORE = 6
+MAXSCORE = 42
+NQ = MAXSCORE + 1
+
+_contexts = {}
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise N.KbbqHipError('torch sees no GPU: kbbq needs an MI355X (gfx950); there is no CPU fallback')
+    return torch
+
+
+def context(device=None):
+    """The process-wide kbbq context of a device, bound to torch's current stream."""
+    torch = _torch()
+    if device is None:
+        device = torch.cuda.current_device()
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = N.Context(device)
+        _contexts[device] = ctx
+    ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+    return ctx
+
+
+class Tables:
+    """The four count arrays of recalibrate.py:51-54 as ONE int64 device buffer
+    [pos_errs | pos_total | dinuc_errs | dinuc_total] (see include/kbbq_hip.h)."""
+
+    def __init__(self, R, S2, device=None):
+        torch = _torch()
+        self.R, self.S2 = int(R), int(S2)
+        n = N.load().kbbq_tables_count(self.R, self.S2)
+        self.buf = torch.zeros(n, dtype=torch.int64, device='cuda' if device is None else device)
+
+    def views(self):
+        R, S2 = self.R, self.S2
+        npos, ndn = R * NQ * S2, R * NQ * 16
+        b = self.buf
+        return (b[:npos].view(R, NQ, S2), b[npos:2 * npos].view(R, NQ, S2),
+                b[2 * npos:2 * npos + ndn].view(R, NQ, 16), b[2 * npos + ndn:].view(R, NQ, 16))
+
+    def to_host(self):
+        """(pos_errs, pos_total, dinuc_errs, dinuc_total) as fresh int64 numpy arrays."""
+        h = self.buf.cpu().numpy()
+        R, S2 = self.R, self.S2
+        npos, ndn = R * NQ * S2, R * NQ * 16
+        return (h[:npos].reshape(R, NQ, S2).copy(), h[npos:2 * npos].reshape(R, NQ, S2).copy(),
+                h[2 * npos:2 * npos + ndn].reshape(R, NQ, 16).copy(),
+                h[2 * npos + ndn:].reshape(R, NQ, 16).copy())
+
+
+class ReadBatch:
+    """Device-resident padded SoA of reads: seq / cseq / qual planes [n, pitch] uint8
+    and the uint32 sidecar (layout: include/kbbq_hip.h)."""
+
+    def __init__(self, n, pitch, with_corrected=True, device=None):
+        torch = _torch()
+        dev = 'cuda' if device is None else device
+        self.n, self.pitch = int(n), int(pitch)
+        rows = max(self.n, 1)
+        self.seq = torch.empty((rows, pitch), dtype=torch.uint8, device=dev)
+        self.qual = torch.empty((rows, pitch), dtype=torch.uint8, device=dev)
+        self.cseq = torch.empty((rows, pitch), dtype=torch.uint8, device=dev) if with_corrected else None
+        self.meta = torch.empty(rows, dtype=torch.int32, device=dev)
+
+    @classmethod
+    def from_host(cls, seq, qual, meta, cseq=None, device=None):
+        torch = _torch()
+        n, pitch = seq.shape
+        b = cls(n, pitch, with_corrected=cseq is not None, device=device)
+        if n:
+            b.seq[:n].copy_(torch.from_numpy(np.ascontiguousarray(seq)))
+            b.qual[:n].copy_(torch.from_numpy(np.ascontiguousarray(qual)))
+            if cseq is not None:
+                b.cseq[:n].copy_(torch.from_numpy(np.ascontiguousarray(cseq)))
+            b.meta[:n].copy_(torch.from_numpy(np.ascontiguousarray(meta).view(np.int32)))
+        return b
+
+    @classmethod
+    def synthetic(cls, first, n, total, seed, len_lo=150, len_hi=150, nrg=1, qlo=0, qhi=41,
+                  pitch=None, device=None):
+        """Synthetic reads generated on the device (spec in oracle/kbbq_oracle.c)."""
+        from ._synth import SYNTH_THR
+        if pitch is None:
+            pitch = max(16, (len_hi + 15) // 16 * 16)
+        b = cls(n, pitch, with_corrected=True, device=device)
+        ctx = context(b.seq.device.index)
+        N.check(N.load().kbbq_synth_dev(ctx.handle, N.ptr(b.seq), N.ptr(b.cseq), N.ptr(b.qual),
+                                        N.ptr(b.meta), first, n, total, pitch, seed,
+                                        len_lo, len_hi, nrg, qlo, qhi, N.ptr(SYNTH_THR)))
+        return b
+
+    def lengths_host(self):
+        return (self.meta[:self.n].cpu().numpy().view(np.uint32) & 0xFFFF).astype(np.int64)
+
+
+def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None):
+    """K1 over a device batch, adding into `tables` (recalibrate.py:57-119)."""
+    ctx = context(batch.seq.device.index)
+    N.check(N.load().kbbq_accumulate_ex_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq),
+                                            N.ptr(batch.qual), N.ptr(batch.meta), batch.n, batch.pitch,
+                                            tables.R, tables.S2, minscore,
+                                            minscore if dinuc_minscore is None else dinuc_minscore,
+                                            N.ptr(tables.buf)))
+    if check:
+        ctx.status()
+
+
+def build_lut(meanq, rgdq, qdq, posdq, dinucdq):
+    """Fold the five model arrays into the int16 apply LUT (host, tiny)."""
+    a = [np.ascontiguousarray(np.asarray(x), dtype=np.int64) for x in (meanq, rgdq, qdq, posdq, dinucdq)]
+    if a[3].ndim != 3 or a[4].ndim != 3:
+        raise ValueError('positiondeltaq / dinucdeltaq must be 3-d')
+    R, Qt, S2 = a[3].shape
+    D = a[4].shape[2]
+    if a[0].shape != (R,) or a[1].shape != (R,) or a[2].shape != (R, Qt) or a[4].shape[:2] != (R, Qt):
+        raise IndexError('delta-Q tables have inconsistent shapes')
+    lut = np.zeros(N.load().kbbq_lut_count(R, Qt, S2), dtype=np.int16)
+    N.check(N.load().kbbq_build_lut(R, Qt, S2, D, N.ptr(a[0]), N.ptr(a[1]), N.ptr(a[2]), N.ptr(a[3]),
+                                    N.ptr(a[4]), N.ptr(lut)))
+    return lut, (R, Qt, S2)
+
+
+def apply(batch, lut_dev, shape, out=None, minscore=MINSCORE, check=True):
+    """K2 over a device batch: new quality bytes [n, pitch] (compare_reads.py:320-328)."""
+    torch = _torch()
+    R, Qt, S2 = shape
+    ctx = context(batch.seq.device.index)
+    if out is None:
+        out = torch.empty_like(batch.qual)
+    N.check(N.load().kbbq_apply_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.qual), N.ptr(batch.meta),
+                                    batch.n, batch.pitch, R, Qt, S2, minscore, N.ptr(lut_dev), N.ptr(out)))
+    if check:
+        ctx.status()
+    return out
+
+
+def lut_to_device(lut, device=None):
+    torch = _torch()
+    return torch.from_numpy(lut).to('cuda' if device is None else device)

@@ -1,0 +1,173 @@
+"""
+ctypes binding of libkbbq_hip.so (C ABI: include/kbbq_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or cannot be loaded,
+or no gfx950 device is present when a context is requested, the error is raised
+to the caller.  Build the library with ``make -C kbbq-py_amd/csrc`` (or
+``python -c "import __graft_entry__ as g; g.build()"`` from the repo root).
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libkbbq_hip.so')
+
+KBBQ_OK = 0
+KBBQ_E_HIP = -1
+KBBQ_E_INDEX = -2
+KBBQ_E_TYPE = -3
+KBBQ_E_ARG = -4
+KBBQ_E_RANGE = -5
+KBBQ_E_NAME = -6
+
+NQ = 43
+NDINUC = 16
+
+_c = ctypes
+_vp, _i, _i64, _u64, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_uint64, _c.c_size_t
+
+# name -> (restype, argtypes); every symbol include/kbbq_hip.h declares
+PROTOTYPES = {
+    'kbbq_abi_version': (_i, []),
+    'kbbq_last_error': (_c.c_char_p, []),
+    'kbbq_device_count': (_i, [_c.POINTER(_i)]),
+    'kbbq_ctx_create': (_i, [_i, _c.POINTER(_vp)]),
+    'kbbq_ctx_destroy': (_i, [_vp]),
+    'kbbq_ctx_set_stream': (_i, [_vp, _vp]),
+    'kbbq_ctx_sync': (_i, [_vp]),
+    'kbbq_ctx_status': (_i, [_vp, _c.POINTER(_i64)]),
+    'kbbq_ctx_info': (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.c_char_p, _i]),
+    'kbbq_dev_alloc': (_i, [_vp, _sz, _c.POINTER(_vp)]),
+    'kbbq_dev_free': (_i, [_vp, _vp]),
+    'kbbq_dev_zero': (_i, [_vp, _vp, _sz]),
+    'kbbq_dev_upload': (_i, [_vp, _vp, _vp, _sz]),
+    'kbbq_dev_download': (_i, [_vp, _vp, _vp, _sz]),
+    'kbbq_tables_count': (_sz, [_i, _i]),
+    'kbbq_lut_count': (_sz, [_i, _i, _i]),
+    'kbbq_accumulate_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
+    'kbbq_accumulate_ex_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
+    'kbbq_accumulate': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'kbbq_build_lut': (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'kbbq_apply_dev': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
+    'kbbq_apply': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i,
+                        _vp, _vp, _vp, _vp, _vp, _vp]),
+    'kbbq_synth_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _u64,
+                            _i, _i, _i, _i, _i, _vp]),
+    'kbbq_ctx_timing': (_i, [_vp, _i]),
+    'kbbq_ctx_kernel_ms': (_i, [_vp, _i, _c.POINTER(_c.c_double), _c.POINTER(_i64), _i]),
+}
+
+_lib = None
+
+
+class KbbqHipError(RuntimeError):
+    """A HIP runtime failure or a bad argument reported by libkbbq_hip."""
+
+
+def load():
+    """dlopen libkbbq_hip.so and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libkbbq_hip.so is not built (%s).  Run `make -C kbbq-py_amd/csrc`; '
+            'this package has no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.kbbq_abi_version() != 1:
+        raise ImportError('libkbbq_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load().kbbq_last_error()
+    return msg.decode('utf-8', 'replace') if msg else ''
+
+
+def check(rc):
+    """Map a C return code to the exception the reference raises in that situation."""
+    if rc == KBBQ_OK:
+        return
+    msg = last_error()
+    if rc == KBBQ_E_INDEX:
+        raise IndexError(msg)
+    if rc == KBBQ_E_TYPE:
+        raise TypeError(msg)
+    if rc == KBBQ_E_RANGE:
+        raise ValueError(msg)
+    if rc == KBBQ_E_NAME:
+        raise AssertionError(msg)
+    if rc == KBBQ_E_ARG:
+        raise ValueError(msg)
+    raise KbbqHipError(msg or ('libkbbq_hip error %d' % rc))
+
+
+def ptr(x):
+    """Device or host address of a torch tensor / numpy array / int / None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return ctypes.c_void_p(x)
+    if hasattr(x, 'data_ptr'):
+        return ctypes.c_void_p(x.data_ptr())
+    return ctypes.c_void_p(x.ctypes.data)
+
+
+class Context:
+    """One per device (kbbq_ctx).  Not thread-safe."""
+
+    def __init__(self, device=0):
+        lib = load()
+        n = ctypes.c_int(0)
+        rc = lib.kbbq_device_count(ctypes.byref(n))
+        if rc != KBBQ_OK or n.value == 0:
+            raise KbbqHipError('no HIP device available (%s); kbbq needs an MI355X (gfx950) -- '
+                               'there is no CPU fallback' % last_error())
+        h = ctypes.c_void_p()
+        check(lib.kbbq_ctx_create(device, ctypes.byref(h)))
+        self._h = h
+        self.device = device
+        cus, lds = ctypes.c_int(0), ctypes.c_int(0)
+        name = ctypes.create_string_buffer(128)
+        check(lib.kbbq_ctx_info(h, ctypes.byref(cus), ctypes.byref(lds), name, 128))
+        self.compute_units, self.lds_bytes = cus.value, lds.value
+        self.name = name.value.decode()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, '_h', None):
+            load().kbbq_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        check(load().kbbq_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def sync(self):
+        check(load().kbbq_ctx_sync(self._h))
+
+    def status(self):
+        """Raise the error the reference would have raised, if a kernel flagged one."""
+        idx = ctypes.c_int64(-1)
+        check(load().kbbq_ctx_status(self._h, ctypes.byref(idx)))
+
+    def timing(self, enable):
+        check(load().kbbq_ctx_timing(self._h, 1 if enable else 0))
+
+    def kernel_ms(self, which, reset=False):
+        ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
+        check(load().kbbq_ctx_kernel_ms(self._h, which, ctypes.byref(ms), ctypes.byref(n), 1 if reset else 0))
+        return ms.value, n.value

@@ -1,0 +1,230 @@
+"""
+FASTQ text <-> padded SoA planes (host side of the hot path).
+
+pysam is not available on either box, so this module stands in for the two
+things the reference uses it for on this path: iterating FASTQ records
+(recalibrate.py:56-57,141-142) and the record type itself (``.name``,
+``.sequence``, ``.quality``, ``.comment``, ``.get_quality_array()``).  ``name`` is
+the header up to the first whitespace, as pysam/kseq define it -- the reference
+prints it without the comment (recalibrate.py:153).
+
+`pack_pair` turns the two files into the device layout documented in
+include/kbbq_hip.h and performs the host-side checks the reference performs
+while it reads: name prefix (recalibrate.py:17), read-group inference in
+first-appearance order (recalibrate.py:59-64, compare_reads.py:308-318),
+second-in-pair (compare_reads.py:304-306) and the shorter-than-running-max
+IndexError (recalibrate.py:89-101).
+"""
+import numpy as np
+
+
+class FastxRecord:
+    """Duck-type of pysam.FastxRecord (see reference tests/test_compare_reads.py:15-24)."""
+
+    def __init__(self, name=None, sequence=None, quality=None, comment=None):
+        self.name = name
+        self.sequence = sequence
+        self.quality = quality
+        self.comment = comment
+
+    def get_quality_array(self, offset=33):
+        return [ord(c) - offset for c in self.quality]
+
+    def __str__(self):
+        return '@%s\n%s\n+\n%s' % (self.name, self.sequence, self.quality)
+
+
+class FastqText:
+    """A whole 4-line-per-record FASTQ file held as bytes plus line offsets."""
+
+    def __init__(self, path):
+        with open(path, 'rb') as fh:
+            self.buf = np.frombuffer(fh.read(), dtype=np.uint8)
+        nl = np.flatnonzero(self.buf == 10)
+        if self.buf.size and (nl.size == 0 or nl[-1] != self.buf.size - 1):
+            nl = np.append(nl, self.buf.size)          # last line without '\n'
+        if nl.size % 4 != 0:
+            raise ValueError('%s: not a 4-line-per-record FASTQ file' % path)
+        starts = np.empty(nl.size, dtype=np.int64)
+        if nl.size:
+            starts[0] = 0
+            starts[1:] = nl[:-1] + 1
+        ends = nl.astype(np.int64)
+        # tolerate CRLF
+        cr = (ends > starts) & (self.buf[np.maximum(ends - 1, 0)] == 13)
+        ends = ends - cr
+        self.n = nl.size // 4
+        self.h0, self.h1 = starts[0::4], ends[0::4]
+        self.s0, self.s1 = starts[1::4], ends[1::4]
+        self.q0, self.q1 = starts[3::4], ends[3::4]
+        if self.n and not np.all(self.buf[self.h0] == ord('@')):
+            raise ValueError('%s: record header does not start with @' % path)
+        if np.any((self.q1 - self.q0) != (self.s1 - self.s0)):
+            raise ValueError('%s: sequence and quality lengths differ' % path)
+
+    def names(self):
+        b = self.buf.tobytes()
+        out = []
+        for a, e in zip(self.h0.tolist(), self.h1.tolist()):
+            f = b[a + 1:e].split(None, 1)
+            out.append(f[0].decode('ascii') if f else '')
+        return out
+
+    def lengths(self):
+        return (self.s1 - self.s0).astype(np.int64)
+
+    def records(self):
+        b = self.buf.tobytes()
+        for i in range(self.n):
+            head = b[self.h0[i] + 1:self.h1[i]].split(None, 1)
+            yield FastxRecord(head[0].decode('ascii') if head else '',
+                              b[self.s0[i]:self.s1[i]].decode('ascii'),
+                              b[self.q0[i]:self.q1[i]].decode('ascii'),
+                              head[1].decode('ascii') if len(head) > 1 else None)
+
+    def plane(self, which, n, pitch):
+        """Rows [0, n) of the seq ('s') or qual ('q') lines as a zero-padded [n, pitch] plane."""
+        a0 = (self.s0 if which == 's' else self.q0)[:n]
+        lens = (self.s1 - self.s0)[:n]
+        out = np.zeros((n, pitch), dtype=np.uint8)
+        if n == 0:
+            return out
+        if np.all(lens == lens[0]) and n > 1 and np.all(np.diff(a0) == a0[1] - a0[0]):
+            # uniform records: one strided view, no index arrays
+            L = int(lens[0]); stride = int(a0[1] - a0[0])
+            view = np.lib.stride_tricks.as_strided(self.buf[int(a0[0]):], shape=(n, L), strides=(stride, 1))
+            out[:, :L] = view
+            return out
+        total = int(lens.sum())
+        row = np.repeat(np.arange(n, dtype=np.int64), lens)
+        first = np.cumsum(lens) - lens
+        col = np.arange(total, dtype=np.int64) - np.repeat(first, lens)
+        out[row, col] = self.buf[np.repeat(a0, lens) + col]
+        return out
+
+
+class FastxFile:
+    """Context-manager iterator over records, pysam.FastxFile style."""
+
+    def __init__(self, path):
+        self._text = FastqText(path)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def __iter__(self):
+        return self._text.records()
+
+
+def infer_second(name):
+    """compare_reads.py:304-306."""
+    return name.split(sep='_')[0][-2:] == '/2'
+
+
+def infer_rg(name):
+    """compare_reads.py:308-318."""
+    rgstr = name.split(sep='_')[1]
+    assert rgstr[0:2] == 'RG'
+    return rgstr.split(':')[-1]
+
+
+def make_meta(names, lens, infer_rg_flag, rg_to_int=None):
+    """uint32 sidecar (len | rg << 16 | second << 31); RG ids in first-appearance order.
+    Returns (meta, rg_to_int, error) where error = (index, exception) for the first read
+    whose read group cannot be inferred (meta is then only valid before that read)."""
+    rg_to_int = {} if rg_to_int is None else rg_to_int
+    meta = np.zeros(len(names), dtype=np.uint32)
+    for i, nm in enumerate(names):
+        try:
+            rg = infer_rg(nm) if infer_rg_flag else 0
+        except (IndexError, AssertionError) as exc:
+            return meta, rg_to_int, (i, exc)
+        r = rg_to_int.setdefault(rg, len(rg_to_int))
+        meta[i] = int(lens[i]) | (r << 16) | (int(infer_second(nm)) << 31)
+    return meta, rg_to_int, None
+
+
+def pitch_for(maxlen):
+    return max(16, (int(maxlen) + 15) // 16 * 16)
+
+
+def pack_pair(path_a, path_b, infer_rg_flag):
+    """Pass-1 input: reads of file A zipped with file B (recalibrate.py:56-57).
+
+    Host-detectable input errors do not raise here: the reference fails at the FIRST
+    offending read, and a device-detected error (TypeError / IndexError) on an earlier
+    read must win.  They are returned as ``pending_error = (index, exception, inclusive)``
+    -- the caller tallies reads [0, index) (or [0, index] when `inclusive`: the read's own
+    device checks precede the host one) and then raises.  Order inside one read, as in
+    recalibrate.py:59-119: read-group inference, name prefix, sequence lengths,
+    [device: alphabet], shorter-than-running-max, [device: q > 42]."""
+    A, B = FastqText(path_a), FastqText(path_b)
+    n = min(A.n, B.n)                                   # zip() truncates
+    names_a, names_b = A.names(), B.names()
+    lens = A.lengths()[:n]
+    meta, rg_to_int, rg_err = make_meta(names_a[:n], lens, infer_rg_flag)
+    cands = []
+    if rg_err is not None:
+        cands.append((rg_err[0], 0, rg_err[1]))
+    for i in range(n):
+        if not names_b[i].startswith(names_a[i]):
+            cands.append((i, 1, AssertionError('corrected read %r does not start with %r'
+                                               % (names_b[i], names_a[i]))))
+            break
+    mism = np.flatnonzero((B.s1 - B.s0)[:n] != lens)
+    if mism.size:
+        cands.append((int(mism[0]), 2, ValueError(
+            'operands could not be broadcast together: read %d and its correction differ in length' % mism[0])))
+    runmax = np.maximum.accumulate(lens) if n else lens
+    short = np.flatnonzero(lens < runmax)
+    if short.size:
+        cands.append((int(short[0]), 4, IndexError(
+            'boolean index did not match indexed array: read %d is shorter than an earlier read '
+            '(reference recalibrate.py:89-101)' % short[0])))
+    pending = None
+    if cands:
+        idx, order, exc = min(cands, key=lambda c: (c[0], c[1]))
+        pending = (idx, exc, order == 4)
+        n = idx + (1 if order == 4 else 0)
+        lens = lens[:n]
+        meta = meta[:n]
+    S = int(lens.max()) if n else 0
+    pitch = pitch_for(S)
+    R = (int(((meta >> 16) & 0x7FFF).max()) + 1) if n else 0
+    return dict(seq=A.plane('s', n, pitch), cseq=B.plane('s', n, pitch), qual=A.plane('q', n, pitch),
+                meta=meta, n=n, pitch=pitch, S=S, R=R, rg_to_int=rg_to_int,
+                names=names_a, text=A, pending_error=pending)
+
+
+def pack_single(text, infer_rg_flag):
+    """Pass-2 input: every read of file A with its own first-appearance RG map
+    (recalibrate.py:141-148)."""
+    names = text.names()
+    lens = text.lengths()
+    meta, rg_to_int, err = make_meta(names, lens, infer_rg_flag)
+    if err is not None:
+        raise err[1]
+    S = int(lens.max()) if text.n else 0
+    pitch = pitch_for(S)
+    return dict(seq=text.plane('s', text.n, pitch), qual=text.plane('q', text.n, pitch), meta=meta,
+                n=text.n, pitch=pitch, S=S, R=len(rg_to_int), names=names)
+
+
+def format_fastq(names, seq_plane, qual_plane, lens):
+    """recalibrate.py:153-156: '@'+name, sequence, '+', qualities -- one str."""
+    n = len(names)
+    if n == 0:
+        return ''
+    parts = []
+    sb = seq_plane.tobytes()
+    qb = qual_plane.tobytes()
+    pitch = seq_plane.shape[1]
+    for i in range(n):
+        L = int(lens[i])
+        o = i * pitch
+        parts.append('@' + names[i] + '\n' + sb[o:o + L].decode('latin-1') + '\n+\n'
+                     + qb[o:o + L].decode('latin-1') + '\n')
+    return ''.join(parts)

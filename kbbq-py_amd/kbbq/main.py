@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""
+kbbq command line -- the `recalibrate` sub-command of the reference CLI
+(reference kbbq/main.py:26-89).  `benchmark` and `plot` are out of scope here.
+"""
+import argparse
+
+from . import __version__
+from . import recalibrate as _recal
+
+
+def recalibrate(args):
+    _recal.recalibrate(bam=args.bam, fastq=args.fastq, infer_rg=args.infer_rg,
+                       use_oq=args.use_oq, set_oq=args.set_oq, gatkreport=args.gatkreport)
+
+
+def main():
+    parser = argparse.ArgumentParser(description='K-mer Based Base Quality score recalibration (MI355X build)')
+    parser.add_argument('-v', '--version', action='version', version=__version__)
+    sub = parser.add_subparsers(title='command', description='valid commands')
+    parser.set_defaults(command=lambda a: parser.print_help)
+    sub.add_parser('help', description='Print help information').set_defaults(
+        command=lambda a: parser.print_help)
+
+    rp = sub.add_parser('recalibrate', description='Recalibrate a BAM or FASTQ file')
+    src = rp.add_mutually_exclusive_group(required=True)
+    src.add_argument('-b', '--bam', help='BAM to recalibrate')
+    src.add_argument('-f', '--fastq', nargs=2,
+                     help='FASTQ file to recalibrate and an error-corrected version of it.')
+    rp.add_argument('-u', '--use-oq', action='store_true',
+                    help='Use the OQ tag for quality scores (BAM input only).')
+    rp.add_argument('-s', '--set-oq', action='store_true',
+                    help="Set the 'OQ' tag before recalibration (BAM output only).")
+    rp.add_argument('-g', '--gatkreport', help='Load the model from / save it to a GATK report.')
+    rp.add_argument('--infer-rg', action='store_true',
+                    help='Infer the read group from the FASTQ read name (name_RG:Z:id).')
+    rp.set_defaults(command=recalibrate)
+
+    args = parser.parse_args()
+    args.command(args)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,107 @@
+"""
+kbbq.recalibrate -- drop-in for the reference module of the same name
+(reference kbbq/recalibrate.py:13-174), with both per-read Python loops replaced
+by HIP kernels on an MI355X:
+
+    pass 1  fastq_to_covariate_arrays  -> K1 (error flagging + covariate binning)
+    model   applybqsr.get_delta_qs     -> host, same SciPy call as the reference
+    pass 2  recalibrate_fastq          -> K2 (delta-Q LUT apply), FASTQ text to stdout
+
+Behaviour kept: argument names and defaults, the 9-tuple order, int64 arrays
+owned by the caller, output through print(), and the exceptions the reference
+raises on bad input (AssertionError, IndexError, TypeError, NotImplementedError,
+ValueError -- SURVEY.md 8(b)).
+"""
+import numpy as np
+
+from . import compare_reads as utils
+from . import fastx
+from . import _device as dev
+from .gatk import applybqsr
+
+
+def find_corrected_sites(uncorr_read, corr_read):
+    """Boolean array, True where the corrected sequence differs from the original."""
+    assert corr_read.name.startswith(uncorr_read.name)
+    a = np.frombuffer(uncorr_read.sequence.encode('utf-32-le'), dtype=np.uint32)
+    b = np.frombuffer(corr_read.sequence.encode('utf-32-le'), dtype=np.uint32)
+    if a.shape != b.shape:
+        raise ValueError('operands could not be broadcast together with shapes %s %s' % (a.shape, b.shape))
+    return a != b
+
+
+def _vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore):
+    """q_* and rg_* are marginals of pos_* (every counted base has exactly one cycle);
+    meanq comes from the per-score totals in longdouble."""
+    q_errs, q_total = pos_errs.sum(axis=2), pos_total.sum(axis=2)
+    rg_errs, rg_total = q_errs.sum(axis=1), q_total.sum(axis=1)
+    expected = (q_total.astype(np.longdouble) * utils.q_to_p(np.arange(maxscore + 1))).sum(axis=1)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        meanq = utils.p_to_q(expected / rg_total, maxscore)
+    return meanq, rg_errs, rg_total, q_errs, q_total, pos_errs, pos_total, dinuc_errs, dinuc_total
+
+
+def _tally(packed, minscore, maxscore, upto=None):
+    """K1 over the packed pair (optionally only its first `upto` reads)."""
+    if maxscore != 42:
+        raise ValueError('the Q axis of the device tables is fixed at 43 (maxscore = 42)')
+    n = packed['n'] if upto is None else upto
+    R, S = max(packed['R'], 0), packed['S']
+    if n == 0 or R == 0:
+        z = lambda *s: np.zeros(s, dtype=np.int64)
+        return z(R, 43, 2 * S), z(R, 43, 2 * S), z(R, 43, 16), z(R, 43, 16)
+    batch = dev.ReadBatch.from_host(packed['seq'][:n], packed['qual'][:n], packed['meta'][:n],
+                                    cseq=packed['cseq'][:n])
+    tables = dev.Tables(R, 2 * S)
+    dev.accumulate(batch, tables, minscore)
+    return tables.to_host()
+
+
+def fastq_to_covariate_arrays(fastq, infer_rg=False, minscore=6, maxscore=42):
+    """Tally errors and observations of the (uncorrected, corrected) FASTQ pair by read
+    group, reported quality, cycle and dinucleotide.  Returns the reference's 9-tuple:
+    meanq, rg_errs, rg_total, q_errs, q_total, pos_errs, pos_total, dinuc_errs, dinuc_total."""
+    packed = fastx.pack_pair(fastq[0], fastq[1], infer_rg)
+    err = packed.get('pending_error')
+    if err is not None:
+        # the reference fails at the FIRST offending read: let the kernel look at the reads
+        # before it (and at it, when its own checks come first) before raising the host error
+        idx, exc, inclusive = err
+        _tally(packed, minscore, maxscore, upto=idx + (1 if inclusive else 0))
+        raise exc
+    tabs = _tally(packed, minscore, maxscore)
+    return _vectors_from_tables(*tabs, maxscore)
+
+
+def recalibrate_fastq(fastq, infer_rg=False):
+    """Recalibrate FASTQ file fastq[0] using its error-corrected version fastq[1];
+    the recalibrated FASTQ is printed to stdout."""
+    meanq, *vectors = fastq_to_covariate_arrays(fastq, infer_rg)
+    dqs = applybqsr.get_delta_qs(meanq, *vectors)
+    text = fastx.FastqText(fastq[0])
+    single = fastx.pack_single(text, infer_rg)
+    if single['n'] == 0:
+        return
+    lut, shape = dev.build_lut(meanq, *dqs)
+    batch = dev.ReadBatch.from_host(single['seq'], single['qual'], single['meta'])
+    out = dev.apply(batch, dev.lut_to_device(lut), shape)
+    newq = out[:single['n']].cpu().numpy()
+    lens = (single['meta'] & 0xFFFF).astype(np.int64)
+    print(fastx.format_fastq(single['names'], single['seq'], newq, lens), end='')
+
+
+def recalibrate_bam(bam, use_oq=False, set_oq=False):
+    """Not implemented in the reference either."""
+    raise NotImplementedError('Recalibrating a bam is not yet implemented. '
+                              'Convert the BAM to FASTQ with `samtools fastq` first.')
+
+
+def recalibrate(bam, fastq, infer_rg=False, use_oq=False, set_oq=False, gatkreport=None):
+    if gatkreport is not None:
+        raise NotImplementedError('GATKreport reading / creation is not yet supported.')
+    elif bam is not None:
+        recalibrate_bam(bam, use_oq, set_oq)
+    elif fastq is not None:
+        recalibrate_fastq(fastq, infer_rg=infer_rg)
+    else:
+        raise ValueError('A BAM or FASTQ file should be provided for recalibration.')

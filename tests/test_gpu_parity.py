@@ -1,0 +1,319 @@
+"""
+GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the
+CPU oracle on the same seeded inputs, against the committed golden vectors
+produced by the unmodified reference, and -- at large sizes -- through
+size-independent properties.  Integer / byte results: bit-exact.
+"""
+import ctypes
+import io
+import contextlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+VEC = ['meanq', 'rg_errs', 'rg_total', 'q_errs', 'q_total', 'pos_errs', 'pos_total',
+       'dinuc_errs', 'dinuc_total']
+DQ = ['rgdq', 'qdq', 'posdq', 'dinucdq']
+
+
+@pytest.fixture(scope='module')
+def dev():
+    import torch
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from kbbq import _device
+    ctx = _device.context()
+    assert 'gfx950' in ctx.name
+    return _device
+
+
+def _files(oracle, info, tmp_path):
+    c = info['case']
+    seq, cseq, qual, meta = oracle.synth(0, c['n'], c['n'], c['seed'], c['len_lo'], c['len_hi'],
+                                         c['nrg'], c['qlo'], c['qhi'])
+    names = oracle.synth_names(0, c['n'], c['nrg'], with_rg=c['infer_rg'])
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, names, cseq, qual, meta)
+    assert [oracle.sha256(open(f, 'rb').read()) for f in (fa, fb)] == info['input_sha256']
+    return fa, fb
+
+
+# ------------------------------------------------------------------ generator
+@pytest.mark.parametrize('shape', [
+    dict(first=0, n=1000, total=1000, seed=1, len_lo=150, len_hi=150, nrg=1),
+    dict(first=123, n=777, total=5000, seed=99, len_lo=36, len_hi=300, nrg=8),
+    dict(first=0, n=65, total=65, seed=5, len_lo=1, len_hi=16, nrg=3, qlo=2, qhi=42),
+])
+def test_device_generator_matches_oracle(dev, oracle, shape):
+    b = dev.ReadBatch.synthetic(**shape)
+    want = oracle.synth(**shape)
+    n = shape['n']
+    for got, w in zip((b.seq, b.cseq, b.qual), want[:3]):
+        assert np.array_equal(got[:n].cpu().numpy(), w)
+    assert np.array_equal(b.meta[:n].cpu().numpy().view(np.uint32), want[3])
+
+
+# ------------------------------------------------------------------ K1 / K2 vs oracle
+def _tables_via_device(dev, seq, cseq, qual, meta, R, S, minscore=6):
+    batch = dev.ReadBatch.from_host(seq, qual, meta, cseq=cseq)
+    t = dev.Tables(R, 2 * S)
+    dev.accumulate(batch, t, minscore)
+    return t.to_host()
+
+
+@pytest.mark.parametrize('shape', [
+    dict(n=1, len_lo=150, len_hi=150, nrg=1),
+    dict(n=63, len_lo=150, len_hi=150, nrg=1),
+    dict(n=64, len_lo=150, len_hi=150, nrg=2),
+    dict(n=65, len_lo=150, len_hi=150, nrg=3),
+    dict(n=5000, len_lo=150, len_hi=150, nrg=1),
+    dict(n=5000, len_lo=150, len_hi=150, nrg=8),
+    dict(n=3000, len_lo=36, len_hi=300, nrg=5),
+    dict(n=700, len_lo=1, len_hi=16, nrg=1),           # pitch 16: one chunk per read
+    dict(n=900, len_lo=100, len_hi=100, nrg=2, qlo=2, qhi=42),
+    dict(n=40000, len_lo=151, len_hi=151, nrg=4),
+])
+@pytest.mark.parametrize('minscore', [6, 0, 20])
+def test_accumulate_and_apply_match_oracle(dev, oracle, shape, minscore):
+    import torch
+    if minscore != 6 and shape['n'] > 5000:
+        pytest.skip('one minscore is enough for the larger shapes')
+    s = dict(first=0, total=shape['n'], seed=7 + shape['n'], qlo=0, qhi=41)
+    s.update(shape)
+    seq, cseq, qual, meta = oracle.synth(**s)
+    R, S = s['nrg'], s['len_hi']
+    got = _tables_via_device(dev, seq, cseq, qual, meta, R, S, minscore)
+    want = oracle.accumulate(seq, cseq, qual, meta, R, S, minscore=minscore)
+    for g, w, k in zip(got, want[5:], VEC[5:]):
+        assert g.dtype == np.int64 and np.array_equal(g, w), k
+    assert got[1].sum() == want[2].sum() > 0
+
+    # apply with a dense pseudo-random model so that every LUT cell matters
+    rng = np.random.default_rng(s['seed'])
+    meanq = rng.integers(10, 30, R); rgdq = rng.integers(-2, 3, R); qdq = rng.integers(-3, 4, (R, 43))
+    posdq = rng.integers(-6, 7, (R, 43, 2 * S)); ddq = rng.integers(-6, 7, (R, 43, 17)); ddq[..., 16] = 0
+    lut, shp = dev.build_lut(meanq, rgdq, qdq, posdq, ddq)
+    batch = dev.ReadBatch.from_host(seq, qual, meta)
+    out = dev.apply(batch, dev.lut_to_device(lut), shp, minscore=minscore)[:s['n']].cpu().numpy()
+    ref = oracle.apply(seq, qual, meta, meanq, rgdq, qdq, posdq, ddq, minscore=minscore)
+    lens = (meta & 0xFFFF).astype(np.int64)
+    inside = np.arange(seq.shape[1])[None, :] < lens[:, None]
+    assert np.array_equal(out[inside].astype(np.int32) - 33, ref[inside])
+    assert not out[~inside].any()
+
+
+def test_accumulate_adds_into_tables_and_is_linear(dev, oracle):
+    seq, cseq, qual, meta = oracle.synth(0, 4000, 4000, 21, nrg=2)
+    whole = _tables_via_device(dev, seq, cseq, qual, meta, 2, 150)
+    t = dev.Tables(2, 300)
+    for lo, hi in ((0, 1500), (1500, 1501), (1501, 4000)):
+        b = dev.ReadBatch.from_host(seq[lo:hi], qual[lo:hi], meta[lo:hi], cseq=cseq[lo:hi])
+        dev.accumulate(b, t)
+    for a, b in zip(whole, t.to_host()):
+        assert np.array_equal(a, b)
+
+
+def test_host_buffer_entry_points(dev, oracle):
+    """kbbq_accumulate / kbbq_apply with plain host pointers (what a ctypes binding of the
+    reference would call with NumPy arrays)."""
+    from kbbq import _native as N
+    seq, cseq, qual, meta = oracle.synth(0, 2000, 2000, 31, nrg=3)
+    R, S2 = 3, 300
+    tabs = [np.zeros((R, 43, S2), np.int64), np.zeros((R, 43, S2), np.int64),
+            np.zeros((R, 43, 16), np.int64), np.zeros((R, 43, 16), np.int64)]
+    ctx = dev.context()
+    for _ in range(2):      # called twice: the entry point ADDS
+        N.check(N.load().kbbq_accumulate(ctx.handle, N.ptr(seq), N.ptr(cseq), N.ptr(qual), N.ptr(meta),
+                                         2000, seq.shape[1], R, S2, 6, *[N.ptr(t) for t in tabs]))
+    want = oracle.accumulate(seq, cseq, qual, meta, R, 150)
+    for g, w in zip(tabs, want[5:]):
+        assert np.array_equal(g, 2 * w)
+    dqs = oracle.get_delta_qs(*want)
+    a = [np.ascontiguousarray(x, dtype=np.int64) for x in (want[0],) + dqs]
+    out = np.zeros_like(qual)
+    N.check(N.load().kbbq_apply(ctx.handle, N.ptr(seq), N.ptr(qual), N.ptr(meta), 2000, seq.shape[1],
+                                R, 43, S2, 17, 6, *[N.ptr(x) for x in a], N.ptr(out)))
+    ref = oracle.apply(seq, qual, meta, want[0], *dqs)
+    inside = np.arange(seq.shape[1])[None, :] < (meta & 0xFFFF)[:, None]
+    assert np.array_equal(out[inside].astype(np.int32) - 33, ref[inside])
+
+
+# ------------------------------------------------------------------ drop-in API vs reference goldens
+@pytest.mark.parametrize('name', GOLDEN_CASES)
+def test_dropin_api_matches_reference_goldens(dev, oracle, name, tmp_path, capfd):
+    from kbbq import recalibrate
+    from kbbq.gatk import applybqsr
+    info, gold = load_golden(name)
+    fa, fb = _files(oracle, info, tmp_path)
+    vectors = recalibrate.fastq_to_covariate_arrays([fa, fb], infer_rg=info['case']['infer_rg'])
+    assert len(vectors) == 9
+    for k, v in zip(VEC, vectors):
+        assert v.dtype == np.int64 and np.array_equal(v, gold[k]), k
+    for k, v in zip(DQ, applybqsr.get_delta_qs(*vectors)):
+        assert np.array_equal(v, gold[k]), k
+    capfd.readouterr()
+    recalibrate.recalibrate_fastq([fa, fb], infer_rg=info['case']['infer_rg'])
+    text = capfd.readouterr().out
+    assert len(text) == info['output_len']
+    assert oracle.sha256(text) == info['output_sha256']
+    assert text.startswith(info['first_records']) and text.endswith(info['last_records'])
+
+
+def _write(tmp_path, name, recs):
+    p = tmp_path / name
+    p.write_text(''.join('@%s\n%s\n+\n%s\n' % r for r in recs))
+    return str(p)
+
+
+def test_reference_known_answers_through_the_device(dev, tmp_path, capfd, monkeypatch):
+    """reference tests/test_recalibrate.py:53-135 and tests/test_compare_reads.py:219-233."""
+    import sys
+    import kbbq.main
+    from kbbq import recalibrate, compare_reads, fastx
+    for nm, rg in (('foo', False), ('foo/1_RG:Z:bar', True)):
+        fa = _write(tmp_path, 'u%d.fq' % rg, [(nm, 'ATG', '((#')])
+        fb = _write(tmp_path, 'c%d.fq' % rg, [(nm, 'ACG', '((#')])
+        v = recalibrate.fastq_to_covariate_arrays([fa, fb], infer_rg=rg)
+        assert [x.tolist() for x in v[:3]] == [[6], [1], [2]]
+        assert v[3][0, 7] == 1 and v[3].sum() == 1 and v[4][0, 7] == 2 and v[4].sum() == 2
+        assert v[5].shape == (1, 43, 6) and v[5][0, 7, 1] == 1 and v[5].sum() == 1
+        assert v[6][0, 7, 0] == 1 and v[6][0, 7, 1] == 1 and v[6].sum() == 2
+        assert v[7].shape == (1, 43, 16) and v[7][0, 7, 1] == 1 and v[8][0, 7, 1] == 1 and v[8].sum() == 1
+        capfd.readouterr()
+        recalibrate.recalibrate_fastq([fa, fb], infer_rg=rg)
+        assert capfd.readouterr().out == "@%s\nATG\n+\n''#\n" % nm
+    recalibrate.recalibrate(bam=None, fastq=[fa, fb], infer_rg=True)
+    assert capfd.readouterr().out == "@foo/1_RG:Z:bar\nATG\n+\n''#\n"
+    fa = _write(tmp_path, 'u.fq', [('foo', 'ATG', '((#')]); fb = _write(tmp_path, 'c.fq', [('foo', 'ACG', '((#')])
+    with monkeypatch.context() as m:
+        m.setattr(sys, 'argv', [sys.argv[0], 'recalibrate', '-f', fa, fb])
+        kbbq.main.main()
+    assert capfd.readouterr().out == "@foo\nATG\n+\n''#\n"
+    with pytest.raises(NotImplementedError), monkeypatch.context() as m:
+        m.setattr(sys, 'argv', [sys.argv[0], 'recalibrate', '-b', 'foo'])
+        kbbq.main.main()
+    # per-read apply, tables with 8 Q rows and an unpadded 16-column dinuc table
+    read = fastx.FastxRecord('foo', 'ATG', '((#')
+    posdq = np.zeros((1, 8, 6)); posdq[0, 7, :] = 3
+    ddq = np.zeros((1, 8, 16)); ddq[0, 7, :] = 5
+    got = compare_reads.recalibrate_fastq(read, np.array([10]), np.array([1]), np.array([[2] * 8]),
+                                          posdq, ddq, np.array([0]), compare_reads.Dinucleotide.dinuc_to_int)
+    assert np.array_equal(got, [21, 21, 2])
+
+
+def test_reference_error_behaviour(dev, tmp_path):
+    from kbbq import recalibrate
+    ok = ('r0', 'ACGTACGT', 'IIIIIIII')
+    def run(recs_a, recs_b=None, **kw):
+        fa = _write(tmp_path, 'ea.fq', recs_a); fb = _write(tmp_path, 'eb.fq', recs_b or recs_a)
+        return recalibrate.fastq_to_covariate_arrays([fa, fb], **kw)
+    with pytest.raises(IndexError):                       # H2 shorter than the running maximum
+        run([ok, ('r1', 'ACG', 'III')])
+    with pytest.raises(IndexError):                       # H7 q = 43 ('L')
+        run([ok, ('r1', 'ACGTACGT', 'IIIILIII')])
+    with pytest.raises(TypeError):                        # lower-case base in a looked-up dinucleotide
+        run([ok, ('r1', 'ACGtACGT', 'IIIIIIII')])
+    run([ok, ('r1', 'ACGtNCGT', "II''IIII")])              # ... but not when q < 6 / N hide it
+    with pytest.raises(AssertionError):                   # name prefix
+        run([ok, ('r1', 'ACGTACGT', 'IIIIIIII')], [ok, ('x1', 'ACGTACGT', 'IIIIIIII')])
+    with pytest.raises(TypeError):                        # earlier device error beats a later host error
+        run([ok, ('r1', 'ACGtACGT', 'IIIIIIII'), ('r2', 'ACG', 'III')])
+    with pytest.raises(TypeError):                        # same read: dinuc lookup precedes the mask error
+        run([ok, ('r1', 'AcG', 'III')])
+    with pytest.raises(IndexError):                       # no RG field with --infer-rg
+        run([ok], infer_rg=True)
+    # pass 2 sees reads pass 1 never saw (zip truncation): a new RG there is an IndexError
+    fa = _write(tmp_path, 'ta.fq', [('a/1_RG:Z:x', 'ACGT', 'IIII'), ('b/1_RG:Z:y', 'ACGT', 'IIII')])
+    fb = _write(tmp_path, 'tb.fq', [('a/1_RG:Z:x', 'ACGT', 'IIII')])
+    with pytest.raises(IndexError), contextlib.redirect_stdout(io.StringIO()):
+        recalibrate.recalibrate_fastq([fa, fb], infer_rg=True)
+
+
+def test_h1_negative_cycle_aliasing(dev, oracle, tmp_path):
+    unc = [('a/2', 'AC', 'II'), ('b/1', 'ACGT', 'IIII'), ('c/2', 'ACGTA', 'IIIII')]
+    from kbbq import recalibrate
+    fa = _write(tmp_path, 'h1.fq', unc)
+    got = recalibrate.fastq_to_covariate_arrays([fa, fa])
+    want = oracle.py_accumulate(unc, unc)
+    for g, w, k in zip(got, want, VEC):
+        assert np.array_equal(g, w), k
+
+
+def test_covariatedata_consume_read(dev, oracle):
+    """reference tests/test_covariate.py:159-165 plus the intended semantics on real reads."""
+    from kbbq import covariate, read
+    try:
+        r = read.ReadData(seq=np.array(['A', 'T', 'G']), qual=np.array([6, 10, 3]),
+                          skips=np.array([False, False, True]), name='read01', rg=0, second=False,
+                          errors=np.array([False, True, True]))
+        cd = covariate.CovariateData()
+        cd.consume_read(r)
+        assert cd.qcov.rgcov[0] == (1, 2)
+        assert cd.qcov[0, 10] == (1, 1)
+        assert cd.cyclecov[0, 6, 0] == (0, 1)
+        assert cd.dinuccov[0, 10, 1] == (1, 1)
+        assert (cd.get_num_rgs(), cd.get_num_qs(), cd.get_num_cycles()) == (1, 11, 3)
+        # a second, longer second-in-pair read with a low-quality unskipped base
+        r2 = read.ReadData(seq=np.array(list('ACGNTA')), qual=np.array([30, 2, 30, 30, 30, 7]),
+                           skips=np.zeros(6, bool), name='read02', rg=0, second=True,
+                           errors=np.array([True, True, False, False, False, True]))
+        cd.consume_read(r2)
+        assert cd.cyclecov.shape() == (1, 31, 12)
+        assert cd.cyclecov[0, 6, 0] == (0, 1)                 # first read's data kept at the front
+        assert cd.cyclecov[0, 30, -1] == (1, 1) and cd.cyclecov[0, 2, -2] == (1, 1)   # q=2 counted (not skipped)
+        assert cd.cyclecov[0, 7, -6] == (1, 1)
+        assert cd.qcov.rgcov[0] == (4, 8)
+        # dinuc: pos1 q<6 -> none; pos2 'CG' ok; pos3 N -> none; pos4 follows N -> none; pos5 'TA'
+        d = compare_dinuc = {'CG': 14, 'TA': 4}
+        assert cd.dinuccov[0, 30, d['CG']] == (0, 1) and cd.dinuccov[0, 7, d['TA']] == (1, 1)
+        assert cd.dinuccov.total.sum() == 3
+    finally:
+        read.ReadData.rg_to_pu = dict(); read.ReadData.rg_to_int = dict(); read.ReadData.numrgs = 0
+
+
+# ------------------------------------------------------------------ large: properties
+def test_large_batch_properties(dev):
+    """4 M synthetic 2x150 reads (600 M bases) generated on the device: counts vs independent
+    torch reductions, linearity over a split, apply invariants."""
+    import torch
+    n = 4_000_000
+    b = dev.ReadBatch.synthetic(0, n, n, seed=2024, nrg=1)
+    t = dev.Tables(1, 300)
+    dev.accumulate(b, t)
+    pe, pt, de, dt = [x.clone() for x in t.views()]
+    q = b.qual[:, :150].to(torch.int16) - 33
+    valid = q >= 6
+    err = (b.seq[:, :150] != b.cseq[:, :150]) & valid
+    assert int(pt.sum()) == int(valid.sum())
+    assert int(pe.sum()) == int(err.sum())
+    # per-score and per-cycle marginals
+    qt = torch.bincount(q[valid].to(torch.int64), minlength=43)
+    assert torch.equal(pt.sum(dim=(0, 2)), qt)
+    second = (b.meta[:n] < 0)                                   # bit 31
+    cyc_first = valid[~second].sum(dim=0)
+    cyc_second = valid[second].sum(dim=0)
+    assert torch.equal(pt[0].sum(dim=0)[:150], cyc_first)
+    assert torch.equal(pt[0].sum(dim=0)[150:], cyc_second.flip(0))
+    assert int(dt.sum()) <= int(pt.sum()) and int(de.sum()) <= int(pe.sum())
+    # split into two launches == one launch
+    t2 = dev.Tables(1, 300)
+    for lo, hi in ((0, 1_234_567), (1_234_567, n)):
+        part = dev.ReadBatch(hi - lo, b.pitch)
+        part.seq, part.cseq, part.qual, part.meta = b.seq[lo:hi], b.cseq[lo:hi], b.qual[lo:hi], b.meta[lo:hi]
+        dev.accumulate(part, t2)
+    assert torch.equal(t.buf, t2.buf)
+    # apply: identity model leaves every byte unchanged; q < 6 is always passed through
+    z = lambda *s: np.zeros(s, dtype=np.int64)
+    qdq = np.broadcast_to(np.arange(43), (1, 43)).copy()
+    lut, shp = dev.build_lut(z(1), z(1), qdq, z(1, 43, 300), z(1, 43, 17))
+    out = dev.apply(b, dev.lut_to_device(lut), shp)
+    assert torch.equal(out, b.qual)
+    lut, shp = dev.build_lut(z(1) + 5, z(1), qdq, z(1, 43, 300), z(1, 43, 17))
+    out = dev.apply(b, dev.lut_to_device(lut), shp)
+    low = (b.qual < 39) | (b.qual == 0)
+    assert torch.equal(out[low], b.qual[low])
+    assert torch.equal(out[~low], b.qual[~low] + 5)

@@ -1,0 +1,294 @@
+"""
+CPU tests of the product's host side: the C ABI library loads and exports every
+symbol include/kbbq_hip.h declares, the FASTQ packer, the model numerics
+(product code vs oracle and vs reference goldens) and the covariate / read data
+classes (restating the reference's tests/test_covariate.py and tests/test_read.py).
+No kernel is launched here.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+import kbbq
+from kbbq import _native, compare_reads, covariate, fastx, read
+from kbbq.gatk import applybqsr
+
+
+# ---------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'kbbq_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(kbbq_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 20
+    lib = _native.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared == set(_native.PROTOTYPES), declared ^ set(_native.PROTOTYPES)
+    assert lib.kbbq_abi_version() == 1
+    assert lib.kbbq_tables_count(2, 300) == 2 * 2 * 43 * 300 + 2 * 2 * 43 * 16
+    assert lib.kbbq_lut_count(1, 43, 300) % 2 == 0
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present')
+    with pytest.raises(_native.KbbqHipError):
+        _native.Context(0)
+    from kbbq import _device
+    with pytest.raises(_native.KbbqHipError):
+        _device.context()
+
+
+def test_build_lut_host():
+    lib = _native.load()
+    R, Qt, S2, D = 2, 5, 6, 17
+    rng = np.random.default_rng(0)
+    meanq = rng.integers(0, 40, R); rgdq = rng.integers(-3, 3, R)
+    qdq = rng.integers(-3, 3, (R, Qt)); posdq = rng.integers(-5, 5, (R, Qt, S2))
+    ddq = rng.integers(-5, 5, (R, Qt, D)); ddq[..., 16] = 0
+    lut = np.zeros(lib.kbbq_lut_count(R, Qt, S2), dtype=np.int16)
+    a = [np.ascontiguousarray(x, dtype=np.int64) for x in (meanq, rgdq, qdq, posdq, ddq)]
+    _native.check(lib.kbbq_build_lut(R, Qt, S2, D, *[_native.ptr(x) for x in a], _native.ptr(lut)))
+    l1 = lut[:R * Qt * S2].reshape(R, Qt, S2)
+    l2 = lut[R * Qt * S2:R * Qt * (S2 + 17)].reshape(R, Qt, 17)
+    assert np.array_equal(l1, (meanq + rgdq)[:, None, None] + qdq[..., None] + posdq)
+    assert np.array_equal(l2, ddq)
+    with pytest.raises(ValueError):
+        _native.check(lib.kbbq_build_lut(R, Qt, S2, 3, *[_native.ptr(x) for x in a], _native.ptr(lut)))
+
+
+# ---------------------------------------------------------------- FASTQ packer
+def _write(tmp_path, name, recs, end='\n'):
+    p = tmp_path / name
+    p.write_text(''.join('@%s\n%s\n+\n%s%s' % (r + (end,)) for r in recs))
+    return str(p)
+
+
+def test_pack_pair_matches_oracle(oracle, tmp_path):
+    info, _ = load_golden('c5cut_2k_mixed')
+    c = info['case']
+    seq, cseq, qual, meta = oracle.synth(0, 300, c['n'], c['seed'], c['len_lo'], c['len_hi'], c['nrg'])
+    names = oracle.synth_names(0, 300, c['nrg'], with_rg=True)
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, names, cseq, qual, meta)
+    got = fastx.pack_pair(fa, fb, True)
+    want = oracle.pack_records(oracle.read_fastq(fa), oracle.read_fastq(fb), True)
+    assert got['pending_error'] is None
+    assert (got['n'], got['S'], got['R'], got['pitch']) == (want['n'], want['S'], want['R'], want['pitch'])
+    for k in ('seq', 'cseq', 'qual', 'meta'):
+        assert np.array_equal(got[k], want[k]), k
+    assert list(got['rg_to_int']) == want['rg_names']
+    single = fastx.pack_single(got['text'], True)
+    assert np.array_equal(single['seq'], want['seq']) and np.array_equal(single['meta'], want['meta'])
+
+
+def test_fastq_reader_names_comments_and_endings(tmp_path):
+    p = tmp_path / 'x.fq'
+    p.write_bytes(b'@r1/1 some comment\nACGT\n+r1\nIIII\r\n@r2/2_RG:Z:foo\tcomment\nAC\n+\nII')
+    t = fastx.FastqText(str(p))
+    assert t.names() == ['r1/1', 'r2/2_RG:Z:foo']
+    recs = list(fastx.FastxFile(str(p)))
+    assert recs[0].comment == 'some comment' and recs[0].sequence == 'ACGT' and recs[1].quality == 'II'
+    assert recs[0].get_quality_array() == [40, 40, 40, 40]
+    assert str(recs[1]) == '@r2/2_RG:Z:foo\nAC\n+\nII'
+    assert fastx.infer_second('r2/2_RG:Z:foo') and not fastx.infer_second('r2_foo_/2')
+    assert fastx.infer_rg('r2/2_RG:Z:foo') == 'foo'
+    m, rgmap, err = fastx.make_meta(t.names(), t.lengths(), False)
+    assert err is None and list(m) == [4, 2 | (1 << 31)]
+
+
+def test_pack_pair_error_ordering(tmp_path):
+    # name mismatch (read 1) comes before the short read (read 2)
+    a = _write(tmp_path, 'a.fq', [('x', 'ACGT', 'IIII'), ('y', 'ACGT', 'IIII'), ('z', 'AC', 'II')])
+    b = _write(tmp_path, 'b.fq', [('x', 'ACGT', 'IIII'), ('q', 'ACGT', 'IIII'), ('z', 'AC', 'II')])
+    p = fastx.pack_pair(a, b, False)
+    idx, exc, inclusive = p['pending_error']
+    assert idx == 1 and isinstance(exc, AssertionError) and not inclusive and p['n'] == 1
+    # short read: IndexError, the read itself still goes to the device (its TypeError would win)
+    p = fastx.pack_pair(a, a, False)
+    idx, exc, inclusive = p['pending_error']
+    assert idx == 2 and isinstance(exc, IndexError) and inclusive and p['n'] == 3
+    # RG inference failure on read 0 wins over everything later
+    p = fastx.pack_pair(a, b, True)
+    assert p['pending_error'][0] == 0 and isinstance(p['pending_error'][1], IndexError)
+    # zip() truncation
+    c = _write(tmp_path, 'c.fq', [('x', 'ACGT', 'IIII')])
+    assert fastx.pack_pair(a, c, False)['n'] == 1
+
+
+# ---------------------------------------------------------------- model numerics
+def test_prior_and_q_p_tables_match_reference():
+    info, _ = load_golden('numeric')
+    prior = [float(x).hex() if np.isfinite(x) else '-inf' for x in compare_reads.RescaledNormal.prior_dist]
+    assert prior == info['prior_dist_hex']
+    assert compare_reads.RescaledNormal.prior_dist.dtype == np.longdouble
+    assert compare_reads.RescaledNormal.prior(0) == np.log(.9)
+    assert np.array_equal(compare_reads.RescaledNormal.prior(np.arange(43)),
+                          compare_reads.RescaledNormal.prior_dist)
+    q = np.arange(43)
+    assert [float(x).hex() for x in compare_reads.q_to_p(q)] == info['q_to_p_hex']
+    assert [int(x) for x in compare_reads.p_to_q(compare_reads.q_to_p(q))] == info['p_to_q_of_q_to_p']
+    s = info['p_to_q_samples']
+    assert [int(x) for x in compare_reads.p_to_q(np.array(s['p']))] == s['q']
+    assert np.array_equal(compare_reads.p_to_q(np.array([.2, .3, .4, .1, .01, .001])),
+                          np.array([6, 5, 3, 10, 20, 30]))
+
+
+def test_gatk_delta_q_matches_reference_grid(oracle):
+    _, gold = load_golden('numeric')
+    errs, tot = gold['grid_errs'], gold['grid_total']
+    prior_q = np.broadcast_to(np.arange(43)[:, None], (43, len(errs))).copy()
+    be = np.broadcast_to(errs, prior_q.shape).copy(); bt = np.broadcast_to(tot, prior_q.shape).copy()
+    dq = compare_reads.gatk_delta_q(prior_q, be, bt)
+    assert np.array_equal(dq, gold['grid_dq'])
+    assert np.array_equal(dq, oracle.gatk_delta_q(prior_q, be, bt))
+    # reference tests/test_compare_reads.py:141-151
+    p = np.array([10, 20, 30])
+    d = compare_reads.gatk_delta_q(p, np.array([10, 200, 0]), np.array([1000, 1000, 50000]))
+    assert d[0] > 0 and d[1] < 0 and d[2] > 0 and np.all(d + p <= 42) and np.all(d + p > 0)
+
+
+@pytest.mark.parametrize('name', ['c1_10k_1rg', 'c5cut_2k_mixed', 'q42_500_3rg'])
+def test_get_delta_qs_matches_reference(name):
+    _, g = load_golden(name)
+    dqs = applybqsr.get_delta_qs(g['meanq'], g['rg_errs'], g['rg_total'], g['q_errs'], g['q_total'],
+                                 g['pos_errs'], g['pos_total'], g['dinuc_errs'], g['dinuc_total'])
+    for k, v in zip(['rgdq', 'qdq', 'posdq', 'dinucdq'], dqs):
+        assert np.array_equal(v, g[k]), k
+    # reference tests/test_gatk_applybqsr.py:105-121
+    a = applybqsr.get_delta_qs(np.array([10]), np.array([0]), np.array([1000]), np.array([[0]]),
+                               np.array([[1000]]), np.array([[[0]]]), np.array([[[1000]]]),
+                               np.array([[[0]]]), np.array([[[1000]]]))
+    assert [x.tolist() for x in a] == [[3], [[2]], [[[1]]], [[[1, 0]]]]
+
+
+def test_meanq_from_marginals_matches_reference():
+    from kbbq import recalibrate
+    for name in ('c1_10k_1rg', 'c3cut_2k_8rg', 'c5cut_2k_mixed', 'q42_500_3rg', 'short_64_1rg'):
+        _, g = load_golden(name)
+        v = recalibrate._vectors_from_tables(g['pos_errs'], g['pos_total'], g['dinuc_errs'],
+                                             g['dinuc_total'], 42)
+        for k, x in zip(['meanq', 'rg_errs', 'rg_total', 'q_errs', 'q_total'], v):
+            assert np.array_equal(x, g[k]), (name, k)
+
+
+# ---------------------------------------------------------------- covariate helpers
+def test_covariate_helpers():
+    # reference tests/test_compare_reads.py:130-139, 168-189
+    order = ['AA', 'AT', 'AG', 'AC', 'TA', 'TT', 'TG', 'TC', 'GA', 'GT', 'GG', 'GC', 'CA', 'CT', 'CG', 'CC']
+    assert order == compare_reads.Dinucleotide.dinucs
+    assert np.array_equal(compare_reads.Dinucleotide.vecget(np.array(order)), np.arange(16))
+    assert compare_reads.Dinucleotide.vecget(np.array(['AA'])) == 0
+    assert np.array_equal(compare_reads.generic_cycle_covariate(17), np.arange(17))
+    assert np.array_equal(compare_reads.generic_cycle_covariate(17, True), -(np.arange(17) + 1))
+    s = np.array(list('ATGCATGC')); q = np.array([10] * 8)
+    want = np.concatenate([[-1], compare_reads.Dinucleotide.vecget(
+        np.array(['AT', 'TG', 'GC', 'CA', 'AT', 'TG', 'GC']))])
+    assert np.array_equal(compare_reads.generic_dinuc_covariate(s, q), want)
+    s[1] = 'N'; want[1] = -1; want[2] = -1
+    assert np.array_equal(compare_reads.generic_dinuc_covariate(s, q), want)
+    q[6] = 2; want[6] = -1
+    assert np.array_equal(compare_reads.generic_dinuc_covariate(s, q), want)
+    with pytest.raises(TypeError):
+        compare_reads.generic_dinuc_covariate(np.array(list('AcGT')), np.array([10] * 4))
+    r = fastx.FastxRecord('foo/2_RG:Z:bar', 'ATG', '((#')
+    assert compare_reads.fastq_infer_secondinpair(r) and compare_reads.fastq_infer_rg(r) == 'bar'
+    assert np.array_equal(compare_reads.fastq_cycle_covariates(r, True), [-1, -2, -3])
+    assert np.array_equal(compare_reads.fastq_dinuc_covariates(r), [-1, 1, -1])
+
+
+# ---------------------------------------------------------------- covariate classes (reference tests/test_covariate.py)
+def test_pad_axis_and_covariate_basics():
+    assert np.array_equal(covariate.pad_axis(np.array([1]), 0, 2), [1, 0, 0])
+    assert np.array_equal(covariate.pad_axis(np.array([[1]]), 0, 2), [[1], [0], [0]])
+    assert np.array_equal(covariate.pad_axis(np.array([[1]]), 1, 2), [[1, 0, 0]])
+    t = covariate.Covariate(); assert t.errors.shape == (0,) and t.total.shape == (0,)
+    t = covariate.Covariate((1, 2)); assert t.shape() == (1, 2)
+    t = covariate.Covariate(); t.pad_axis(0); assert t.shape() == (1,)
+    t = covariate.Covariate((3, 4)); t.pad_axis(1, 2); assert t.shape() == (3, 6)
+    t = covariate.Covariate(); t.pad_axis_to_fit(0, 99); assert t.shape() == (100,)
+    t = covariate.Covariate((1, 2)); t.pad_axis_to_fit(1, -10); assert t.shape() == (1, 10)
+    t.pad_axis_to_fit(1, 0); assert t.shape() == (1, 10)
+    t = covariate.Covariate((10,)); t.increment((0, 0), (0, 1))
+    assert np.array_equal(t.errors, np.zeros(10)) and np.array_equal(t.total, [1] + [0] * 9)
+    t = covariate.Covariate((1,)); t[0] = (0, 1); t.increment((0, 0), (0, 1)); assert t[0] == (0, 2)
+
+
+def test_cyclecovariate_growth_keeps_negative_half():
+    t = covariate.CycleCovariate(); assert t.shape() == (0, 0, 0)
+    t.pad_axis(axis=0, n=1); assert t.shape() == (1, 0, 0)
+    with pytest.raises(ValueError):
+        t.pad_axis(2, 1)
+    t.pad_axis(1, 1); t.pad_axis(2, 2); assert t.shape() == (1, 1, 2)
+    t[(0, 0, 0)] = (1, 1); t[(0, 0, -1)] = (2, 2)
+    t.pad_axis(2, 4)
+    assert t.shape() == (1, 1, 6) and t[0, 0, 0] == (1, 1) and t[0, 0, -1] == (2, 2)
+    c = covariate.CycleCovariate(); c.pad_axis(2, 2); assert c.num_cycles() == 1
+    d = covariate.DinucCovariate(); assert d.shape() == (0, 0, 16) and d.num_dinucs() == 16
+    cd = covariate.CovariateData()
+    assert cd.qcov.shape() == (0, 0) and cd.cyclecov.shape() == (0, 0, 0) and cd.dinuccov.shape() == (0, 0, 16)
+    assert (cd.get_num_rgs(), cd.get_num_qs(), cd.get_num_cycles(), cd.get_num_dinucs()) == (0, 0, 0, 16)
+
+
+@pytest.fixture()
+def exreaddata():
+    # reference tests/conftest.py:204-218
+    yield read.ReadData(seq=np.array(['A', 'T', 'G']), qual=np.array([6, 10, 3]),
+                        skips=np.array([False, False, True]), name='read01', rg=0, second=False,
+                        errors=np.array([False, True, True]))
+    read.ReadData.rg_to_pu = dict(); read.ReadData.rg_to_int = dict(); read.ReadData.numrgs = 0
+
+
+def test_readdata_getters(exreaddata):
+    r = exreaddata
+    assert len(r) == 3 and r.get_rg_int() == 0 and r.get_pu() == 0 and r.canonical_name() == 'read01/1'
+    assert r.str_qual() == ["'", '+', '$']
+    assert np.array_equal(r.not_skipped_errors(), [False, True, False])
+    rge, rgv = r.get_rg_errors(); assert list(rge) == [0] and list(rgv) == [0, 0]
+    qe, qv = r.get_q_errors(); assert list(qe) == [10] and list(qv) == [6, 10]
+    ce, cv = r.get_cycle_errors(); assert list(ce) == [1] and list(cv) == [0, 1]
+    assert list(r.get_dinucleotide_array()) == [-1, 1, -1]
+    de, dv = r.get_dinuc_errors(); assert list(de) == [1] and list(dv) == [1]
+    r.second = True
+    assert list(r.get_cycle_array()) == [-1, -2, -3]
+
+
+def test_readdata_from_fastq():
+    rec = fastx.FastxRecord('foo/2_RG:Z:bar', 'ATG', '((#')
+    r = read.ReadData.from_fastq(rec)
+    assert r.name == 'foo' and r.rg == 'bar' and r.second and list(r.qual) == [7, 7, 2]
+    assert not r.skips.any() and not r.errors.any()
+    assert read.ReadData.rg_to_int['bar'] == r.get_rg_int()
+    read.ReadData.rg_to_pu = dict(); read.ReadData.rg_to_int = dict(); read.ReadData.numrgs = 0
+
+
+def test_rg_and_q_covariate_consume_read(exreaddata):
+    t = covariate.RGCovariate()
+    res = t.consume_read(exreaddata)
+    assert list(res[0]) == [0] and list(res[1]) == [0, 0] and t[0] == (1, 2) and t.num_rgs() == 1
+    q = covariate.QCovariate(); assert q.num_qs() == 0
+    (rge, rgv), (qe, qv) = q.consume_read(exreaddata)
+    assert list(qe) == [10] and list(qv) == [6, 10] and q[(0, 10)] == (1, 1) and q.num_qs() == 11
+
+
+def test_dispatcher_errors():
+    from kbbq import recalibrate
+    with pytest.raises(NotImplementedError):
+        recalibrate.recalibrate_bam(None)
+    with pytest.raises(NotImplementedError):
+        recalibrate.recalibrate(fastq=None, bam='foo')
+    with pytest.raises(NotImplementedError):
+        recalibrate.recalibrate(fastq=None, bam=None, gatkreport='foo')
+    with pytest.raises(ValueError):
+        recalibrate.recalibrate(fastq=None, bam=None, gatkreport=None)
+    a = fastx.FastxRecord('r', 'ACGTAC', 'IIIIII'); b = fastx.FastxRecord('r', 'ACGTAC', 'IIIIII')
+    b.sequence = 'ACGTAG'
+    assert list(recalibrate.find_corrected_sites(a, b)) == [False] * 5 + [True]
+    with pytest.raises(AssertionError):
+        recalibrate.find_corrected_sites(a, fastx.FastxRecord('s', 'ACGTAC', 'IIIIII'))
