@@ -243,7 +243,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_accumulate(K1Params p)
                     const int dcol = second ? -4 : 4;
                     int colbase = col0 * 4 - 33 * (int)row_bytes;
                     const int dnb = (int)dn_base - 33 * 128;
-                    u32 pc = prev_code;
+                    u32 pc = prev_code << 24;        // alignbyte below takes byte 3 of the previous word
 #pragma unroll
                     for (int wd = 0; wd < 4; ++wd) {
                         const u32 pw = __builtin_amdgcn_alignbyte(code[wd], pc, 3);  // codes of bases i-1
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_apply(K2Params p)
                     const int rgc = rg < p.R ? rg : 0;
                     int col = second ? (p.S2 - 1 - pos0) : pos0;     // compare_reads.py:325: Python wrap on S2
                     const int dcol = second ? -1 : 1;
-                    u32 pc = prev_code;
+                    u32 pc = prev_code << 24;        // alignbyte below takes byte 3 of the previous word
 #pragma unroll
                     for (int wd = 0; wd < 4; ++wd) {
                         const u32 pw = __builtin_amdgcn_alignbyte(code[wd], pc, 3);

@@ -73,6 +73,10 @@ def load():
         raise ImportError(
             'libkbbq_hip.so is not built (%s).  Run `make -C kbbq-py_amd/csrc`; '
             'this package has no CPU fallback.' % LIB_PATH)
+    # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Two HIP runtimes in one
+    # process cannot both open the GPU, so torch's must be the one already mapped when
+    # libkbbq_hip.so resolves its DT_NEEDED libamdhip64.so.7.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

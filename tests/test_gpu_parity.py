@@ -217,7 +217,7 @@ def test_reference_error_behaviour(dev, tmp_path):
         run([ok, ('r1', 'ACGTACGT', 'IIIILIII')])
     with pytest.raises(TypeError):                        # lower-case base in a looked-up dinucleotide
         run([ok, ('r1', 'ACGtACGT', 'IIIIIIII')])
-    run([ok, ('r1', 'ACGtNCGT', "II''IIII")])              # ... but not when q < 6 / N hide it
+    run([ok, ('r1', 'ACGtNCGT', "II##IIII")])              # ... but not when q < 6 / N hide it
     with pytest.raises(AssertionError):                   # name prefix
         run([ok, ('r1', 'ACGTACGT', 'IIIIIIII')], [ok, ('x1', 'ACGTACGT', 'IIIIIIII')])
     with pytest.raises(TypeError):                        # earlier device error beats a later host error
