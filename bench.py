@@ -81,10 +81,8 @@ def main():
         tables.buf.zero_()
         dev.accumulate(batch, tables, check=False)
         parallel.allreduce_tables(tables.buf)
-        vectors = recalibrate._vectors_from_tables(*tables.to_host(), 42)
-        dqs = applybqsr.get_delta_qs(*vectors)
-        lut, shape = dev.build_lut(vectors[0], *dqs)
-        dev.apply(batch, dev.lut_to_device(lut), shape, out=out, check=False)
+        lut, shape, _, _ = dev.solve(tables)
+        dev.apply(batch, lut, shape, out=out, check=False)
 
     def fence():
         if world > 1:

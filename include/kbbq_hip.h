@@ -62,8 +62,9 @@ const char* kbbq_last_error(void);
 int         kbbq_device_count(int* count);
 int         kbbq_ctx_create(int device, kbbq_ctx** out);
 int         kbbq_ctx_destroy(kbbq_ctx* ctx);
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the
- * context's own stream.                                                    */
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream).  NULL selects the
+ * device's default (null) stream -- which IS torch's current stream unless the caller
+ * changed it.  A fresh context runs on a private non-blocking stream until this is called. */
 int         kbbq_ctx_set_stream(kbbq_ctx* ctx, void* hip_stream);
 int         kbbq_ctx_sync(kbbq_ctx* ctx);
 /* Synchronise, fetch and clear the kernels' status word.  Returns KBBQ_OK or the
@@ -115,24 +116,58 @@ int kbbq_accumulate(kbbq_ctx* ctx, const uint8_t* seq, const uint8_t* cseq,
 /* ---- K2: delta-Q table lookup / apply ----------------------------------
  * Replaces compare_reads.recalibrate_fastq (compare_reads.py:320-328) as driven
  * by recalibrate.py:141-152.  The five model arrays are folded on the host into
- * one int16 LUT (kbbq_build_lut):
- *     lut1[R][Qt][S2]  = meanq[rg] + rgdq[rg] + qdq[rg][q] + posdq[rg][q][cycle]
- *     lut2[R][Qt][17]  = dinucdq[rg][q][d]     (column 16 = "no context", index -1)
- * new_q = lut1 + lut2 for q >= minscore, q otherwise; the output byte is
- * new_q + 33 (no clipping, compare_reads.py:327; outside 0..255 -> KBBQ_E_RANGE).
- * Cycle -(i+1) wraps on the final S2 (Python negative index).  q >= Qt, rg >= R
- * or a cycle beyond S2 -> KBBQ_E_INDEX.                                     */
+ * one int16 LUT (kbbq_build_lut), one row of kbbq_lut_row_stride(S2) entries per
+ * (read group, quality):
+ *     row[0 .. S2-1]    = meanq[rg] + rgdq[rg] + qdq[rg][q] + posdq[rg][q][cycle]
+ *     row[S2 .. S2+24]  = dinucdq[rg][q][d] indexed by 5*code(prev)+code(cur), codes
+ *                         A0 T1 G2 C3 (compare_reads.py:199) and 4 = N / no previous
+ *                         base; entries involving code 4 hold dinucdq[rg][q][-1]
+ * new_q = row[cycle] + row[S2 + context] for q >= minscore, q otherwise; the output
+ * byte is new_q + 33 (no clipping, compare_reads.py:327; outside 0..255 ->
+ * KBBQ_E_RANGE).  Cycle -(i+1) wraps on the final S2 (Python negative index).
+ * q >= Qt, rg >= R or a cycle beyond S2 -> KBBQ_E_INDEX.  *range_safe is set when
+ * no (cycle, context) combination of any row can leave 0..255; passing it to
+ * kbbq_apply_dev selects the kernel variant without the per-base range test.  */
+int    kbbq_lut_row_stride(int S2);
 int kbbq_build_lut(int R, int Qt, int S2, int D,
                    const int64_t* meanq, const int64_t* rgdq, const int64_t* qdq,
-                   const int64_t* posdq, const int64_t* dinucdq, int16_t* lut_out);
+                   const int64_t* posdq, const int64_t* dinucdq, int16_t* lut_out,
+                   int* range_safe);
 int kbbq_apply_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_qual,
                    const uint32_t* d_meta, int64_t nreads, int pitch,
                    int R, int Qt, int S2, int minscore,
-                   const int16_t* d_lut, uint8_t* d_qual_out);
+                   const int16_t* d_lut, int range_safe, uint8_t* d_qual_out);
 int kbbq_apply(kbbq_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint32_t* meta,
                int64_t nreads, int pitch, int R, int Qt, int S2, int D, int minscore,
                const int64_t* meanq, const int64_t* rgdq, const int64_t* qdq,
                const int64_t* posdq, const int64_t* dinucdq, uint8_t* qual_out);
+
+/* ---- K3: delta-Q model solve ------------------------------------------
+ * Replaces compare_reads.gatk_delta_q (compare_reads.py:235-260) and, fused,
+ * applybqsr.get_delta_qs (gatk/applybqsr.py:80-103).  Split of labour (DESIGN.md
+ * "K3"): the host evaluates everything transcendental with the SciPy calls the
+ * reference makes -- per cell comb = gammaln(n+1) - (gammaln(k+1) + gammaln(n-k+1)),
+ * k = errs+1, n = total+2, and the 3 x 43 table h_consts129 = [prior_dist |
+ * log p | log1p(-p)] -- and the device multiplies/adds those float64 values in
+ * SciPy's order, adds the longdouble prior with an exact 80-bit emulation and
+ * takes the first maximum over the 43 candidates.  Results are integers
+ * identical to the reference's.
+ *
+ * kbbq_delta_q_dev: dq[i] = argmax_i - prior_q[i] for ncells independent cells
+ * (prior_q must lie in 0..42).
+ * kbbq_solve_dev: the whole hierarchy from the device count tables: marginals,
+ * read-group and quality levels (d_post_q[R*43] scratch), then cycle and
+ * dinucleotide levels, writing the K2 LUT (kbbq_lut_count elements) and, when
+ * d_dq != NULL, int32 [rgdq R | qdq R*43 | posdq R*43*S2 | dinucdq R*43*17].
+ * d_aux (kbbq_solve_aux_count doubles) = [comb_rg | comb_q | comb_pos | comb_dn].  */
+int    kbbq_delta_q_dev(kbbq_ctx* ctx, const int64_t* d_prior_q, const int64_t* d_errs,
+                        const int64_t* d_total, const double* d_comb, int64_t ncells,
+                        const double* h_consts129, int64_t* d_dq);
+size_t kbbq_solve_aux_count(int R, int S2);
+size_t kbbq_solve_dq_count(int R, int S2);
+int    kbbq_solve_dev(kbbq_ctx* ctx, const int64_t* d_tables, int R, int S2,
+                      const int32_t* d_meanq, const double* d_aux, const double* h_consts129,
+                      int32_t* d_post_q, int16_t* d_lut, int32_t* d_dq);
 
 /* ---- synthetic reads (bench / tests) -----------------------
  * Device twin of the generator documented in oracle/kbbq_oracle.c.          */

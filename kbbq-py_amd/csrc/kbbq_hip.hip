@@ -1,9 +1,12 @@
 // kbbq_hip.hip -- C ABI of libkbbq_hip.so (see include/kbbq_hip.h).
 // gfx950 only.  Host side: launch geometry, device staging, status decoding.
 #include "kbbq_kernels.h"
+#include "kbbq_solve_kernels.h"
 #include "../../include/kbbq_hip.h"
 
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -84,7 +87,8 @@ int kbbq_ctx_create(int device, kbbq_ctx** out)
     // allow the full 160 KiB of LDS as dynamic shared memory
     (void)hipFuncSetAttribute((const void*)k1_accumulate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k1_accumulate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)k2_apply, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)k2_apply<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)k2_apply<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipGetLastError();
     *out = c;
     return KBBQ_OK;
@@ -105,7 +109,7 @@ int kbbq_ctx_destroy(kbbq_ctx* c)
 int kbbq_ctx_set_stream(kbbq_ctx* c, void* s)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;      // NULL is the device's default (null) stream, e.g. torch's
     return KBBQ_OK;
 }
 
@@ -196,10 +200,11 @@ size_t kbbq_tables_count(int R, int S2)
     return 2 * (size_t)R * KQ * (size_t)S2 + 2 * (size_t)R * KQ * KND;
 }
 
+int kbbq_lut_row_stride(int S2) { return lut_row_stride(S2); }
+
 size_t kbbq_lut_count(int R, int Qt, int S2)
 {
-    size_t n = (size_t)R * Qt * ((size_t)S2 + 17);
-    return (n + 1) & ~(size_t)1;       // even: K2 stages the LUT as 32-bit words
+    return (size_t)R * Qt * (size_t)lut_row_stride(S2);     // even: K2 stages the LUT as 32-bit words
 }
 
 int kbbq_ctx_timing(kbbq_ctx* c, int enable)
@@ -307,13 +312,15 @@ int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_c
 
 int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta,
                    int64_t nreads, int pitch, int R, int Qt, int S2, int minscore,
-                   const int16_t* d_lut, uint8_t* d_out)
+                   const int16_t* d_lut, int range_safe, uint8_t* d_out)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
     int rc = check_planes("kbbq_apply_dev", nreads, pitch, d_seq, d_qual, d_out);
     if (rc) return rc;
-    if (R <= 0 || Qt <= 0 || Qt > 223 || S2 <= 0) return fail(KBBQ_E_ARG, "kbbq_apply_dev: bad table shape R=%d Qt=%d S2=%d", R, Qt, S2);
-    if (minscore < 0) return fail(KBBQ_E_ARG, "kbbq_apply_dev: minscore < 0");
+    if (R <= 0 || R > 32767 || Qt <= 0 || Qt > 95 || S2 <= 0 || S2 > 65536)
+        return fail(KBBQ_E_ARG, "kbbq_apply_dev: bad table shape R=%d Qt=%d S2=%d (Qt <= 95)", R, Qt, S2);
+    if (minscore < 0 || minscore > 222) return fail(KBBQ_E_ARG, "kbbq_apply_dev: minscore out of range");
+    if ((uintptr_t)d_lut & 3) return fail(KBBQ_E_ARG, "kbbq_apply_dev: LUT must be 4-byte aligned");
     if (nreads == 0) return KBBQ_OK;
     HIPCHK(hipSetDevice(c->device));
 
@@ -324,10 +331,11 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
     p.lut = d_lut; p.lut_count = (int)kbbq_lut_count(R, Qt, S2);
     p.out = d_out; p.status = c->d_status;
     const size_t lut_bytes = (size_t)p.lut_count * 2;
-    // keep at least 2 workgroups per CU when staging the LUT in LDS
-    p.lut_in_lds = lut_bytes <= (size_t)c->lds_bytes / 2 ? 1 : 0;
-    const size_t lds = p.lut_in_lds ? lut_bytes : 0;
-    int per_cu = p.lut_in_lds ? std::min<int>((int)(c->lds_bytes / std::max<size_t>(lds, 1)), 2048 / K2_THREADS) : 2048 / K2_THREADS;
+    // stage the LUT in LDS when at least 2 workgroups per CU still fit
+    const bool in_lds = lut_bytes <= (size_t)c->lds_bytes / 2;
+    p.lut_in_lds = in_lds ? 1 : 0;
+    const size_t lds = in_lds ? lut_bytes : 0;
+    int per_cu = in_lds ? std::min<int>((int)(c->lds_bytes / std::max<size_t>(lds, 1)), 2048 / K2_THREADS) : 2048 / K2_THREADS;
     per_cu = std::max(per_cu, 1);
     const int64_t nblocks = (nreads + 63) / 64;
     const int64_t want = (nblocks + (K2_THREADS / 64) - 1) / (K2_THREADS / 64);
@@ -335,40 +343,47 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
     dim3 grid((unsigned)std::max(gx, 1), 1, 1), block(K2_THREADS, 1, 1);
     {
         Timed t(c, 1);
-        hipLaunchKernelGGL(k2_apply, grid, block, lds, c->stream, p);
+        if (!in_lds) hipLaunchKernelGGL((k2_apply<false, true>), grid, block, 0, c->stream, p);
+        else if (range_safe) hipLaunchKernelGGL((k2_apply<true, false>), grid, block, lds, c->stream, p);
+        else hipLaunchKernelGGL((k2_apply<true, true>), grid, block, lds, c->stream, p);
     }
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
 }
 
 int kbbq_build_lut(int R, int Qt, int S2, int D, const int64_t* meanq, const int64_t* rgdq,
-                   const int64_t* qdq, const int64_t* posdq, const int64_t* dinucdq, int16_t* out)
+                   const int64_t* qdq, const int64_t* posdq, const int64_t* dinucdq, int16_t* out,
+                   int* range_safe)
 {
     // D = 17 is what get_delta_qs returns (applybqsr.py:98-101); D = 16 is accepted because the
     // reference's own apply test passes an unpadded table (index -1 then aliases column 15)
     if (R <= 0 || Qt <= 0 || S2 <= 0 || D < 16 || D > 17)
         return fail(KBBQ_E_ARG, "kbbq_build_lut: bad shape R=%d Qt=%d S2=%d D=%d", R, Qt, S2, D);
-    int16_t* l1 = out;
-    int16_t* l2 = out + (size_t)R * Qt * S2;
+    const int rs = lut_row_stride(S2);
+    bool safe = true;
     for (int r = 0; r < R; ++r)
         for (int q = 0; q < Qt; ++q) {
             const size_t cell = (size_t)r * Qt + q;
+            int16_t* row = out + cell * rs;
             const int64_t base = meanq[r] + rgdq[r] + qdq[cell];
+            int64_t lo1 = INT64_MAX, hi1 = INT64_MIN, lo2 = INT64_MAX, hi2 = INT64_MIN;
             for (int s = 0; s < S2; ++s) {
                 const int64_t v = base + posdq[cell * S2 + s];
                 if (v < -32768 || v > 32767) return fail(KBBQ_E_RANGE, "kbbq_build_lut: value %lld does not fit the LUT", (long long)v);
-                l1[cell * S2 + s] = (int16_t)v;
+                row[s] = (int16_t)v; lo1 = std::min(lo1, v); hi1 = std::max(hi1, v);
             }
-            // Python index d (0..15) and -1 on a D-column table: column 16 of the LUT is "index -1"
-            for (int d = 0; d < 17; ++d) {
-                int64_t v;
-                if (d < 16) v = dinucdq[cell * D + d];
-                else v = dinucdq[cell * D + (D - 1)];
-                if (v < -32768 || v > 32767) return fail(KBBQ_E_RANGE, "kbbq_build_lut: value %lld does not fit the LUT", (long long)v);
-                l2[cell * 17 + d] = (int16_t)v;
-            }
+            // dinucleotide index 5 * prev + cur, codes A0 T1 G2 C3 and 4 = N / no previous base;
+            // anything involving code 4 is the reference's index -1, i.e. column D - 1
+            for (int a = 0; a < 5; ++a)
+                for (int b = 0; b < 5; ++b) {
+                    const int64_t v = (a < 4 && b < 4) ? dinucdq[cell * D + 4 * a + b] : dinucdq[cell * D + (D - 1)];
+                    if (v < -32768 || v > 32767) return fail(KBBQ_E_RANGE, "kbbq_build_lut: value %lld does not fit the LUT", (long long)v);
+                    row[S2 + 5 * a + b] = (int16_t)v; lo2 = std::min(lo2, v); hi2 = std::max(hi2, v);
+                }
+            for (int s = S2 + 25; s < rs; ++s) row[s] = 0;
+            if (lo1 + lo2 + 33 < 0 || hi1 + hi2 + 33 > 255) safe = false;
         }
-    if (kbbq_lut_count(R, Qt, S2) > (size_t)R * Qt * ((size_t)S2 + 17)) out[kbbq_lut_count(R, Qt, S2) - 1] = 0;
+    if (range_safe) *range_safe = safe ? 1 : 0;
     return KBBQ_OK;
 }
 
@@ -391,6 +406,58 @@ int kbbq_synth_dev(kbbq_ctx* c, uint8_t* d_seq, uint8_t* d_cseq, uint8_t* d_qual
     const int64_t nchunks = nreads * p.cpr;
     int gx = (int)std::min<int64_t>((nchunks + 255) / 256, (int64_t)c->cus * 8);
     hipLaunchKernelGGL(ks_synth, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+// ---- K3: model solve ------------------------------------------------------
+static int load_consts(SolveConsts& c, const double* h_consts)
+{
+    if (!h_consts) return fail(KBBQ_E_ARG, "model constants are NULL");
+    memcpy(c.prior, h_consts, sizeof c.prior);
+    memcpy(c.logp, h_consts + KSOLVE_NQ, sizeof c.logp);
+    memcpy(c.log1mp, h_consts + 2 * KSOLVE_NQ, sizeof c.log1mp);
+    return KBBQ_OK;
+}
+
+int kbbq_delta_q_dev(kbbq_ctx* c, const int64_t* d_prior_q, const int64_t* d_errs, const int64_t* d_total,
+                     const double* d_comb, int64_t ncells, const double* h_consts129, int64_t* d_dq)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (ncells < 0) return fail(KBBQ_E_ARG, "kbbq_delta_q_dev: ncells < 0");
+    if (ncells == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    K3CellParams p;
+    p.prior_q = (const long long*)d_prior_q; p.errs = (const long long*)d_errs; p.total = (const long long*)d_total;
+    p.comb = d_comb; p.n = ncells; p.dq = (long long*)d_dq;
+    int rc = load_consts(p.c, h_consts129);
+    if (rc) return rc;
+    int gx = (int)std::min<int64_t>((ncells + 255) / 256, (int64_t)c->cus * 8);
+    hipLaunchKernelGGL(k3_delta_q, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+size_t kbbq_solve_aux_count(int R, int S2) { return (size_t)R + (size_t)R * KQ + (size_t)R * KQ * S2 + (size_t)R * KQ * KND; }
+size_t kbbq_solve_dq_count(int R, int S2) { return (size_t)R + (size_t)R * KQ + (size_t)R * KQ * S2 + (size_t)R * KQ * 17; }
+
+int kbbq_solve_dev(kbbq_ctx* c, const int64_t* d_tables, int R, int S2, const int32_t* d_meanq,
+                   const double* d_aux, const double* h_consts129, int32_t* d_post_q,
+                   int16_t* d_lut, int32_t* d_dq)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (R <= 0 || R > 32767 || S2 <= 0 || S2 > 65536) return fail(KBBQ_E_ARG, "kbbq_solve_dev: bad shape R=%d S2=%d", R, S2);
+    if (!d_tables || !d_meanq || !d_aux || !d_post_q || !d_lut) return fail(KBBQ_E_ARG, "kbbq_solve_dev: NULL device pointer");
+    HIPCHK(hipSetDevice(c->device));
+    K3FusedParams p;
+    p.tables = (const long long*)d_tables; p.R = R; p.S2 = S2; p.rs = lut_row_stride(S2);
+    p.meanq = d_meanq; p.aux = d_aux; p.post_q = d_post_q; p.lut = d_lut; p.dq = d_dq;
+    int rc = load_consts(p.c, h_consts129);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k3_levels_ab, dim3((unsigned)R), dim3(64), 0, c->stream, p);
+    const int64_t cells = (int64_t)R * KQ * ((int64_t)S2 + KND);
+    int gx = (int)std::min<int64_t>((cells + 255) / 256, (int64_t)c->cus * 8);
+    hipLaunchKernelGGL(k3_level_c, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
 }
@@ -441,7 +508,8 @@ int kbbq_apply(kbbq_ctx* c, const uint8_t* seq, const uint8_t* qual, const uint3
     if (nreads < 0 || pitch <= 0 || (pitch & 15)) return fail(KBBQ_E_ARG, "kbbq_apply: bad nreads/pitch");
     HIPCHK(hipSetDevice(c->device));
     std::vector<int16_t> lut(kbbq_lut_count(R, Qt, S2));
-    int rc = kbbq_build_lut(R, Qt, S2, D, meanq, rgdq, qdq, posdq, dinucdq, lut.data());
+    int range_safe = 0;
+    int rc = kbbq_build_lut(R, Qt, S2, D, meanq, rgdq, qdq, posdq, dinucdq, lut.data(), &range_safe);
     if (rc) return rc;
     const size_t plane = (size_t)nreads * pitch;
     DevBuf ds, dq, dm, dl, dout;
@@ -452,7 +520,7 @@ int kbbq_apply(kbbq_ctx* c, const uint8_t* seq, const uint8_t* qual, const uint3
     HIPCHK(hipMemcpyAsync(dm.p, meta, (size_t)nreads * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(dl.p, lut.data(), lut.size() * 2, hipMemcpyHostToDevice, c->stream));
     rc = kbbq_apply_dev(c, (const uint8_t*)ds.p, (const uint8_t*)dq.p, (const uint32_t*)dm.p, nreads, pitch,
-                        R, Qt, S2, minscore, (const int16_t*)dl.p, (uint8_t*)dout.p);
+                        R, Qt, S2, minscore, (const int16_t*)dl.p, range_safe, (uint8_t*)dout.p);
     if (rc) return rc;
     rc = kbbq_ctx_status(c, nullptr);
     if (rc) return rc;

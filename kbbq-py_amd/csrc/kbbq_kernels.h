@@ -282,25 +282,69 @@ __global__ __launch_bounds__(K1_THREADS) void k1_accumulate(K1Params p)
 }
 
 // ---------------------------------------------------------------- K2
-// LUT (int16): lut1[R][Qt][S2] then lut2[R][Qt][17]; staged in LDS when it fits.
+// LUT (int16), one row of `rs` entries per (read group, quality):
+//     row[0 .. S2-1]      = meanq + rgdq + qdq + posdq[cycle]          (lut1)
+//     row[S2 .. S2+24]    = dinucdq[5 * code(prev) + code(cur)]        (lut2, code N/none = 4:
+//                           every entry that involves code 4 holds dinucdq[..., -1])
+// rs = lut_row_stride(S2): rs / 2 is odd so that consecutive rows start on different banks.
+__host__ __device__ __forceinline__ int lut_row_stride(int S2)
+{
+    int rs = (S2 + 25 + 1) & ~1;
+    if (((rs >> 1) & 1) == 0) rs += 2;
+    return rs;
+}
+
+// Exact per-base restatement of compare_reads.py:320-328 for ONE chunk, used whenever the
+// fast path cannot be taken (read group / quality / cycle beyond the tables).  Reads the LUT
+// from global memory.  Returns the 16 output bytes through o[4].
+__device__ __noinline__ uint4 chunk_apply_exact(const int16_t* lut, int rs, int R, int Qt, int S2,
+                                               u32 qlo, int rg, bool second, int pos0, int nb,
+                                               u32 q0, u32 q1, u32 q2, u32 q3,
+                                               u32 d0, u32 d1, u32 d2, u32 d3,
+                                               u64* status, long long read)
+{
+    const u32 q[4] = {q0, q1, q2, q3};
+    const u32 d5[4] = {d0, d1, d2, d3};
+    u32 o[4] = {0u, 0u, 0u, 0u};
+    for (int i = 0; i < 16; ++i) {
+        const u32 qb = (q[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        u32 ob = qb;
+        if (i < nb && qb >= qlo) {
+            const int qq = (int)qb - 33;
+            const int pos = pos0 + i;
+            const int col = second ? (S2 - 1 - pos) : pos;           // Python wrap of -(i+1) on S2
+            if (rg >= R || qq >= Qt || col < 0 || col >= S2) flag(status, ST_INDEX, read);
+            else {
+                const int16_t* row = lut + ((size_t)rg * Qt + qq) * rs;
+                const int v = (int)row[col] + (int)row[S2 + (int)((d5[i >> 2] >> (8 * (i & 3))) & 0xFFu)] + 33;
+                if (v < 0 || v > 255) flag(status, ST_RANGE, read);
+                ob = (u32)v & 0xFFu;
+            }
+        }
+        if (i >= nb) ob = 0u;
+        o[i >> 2] |= ob << (8 * (i & 3));
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+template <bool LDS_LUT, bool CHECK_RANGE>
 __global__ __launch_bounds__(K2_THREADS) void k2_apply(K2Params p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
-    const int16_t* lut = p.lut;
-    if (p.lut_in_lds) {
-        int16_t* l = reinterpret_cast<int16_t*>(lds);
+    if (LDS_LUT) {
         const u32* src = reinterpret_cast<const u32*>(p.lut);
-        const int nw = (p.lut_count + 1) >> 1;
+        const int nw = p.lut_count >> 1;
         for (int i = threadIdx.x; i < nw; i += blockDim.x) lds[i] = src[i];
         __syncthreads();
-        lut = l;
     }
-    const int16_t* lut2 = lut + (size_t)p.R * p.Qt * p.S2;
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int nwaves = blockDim.x >> 6;
     const long long nblocks = (p.nreads + 63) >> 6;
     const u32 qlo = p.qlo;
+    const int rs = lut_row_stride(p.S2);
+    const u32 rs2 = (u32)rs * 2u;                               // row stride in bytes
+    const u32 hi_add = (u32)(0x80 - (p.Qt + 33)) * 0x01010101u; // byte >= Qt+33  <=>  bit 7 of byte + hi_add
 
     for (long long blk = (long long)blockIdx.x * nwaves + wave; blk < nblocks;
          blk += (long long)gridDim.x * nwaves) {
@@ -309,7 +353,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_apply(K2Params p)
         const u32 m = myread < p.nreads ? p.meta[myread] : 0u;
         const int n = (int)((p.nreads - read0) < 64 ? (p.nreads - read0) : 64);
         const int total = n * p.cpr;
-        u32 carry_code = 0x10u, carry_char = 0u;
+        u32 carry_code = 4u, carry_char = 0u;
         for (int w0 = 0; w0 < total; w0 += 64) {
             const int w = w0 + lane;
             const bool act0 = w < total;
@@ -331,12 +375,14 @@ __global__ __launch_bounds__(K2_THREADS) void k2_apply(K2Params p)
                 s[0] = sv.x; s[1] = sv.y; s[2] = sv.z; s[3] = sv.w;
                 q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
             }
-            u32 code[4], badbits = 0u;
+            u32 code[4], badbits = 0u, hiq = 0u;
 #pragma unroll
             for (int wd = 0; wd < 4; ++wd) {
-                u32 expect;
-                decode4(s[wd], expect, code[wd]);
+                const u32 h = (s[wd] >> 1) & 0x07070707u;
+                const u32 expect = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, h);
+                code[wd] = __builtin_amdgcn_perm(0x04040404u, 0x02010300u, h);   // A0 T1 G2 C3, N/other 4
                 badbits |= (expect ^ s[wd]) & byte_mask(nb, wd);
+                hiq |= (((q[wd] & 0x7F7F7F7Fu) + hi_add) | q[wd]) & 0x80808080u;   // some q >= Qt
             }
             const u32 last_code = code[3] >> 24;
             const u32 last_char = s[3] >> 24;
@@ -344,45 +390,55 @@ __global__ __launch_bounds__(K2_THREADS) void k2_apply(K2Params p)
             u32 prev_char = wave_shr1(last_char, carry_char);
             carry_code = (u32)__builtin_amdgcn_readlane((int)last_code, 63);
             carry_char = (u32)__builtin_amdgcn_readlane((int)last_char, 63);
-            if (j == 0) { prev_code = 0x10u; prev_char = 0u; }
-            if (act0 && pos0 < p.pitch) {
+            if (j == 0) { prev_code = 4u; prev_char = 0u; }           // dinuc[0] = -1
+            if (act0) {
                 u32 o[4] = {0u, 0u, 0u, 0u};
                 if (act) {
-                    if (badbits && chunk_type_error(s[0], s[1], s[2], s[3], q[0], q[1], q[2], q[3], prev_char, nb, pos0, p.minscore))
+                    if (badbits && chunk_type_error(s[0], s[1], s[2], s[3], q[0], q[1], q[2], q[3],
+                                                    prev_char, nb, pos0, p.minscore))
                         flag(p.status, ST_TYPE, read);
-                    bool idx_err = rg >= p.R;
-                    const int rgc = rg < p.R ? rg : 0;
-                    int col = second ? (p.S2 - 1 - pos0) : pos0;     // compare_reads.py:325: Python wrap on S2
-                    const int dcol = second ? -1 : 1;
-                    u32 pc = prev_code << 24;        // alignbyte below takes byte 3 of the previous word
+                    // 5 * code(prev) + code(cur) for the 16 bases
+                    u32 d5[4];
+                    u32 pc = prev_code << 24;
 #pragma unroll
                     for (int wd = 0; wd < 4; ++wd) {
                         const u32 pw = __builtin_amdgcn_alignbyte(code[wd], pc, 3);
-                        const u32 dw = (pw << 2) + code[wd];
+                        d5[wd] = (pw << 2) + pw + code[wd];
                         pc = code[wd];
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const int i = 4 * wd + b;
-                            const u32 qb = (q[wd] >> (8 * b)) & 0xFFu;
-                            u32 ob = qb;                                  // q < minscore: unchanged (:322-323)
-                            if (i < nb && qb >= qlo) {
-                                const int qq = (int)qb - 33;
-                                if (qq >= p.Qt || col < 0 || col >= p.S2) idx_err = true;
-                                else {
-                                    u32 d = (dw >> (8 * b)) & 0xFFu;
-                                    d = d < 16u ? d : 16u;               // index -1 -> pad column (applybqsr.py:98-101)
-                                    const int cell = rgc * p.Qt + qq;
-                                    const int v = (int)lut[(size_t)cell * p.S2 + col] + (int)lut2[cell * 17 + (int)d] + 33;
-                                    if (v < 0 || v > 255) flag(p.status, ST_RANGE, read);
-                                    ob = (u32)v & 0xFFu;
-                                }
-                            }
-                            if (i >= nb) ob = 0u;
-                            o[wd] |= ob << (8 * b);
-                            col += dcol;
-                        }
                     }
-                    if (idx_err) flag(p.status, ST_INDEX, read);
+                    const bool trouble = hiq != 0u || rg >= p.R || len > p.S2;
+                    if (trouble || !LDS_LUT) {
+                        const uint4 e = chunk_apply_exact(p.lut, rs, p.R, p.Qt, p.S2, qlo, rg, second, pos0, nb,
+                                                          q[0], q[1], q[2], q[3], d5[0], d5[1], d5[2], d5[3],
+                                                          p.status, read);
+                        o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = e.w;
+                    } else {
+                        // fast path: every index is in range; bytes beyond the read are 0 (< qlo) and pass through
+                        const u32 rowbase = (u32)rg * (u32)p.Qt * rs2 - 33u * rs2;
+                        u32 colb = rowbase + (u32)(second ? (p.S2 - 1 - pos0) : pos0) * 2u;
+                        const u32 dcol = second ? (u32)-2 : 2u;
+                        const u32 dnb = rowbase + (u32)p.S2 * 2u;
+                        bool range_err = false;
+#pragma unroll
+                        for (int wd = 0; wd < 4; ++wd) {
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const u32 qb = (q[wd] >> (8 * b)) & 0xFFu;
+                                const u32 qc = qb > 33u ? qb : 33u;               // keep the address inside the LUT
+                                const u32 rowq = __umul24(qc, rs2);
+                                const u32 dd = (d5[wd] >> (8 * b)) & 0xFFu;
+                                const int v1 = *reinterpret_cast<const int16_t*>(reinterpret_cast<const char*>(lds) + (rowq + colb));
+                                const int v2 = *reinterpret_cast<const int16_t*>(reinterpret_cast<const char*>(lds) + (rowq + dnb + dd * 2u));
+                                const int v = v1 + v2 + 33;
+                                const bool counted = qb >= qlo;
+                                if (CHECK_RANGE) range_err |= counted && (u32)v > 255u;
+                                const u32 ob = counted ? ((u32)v & 0xFFu) : qb;
+                                o[wd] |= ob << (8 * b);
+                                colb += dcol;
+                            }
+                        }
+                        if (CHECK_RANGE && range_err) flag(p.status, ST_RANGE, read);
+                    }
                 }
                 *reinterpret_cast<uint4*>(p.out + rowoff) = make_uint4(o[0], o[1], o[2], o[3]);
             }

@@ -131,20 +131,22 @@ def build_lut(meanq, rgdq, qdq, posdq, dinucdq):
     if a[0].shape != (R,) or a[1].shape != (R,) or a[2].shape != (R, Qt) or a[4].shape[:2] != (R, Qt):
         raise IndexError('delta-Q tables have inconsistent shapes')
     lut = np.zeros(N.load().kbbq_lut_count(R, Qt, S2), dtype=np.int16)
+    safe = ctypes.c_int(0)
     N.check(N.load().kbbq_build_lut(R, Qt, S2, D, N.ptr(a[0]), N.ptr(a[1]), N.ptr(a[2]), N.ptr(a[3]),
-                                    N.ptr(a[4]), N.ptr(lut)))
-    return lut, (R, Qt, S2)
+                                    N.ptr(a[4]), N.ptr(lut), ctypes.byref(safe)))
+    return lut, (R, Qt, S2, safe.value)
 
 
 def apply(batch, lut_dev, shape, out=None, minscore=MINSCORE, check=True):
     """K2 over a device batch: new quality bytes [n, pitch] (compare_reads.py:320-328)."""
     torch = _torch()
-    R, Qt, S2 = shape
+    R, Qt, S2, range_safe = shape
     ctx = context(batch.seq.device.index)
     if out is None:
         out = torch.empty_like(batch.qual)
     N.check(N.load().kbbq_apply_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.qual), N.ptr(batch.meta),
-                                    batch.n, batch.pitch, R, Qt, S2, minscore, N.ptr(lut_dev), N.ptr(out)))
+                                    batch.n, batch.pitch, R, Qt, S2, minscore, N.ptr(lut_dev),
+                                    range_safe, N.ptr(out)))
     if check:
         ctx.status()
     return out
@@ -153,3 +155,67 @@ def apply(batch, lut_dev, shape, out=None, minscore=MINSCORE, check=True):
 def lut_to_device(lut, device=None):
     torch = _torch()
     return torch.from_numpy(lut).to('cuda' if device is None else device)
+
+
+_consts = None
+
+
+def _model_consts():
+    global _consts
+    if _consts is None:
+        from . import _solve
+        _consts = _solve.model_consts()
+    return _consts
+
+
+def delta_q(prior_q, numerrs, numtotal):
+    """K3, generic form: compare_reads.gatk_delta_q on the device (host: gammaln terms)."""
+    from . import _solve
+    torch = _torch()
+    pq = np.ascontiguousarray(np.asarray(prior_q), dtype=np.int64)
+    e = np.ascontiguousarray(np.asarray(numerrs), dtype=np.int64)
+    t = np.ascontiguousarray(np.asarray(numtotal), dtype=np.int64)
+    assert pq.shape == e.shape == t.shape
+    if pq.size and (pq.min() < 0 or pq.max() > MAXSCORE):
+        raise IndexError('index %d is out of bounds for axis 0 with size %d'
+                         % (int(np.abs(pq).max()), MAXSCORE + 1))   # prior_dist[|q' - prior_q|]
+    if pq.size == 0:
+        return np.zeros(pq.shape, dtype=np.int_)
+    comb = np.ascontiguousarray(_solve.combiln(e, t), dtype=np.float64)
+    ctx = context()
+    d = [torch.from_numpy(x.ravel()).cuda() for x in (pq, e, t, comb)]
+    out = torch.empty(pq.size, dtype=torch.int64, device='cuda')
+    N.check(N.load().kbbq_delta_q_dev(ctx.handle, N.ptr(d[0]), N.ptr(d[1]), N.ptr(d[2]), N.ptr(d[3]),
+                                      pq.size, N.ptr(_model_consts()), N.ptr(out)))
+    return out.cpu().numpy().reshape(pq.shape).astype(np.int_)
+
+
+def solve(tables, want_dq=False):
+    """K3, fused form: count tables (device) -> apply LUT (device), the whole of
+    applybqsr.get_delta_qs.  Host work: marginals, meanq and the gammaln terms.
+    Returns (lut_dev, shape, vectors, dqs) -- dqs is None unless want_dq."""
+    from . import _solve
+    torch = _torch()
+    R, S2 = tables.R, tables.S2
+    vectors = _solve.vectors_from_tables(*tables.to_host())
+    meanq, rg_e, rg_t, q_e, q_t, p_e, p_t, d_e, d_t = vectors
+    aux = np.concatenate([_solve.combiln(rg_e, rg_t).ravel(), _solve.combiln(q_e, q_t).ravel(),
+                          _solve.combiln(p_e, p_t).ravel(), _solve.combiln(d_e, d_t).ravel()])
+    lib = N.load()
+    assert aux.size == lib.kbbq_solve_aux_count(R, S2)
+    dev = tables.buf.device
+    d_aux = torch.from_numpy(np.ascontiguousarray(aux, dtype=np.float64)).to(dev)
+    d_meanq = torch.from_numpy(np.ascontiguousarray(meanq, dtype=np.int32)).to(dev)
+    post_q = torch.empty(R * NQ, dtype=torch.int32, device=dev)
+    lut = torch.empty(lib.kbbq_lut_count(R, NQ, S2), dtype=torch.int16, device=dev)
+    dq = torch.empty(lib.kbbq_solve_dq_count(R, S2), dtype=torch.int32, device=dev) if want_dq else None
+    ctx = context(dev.index)
+    N.check(lib.kbbq_solve_dev(ctx.handle, N.ptr(tables.buf), R, S2, N.ptr(d_meanq), N.ptr(d_aux),
+                               N.ptr(_model_consts()), N.ptr(post_q), N.ptr(lut), N.ptr(dq)))
+    dqs = None
+    if want_dq:
+        h = dq.cpu().numpy().astype(np.int_)
+        o1, o2, o3 = R, R + R * NQ, R + R * NQ + R * NQ * S2
+        dqs = (h[:o1].copy(), h[o1:o2].reshape(R, NQ).copy(), h[o2:o3].reshape(R, NQ, S2).copy(),
+               h[o3:].reshape(R, NQ, 17).copy())
+    return lut, (R, NQ, S2, 0), vectors, dqs

@@ -47,10 +47,15 @@ PROTOTYPES = {
     'kbbq_accumulate_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     'kbbq_accumulate_ex_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     'kbbq_accumulate': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    'kbbq_build_lut': (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'kbbq_apply_dev': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
+    'kbbq_lut_row_stride': (_i, [_i]),
+    'kbbq_build_lut': (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(_i)]),
+    'kbbq_apply_dev': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'kbbq_apply': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i,
                         _vp, _vp, _vp, _vp, _vp, _vp]),
+    'kbbq_delta_q_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    'kbbq_solve_aux_count': (_sz, [_i, _i]),
+    'kbbq_solve_dq_count': (_sz, [_i, _i]),
+    'kbbq_solve_dev': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kbbq_synth_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _u64,
                             _i, _i, _i, _i, _i, _vp]),
     'kbbq_ctx_timing': (_i, [_vp, _i]),
@@ -158,7 +163,7 @@ class Context:
             pass
 
     def set_stream(self, stream_ptr):
-        check(load().kbbq_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr) if stream_ptr else None))
+        check(load().kbbq_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr) if stream_ptr else None))   # 0 = null stream
 
     def sync(self):
         check(load().kbbq_ctx_sync(self._h))

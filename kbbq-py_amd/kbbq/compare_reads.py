@@ -9,13 +9,13 @@ per-read apply recalibrate_fastq.  The BAM/VCF truth-set helpers and the
 regression experiment of the reference file are out of scope.
 
 What runs where: the per-read apply goes through the K2 HIP kernel (C ABI
-kbbq_apply); the model numerics below are host NumPy/SciPy with the same
-library calls as the reference so the integer results are identical (SURVEY
-hazards H4/H5); the small covariate helpers are plain NumPy views of the same
+kbbq_apply) and gatk_delta_q through the K3 kernel (kbbq_delta_q_dev, with the
+transcendental terms from the host's SciPy, kbbq/_solve.py); p_to_q / q_to_p and
+the prior table are host NumPy with the reference's own calls (SURVEY hazards
+H4/H5); the small covariate helpers are plain NumPy views of the same
 definitions the kernels implement.
 """
 import numpy as np
-import scipy.stats
 
 from . import _native as N
 
@@ -94,30 +94,15 @@ def p_to_q(p, maxscore=_MAXSCORE):
 
 def gatk_delta_q(prior_q, numerrs, numtotal, maxscore=_MAXSCORE):
     """MAP quality minus prior quality for every cell (reference compare_reads.py:235-260):
-    argmax over q' = 0..maxscore of  prior_dist[|q' - prior_q|] + logpmf(errs+1; total+2, 10^(-q'/10)),
-    first maximum wins.  Same SciPy call as the reference; evaluated one candidate at
-    a time so no [43, ...] temporaries are built."""
+    argmax over q' = 0..42 of  prior_dist[|q' - prior_q|] + logpmf(errs+1; total+2, 10^(-q'/10)),
+    first maximum wins.  Runs on the device (K3 kernel, C ABI kbbq_delta_q_dev); the host
+    supplies the gammaln terms with the SciPy functions logpmf itself uses (kbbq._solve)."""
     prior_q = np.asarray(prior_q)
-    numerrs = np.asarray(numerrs)
-    numtotal = np.asarray(numtotal)
-    assert prior_q.shape == numerrs.shape == numtotal.shape
-    pq = prior_q.astype(np.int_).ravel()
-    k = (numerrs.ravel() + 1)
-    n = (numtotal.ravel() + 2)
-    pvals = q_to_p(np.arange(maxscore + 1, dtype=np.int_)).astype(np.float64)
-    best = np.full(pq.shape, -np.inf, dtype=np.longdouble)
-    arg = np.zeros(pq.shape, dtype=np.int_)
-    have = np.zeros(pq.shape, dtype=bool)
-    for cand in range(maxscore + 1):
-        prior = RescaledNormal.prior_dist[np.absolute(cand - pq)]
-        post = prior + scipy.stats.binom.logpmf(k, n, pvals[cand])
-        # np.argmax semantics: the first maximum wins and a NaN counts as the maximum
-        isn = np.isnan(post)
-        better = ((post > best) & ~have & ~isn) | (isn & ~have)
-        have |= isn
-        arg[better] = cand
-        best[better] = post[better]
-    return (arg - pq).reshape(prior_q.shape)
+    assert prior_q.shape == np.shape(numerrs) == np.shape(numtotal)
+    if maxscore != _MAXSCORE:
+        raise ValueError('the prior table and the device solve are fixed at maxscore = 42')
+    from ._device import delta_q
+    return delta_q(prior_q, numerrs, numtotal)
 
 
 def generic_cycle_covariate(sequencelen, secondinpair=False):

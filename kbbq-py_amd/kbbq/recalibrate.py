@@ -17,6 +17,7 @@ import numpy as np
 from . import compare_reads as utils
 from . import fastx
 from . import _device as dev
+from . import _solve
 from .gatk import applybqsr
 
 
@@ -31,60 +32,61 @@ def find_corrected_sites(uncorr_read, corr_read):
 
 
 def _vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore):
-    """q_* and rg_* are marginals of pos_* (every counted base has exactly one cycle);
-    meanq comes from the per-score totals in longdouble."""
-    q_errs, q_total = pos_errs.sum(axis=2), pos_total.sum(axis=2)
-    rg_errs, rg_total = q_errs.sum(axis=1), q_total.sum(axis=1)
-    expected = (q_total.astype(np.longdouble) * utils.q_to_p(np.arange(maxscore + 1))).sum(axis=1)
-    with np.errstate(divide='ignore', invalid='ignore'):
-        meanq = utils.p_to_q(expected / rg_total, maxscore)
-    return meanq, rg_errs, rg_total, q_errs, q_total, pos_errs, pos_total, dinuc_errs, dinuc_total
+    return _solve.vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore)
 
 
 def _tally(packed, minscore, maxscore, upto=None):
-    """K1 over the packed pair (optionally only its first `upto` reads)."""
+    """K1 over the packed pair (optionally only its first `upto` reads) -> device Tables."""
     if maxscore != 42:
         raise ValueError('the Q axis of the device tables is fixed at 43 (maxscore = 42)')
     n = packed['n'] if upto is None else upto
     R, S = max(packed['R'], 0), packed['S']
     if n == 0 or R == 0:
-        z = lambda *s: np.zeros(s, dtype=np.int64)
-        return z(R, 43, 2 * S), z(R, 43, 2 * S), z(R, 43, 16), z(R, 43, 16)
+        return None
     batch = dev.ReadBatch.from_host(packed['seq'][:n], packed['qual'][:n], packed['meta'][:n],
                                     cseq=packed['cseq'][:n])
     tables = dev.Tables(R, 2 * S)
     dev.accumulate(batch, tables, minscore)
-    return tables.to_host()
+    return tables
 
 
-def fastq_to_covariate_arrays(fastq, infer_rg=False, minscore=6, maxscore=42):
-    """Tally errors and observations of the (uncorrected, corrected) FASTQ pair by read
-    group, reported quality, cycle and dinucleotide.  Returns the reference's 9-tuple:
-    meanq, rg_errs, rg_total, q_errs, q_total, pos_errs, pos_total, dinuc_errs, dinuc_total."""
+def _pack_and_tally(fastq, infer_rg, minscore, maxscore):
     packed = fastx.pack_pair(fastq[0], fastq[1], infer_rg)
     err = packed.get('pending_error')
     if err is not None:
         # the reference fails at the FIRST offending read: let the kernel look at the reads
         # before it (and at it, when its own checks come first) before raising the host error
         idx, exc, inclusive = err
-        _tally(packed, minscore, maxscore, upto=idx + (1 if inclusive else 0))
+        _tally(packed, minscore, maxscore)
         raise exc
-    tabs = _tally(packed, minscore, maxscore)
-    return _vectors_from_tables(*tabs, maxscore)
+    return packed, _tally(packed, minscore, maxscore)
+
+
+def fastq_to_covariate_arrays(fastq, infer_rg=False, minscore=6, maxscore=42):
+    """Tally errors and observations of the (uncorrected, corrected) FASTQ pair by read
+    group, reported quality, cycle and dinucleotide.  Returns the reference's 9-tuple:
+    meanq, rg_errs, rg_total, q_errs, q_total, pos_errs, pos_total, dinuc_errs, dinuc_total."""
+    packed, tables = _pack_and_tally(fastq, infer_rg, minscore, maxscore)
+    if tables is None:
+        z = lambda *s: np.zeros(s, dtype=np.int64)
+        R, S = packed['R'], packed['S']
+        return _vectors_from_tables(z(R, 43, 2 * S), z(R, 43, 2 * S), z(R, 43, 16), z(R, 43, 16), maxscore)
+    return _vectors_from_tables(*tables.to_host(), maxscore)
 
 
 def recalibrate_fastq(fastq, infer_rg=False):
     """Recalibrate FASTQ file fastq[0] using its error-corrected version fastq[1];
-    the recalibrated FASTQ is printed to stdout."""
-    meanq, *vectors = fastq_to_covariate_arrays(fastq, infer_rg)
-    dqs = applybqsr.get_delta_qs(meanq, *vectors)
-    text = fastx.FastqText(fastq[0])
-    single = fastx.pack_single(text, infer_rg)
+    the recalibrated FASTQ is printed to stdout.  K1 -> K3 -> K2, tables and LUT stay on
+    the device between the kernels."""
+    packed, tables = _pack_and_tally(fastq, infer_rg, 6, 42)
+    single = fastx.pack_single(packed['text'], infer_rg)
     if single['n'] == 0:
         return
-    lut, shape = dev.build_lut(meanq, *dqs)
+    if tables is None:
+        raise IndexError('index 0 is out of bounds for axis 0 with size 0')   # no read was tallied
+    lut, shape, _, _ = dev.solve(tables)
     batch = dev.ReadBatch.from_host(single['seq'], single['qual'], single['meta'])
-    out = dev.apply(batch, dev.lut_to_device(lut), shape)
+    out = dev.apply(batch, lut, shape)
     newq = out[:single['n']].cpu().numpy()
     lens = (single['meta'] & 0xFFFF).astype(np.int64)
     print(fastx.format_fastq(single['names'], single['seq'], newq, lens), end='')

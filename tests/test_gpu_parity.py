@@ -142,6 +142,68 @@ def test_host_buffer_entry_points(dev, oracle):
     assert np.array_equal(out[inside].astype(np.int32) - 33, ref[inside])
 
 
+# ------------------------------------------------------------------ K3: model solve
+def test_k3_delta_q_matches_reference_grid_and_oracle(dev, oracle):
+    from kbbq import compare_reads
+    _, gold = load_golden('numeric')
+    errs, tot = gold['grid_errs'], gold['grid_total']
+    prior_q = np.broadcast_to(np.arange(43)[:, None], (43, len(errs))).copy()
+    be = np.broadcast_to(errs, prior_q.shape).copy(); bt = np.broadcast_to(tot, prior_q.shape).copy()
+    dq = compare_reads.gatk_delta_q(prior_q, be, bt)
+    assert dq.shape == prior_q.shape and np.array_equal(dq, gold['grid_dq'])
+    # reference tests/test_compare_reads.py:141-151
+    p = np.array([10, 20, 30])
+    d = compare_reads.gatk_delta_q(p, np.array([10, 200, 0]), np.array([1000, 1000, 50000]))
+    assert d[0] > 0 and d[1] < 0 and d[2] > 0 and np.all(d + p <= 42) and np.all(d + p > 0)
+    # adversarial cells: tiny and empty cells, errs == total, counts up to 3e10
+    rng = np.random.default_rng(2025)
+    n = 60000
+    t = (10 ** rng.uniform(0, 10.5, n)).astype(np.int64)
+    e = np.minimum((t * 10 ** (-rng.uniform(0, 5, n))).astype(np.int64), t)
+    t[:500] = rng.integers(0, 6, 500); e[:500] = np.minimum(rng.integers(0, 4, 500), t[:500])
+    e[500:800] = t[500:800]; e[800:1100] = 0
+    pq = rng.integers(0, 43, n)
+    assert np.array_equal(compare_reads.gatk_delta_q(pq, e, t), oracle.gatk_delta_q(pq, e, t))
+    # outside the support / outside the prior table
+    assert list(compare_reads.gatk_delta_q(np.array([5, 5]), np.array([10, -3]), np.array([3, 4]))) == \
+        list(oracle.gatk_delta_q(np.array([5, 5]), np.array([10, -3]), np.array([3, 4])))
+    with pytest.raises(IndexError):
+        compare_reads.gatk_delta_q(np.array([43]), np.array([0]), np.array([0]))
+
+
+@pytest.mark.parametrize('name', ['c1_10k_1rg', 'c3cut_2k_8rg', 'c5cut_2k_mixed', 'q42_500_3rg', 'short_64_1rg'])
+def test_k3_get_delta_qs_and_fused_solve_match_reference(dev, name):
+    import torch
+    from kbbq.gatk import applybqsr
+    _, g = load_golden(name)
+    dqs = applybqsr.get_delta_qs(g['meanq'], g['rg_errs'], g['rg_total'], g['q_errs'], g['q_total'],
+                                 g['pos_errs'], g['pos_total'], g['dinuc_errs'], g['dinuc_total'])
+    for k, v in zip(DQ, dqs):
+        assert np.array_equal(v, g[k]), k
+    # fused: golden count tables on the device -> LUT + delta tables
+    R, _, S2 = g['pos_total'].shape
+    t = dev.Tables(R, S2)
+    flat = np.concatenate([g[k].ravel() for k in ('pos_errs', 'pos_total', 'dinuc_errs', 'dinuc_total')])
+    t.buf.copy_(torch.from_numpy(flat))
+    lut, shape, vectors, fdq = dev.solve(t, want_dq=True)
+    for k, v in zip(VEC, vectors):
+        assert np.array_equal(v, g[k]), k
+    for k, v in zip(DQ, fdq):
+        assert np.array_equal(v, g[k]), k
+    want_lut, want_shape = dev.build_lut(g['meanq'], g['rgdq'], g['qdq'], g['posdq'], g['dinucdq'])
+    assert shape[:3] == want_shape[:3]
+    assert np.array_equal(lut.cpu().numpy(), want_lut)
+
+
+def test_get_delta_qs_known_answer(dev):
+    # reference tests/test_gatk_applybqsr.py:105-121
+    from kbbq.gatk import applybqsr
+    a = applybqsr.get_delta_qs(np.array([10]), np.array([0]), np.array([1000]), np.array([[0]]),
+                               np.array([[1000]]), np.array([[[0]]]), np.array([[[1000]]]),
+                               np.array([[[0]]]), np.array([[[1000]]]))
+    assert [x.tolist() for x in a] == [[3], [[2]], [[[1]]], [[[1, 0]]]]
+
+
 # ------------------------------------------------------------------ drop-in API vs reference goldens
 @pytest.mark.parametrize('name', GOLDEN_CASES)
 def test_dropin_api_matches_reference_goldens(dev, oracle, name, tmp_path, capfd):

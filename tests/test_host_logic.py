@@ -5,6 +5,7 @@ symbol include/kbbq_hip.h declares, the FASTQ packer, the model numerics
 classes (restating the reference's tests/test_covariate.py and tests/test_read.py).
 No kernel is launched here.
 """
+import ctypes
 import os
 import re
 
@@ -15,7 +16,6 @@ from conftest import ROOT, load_golden
 
 import kbbq
 from kbbq import _native, compare_reads, covariate, fastx, read
-from kbbq.gatk import applybqsr
 
 
 # ---------------------------------------------------------------- C ABI
@@ -31,6 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.kbbq_abi_version() == 1
     assert lib.kbbq_tables_count(2, 300) == 2 * 2 * 43 * 300 + 2 * 2 * 43 * 16
     assert lib.kbbq_lut_count(1, 43, 300) % 2 == 0
+    assert lib.kbbq_lut_row_stride(300) == 326
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -51,15 +52,28 @@ def test_build_lut_host():
     meanq = rng.integers(0, 40, R); rgdq = rng.integers(-3, 3, R)
     qdq = rng.integers(-3, 3, (R, Qt)); posdq = rng.integers(-5, 5, (R, Qt, S2))
     ddq = rng.integers(-5, 5, (R, Qt, D)); ddq[..., 16] = 0
+    rs = lib.kbbq_lut_row_stride(S2)
+    assert rs >= S2 + 25 and rs % 2 == 0 and (rs // 2) % 2 == 1
+    assert lib.kbbq_lut_count(R, Qt, S2) == R * Qt * rs
     lut = np.zeros(lib.kbbq_lut_count(R, Qt, S2), dtype=np.int16)
     a = [np.ascontiguousarray(x, dtype=np.int64) for x in (meanq, rgdq, qdq, posdq, ddq)]
-    _native.check(lib.kbbq_build_lut(R, Qt, S2, D, *[_native.ptr(x) for x in a], _native.ptr(lut)))
-    l1 = lut[:R * Qt * S2].reshape(R, Qt, S2)
-    l2 = lut[R * Qt * S2:R * Qt * (S2 + 17)].reshape(R, Qt, 17)
-    assert np.array_equal(l1, (meanq + rgdq)[:, None, None] + qdq[..., None] + posdq)
-    assert np.array_equal(l2, ddq)
+    safe = ctypes.c_int(-1)
+    _native.check(lib.kbbq_build_lut(R, Qt, S2, D, *[_native.ptr(x) for x in a], _native.ptr(lut),
+                                     ctypes.byref(safe)))
+    rows = lut.reshape(R, Qt, rs)
+    assert np.array_equal(rows[..., :S2], (meanq + rgdq)[:, None, None] + qdq[..., None] + posdq)
+    for pa in range(5):
+        for pb in range(5):
+            want = ddq[..., 4 * pa + pb] if pa < 4 and pb < 4 else ddq[..., 16]
+            assert np.array_equal(rows[..., S2 + 5 * pa + pb], want)
+    assert safe.value == 1
+    a[3][0, 0, 0] = 300
+    _native.check(lib.kbbq_build_lut(R, Qt, S2, D, *[_native.ptr(x) for x in a], _native.ptr(lut),
+                                     ctypes.byref(safe)))
+    assert safe.value == 0
     with pytest.raises(ValueError):
-        _native.check(lib.kbbq_build_lut(R, Qt, S2, 3, *[_native.ptr(x) for x in a], _native.ptr(lut)))
+        _native.check(lib.kbbq_build_lut(R, Qt, S2, 3, *[_native.ptr(x) for x in a], _native.ptr(lut),
+                                         ctypes.byref(safe)))
 
 
 # ---------------------------------------------------------------- FASTQ packer
@@ -138,34 +152,6 @@ def test_prior_and_q_p_tables_match_reference():
     assert [int(x) for x in compare_reads.p_to_q(np.array(s['p']))] == s['q']
     assert np.array_equal(compare_reads.p_to_q(np.array([.2, .3, .4, .1, .01, .001])),
                           np.array([6, 5, 3, 10, 20, 30]))
-
-
-def test_gatk_delta_q_matches_reference_grid(oracle):
-    _, gold = load_golden('numeric')
-    errs, tot = gold['grid_errs'], gold['grid_total']
-    prior_q = np.broadcast_to(np.arange(43)[:, None], (43, len(errs))).copy()
-    be = np.broadcast_to(errs, prior_q.shape).copy(); bt = np.broadcast_to(tot, prior_q.shape).copy()
-    dq = compare_reads.gatk_delta_q(prior_q, be, bt)
-    assert np.array_equal(dq, gold['grid_dq'])
-    assert np.array_equal(dq, oracle.gatk_delta_q(prior_q, be, bt))
-    # reference tests/test_compare_reads.py:141-151
-    p = np.array([10, 20, 30])
-    d = compare_reads.gatk_delta_q(p, np.array([10, 200, 0]), np.array([1000, 1000, 50000]))
-    assert d[0] > 0 and d[1] < 0 and d[2] > 0 and np.all(d + p <= 42) and np.all(d + p > 0)
-
-
-@pytest.mark.parametrize('name', ['c1_10k_1rg', 'c5cut_2k_mixed', 'q42_500_3rg'])
-def test_get_delta_qs_matches_reference(name):
-    _, g = load_golden(name)
-    dqs = applybqsr.get_delta_qs(g['meanq'], g['rg_errs'], g['rg_total'], g['q_errs'], g['q_total'],
-                                 g['pos_errs'], g['pos_total'], g['dinuc_errs'], g['dinuc_total'])
-    for k, v in zip(['rgdq', 'qdq', 'posdq', 'dinucdq'], dqs):
-        assert np.array_equal(v, g[k]), k
-    # reference tests/test_gatk_applybqsr.py:105-121
-    a = applybqsr.get_delta_qs(np.array([10]), np.array([0]), np.array([1000]), np.array([[0]]),
-                               np.array([[1000]]), np.array([[[0]]]), np.array([[[1000]]]),
-                               np.array([[[0]]]), np.array([[[1000]]]))
-    assert [x.tolist() for x in a] == [[3], [[2]], [[[1]]], [[[1, 0]]]]
 
 
 def test_meanq_from_marginals_matches_reference():

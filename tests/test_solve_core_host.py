@@ -1,0 +1,84 @@
+"""
+CPU tests of the device solve's building blocks (no kernel launched):
+  * kbbq._solve's decomposition of scipy.stats.binom.logpmf is bit-identical to logpmf;
+  * csrc/solve_core.h compiled for the host (tests/native/solve_check.cpp) returns the
+    reference's argmax on the golden gatk_delta_q grid and on adversarial cells.
+"""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.stats
+
+from conftest import ROOT, load_golden
+from kbbq import _solve
+
+
+def _cells(rng, n):
+    tot = (10 ** rng.uniform(0, 10.5, n)).astype(np.int64)
+    err = (tot * 10 ** (-rng.uniform(0, 5, n))).astype(np.int64)
+    err = np.minimum(err, tot)
+    tot[:50] = rng.integers(0, 5, 50); err[:50] = rng.integers(0, 3, 50); err[:50] = np.minimum(err[:50], tot[:50])
+    err[50:80] = tot[50:80]; err[80:110] = 0
+    return err, tot
+
+
+def test_logpmf_decomposition_is_bit_identical():
+    rng = np.random.default_rng(1)
+    err, tot = _cells(rng, 4000)
+    consts = _solve.model_consts()
+    prior, logp, log1mp = consts[:43], consts[43:86], consts[86:]
+    comb = _solve.combiln(err, tot)
+    p = (10.0 ** (-(np.arange(43) / 10.0)))
+    k = (err + 1).astype(np.float64); nk = (tot + 2).astype(np.float64) - k
+    with np.errstate(all='ignore'):
+        for cand in range(43):
+            want = scipy.stats.binom.logpmf(err + 1, tot + 2, p[cand])
+            got = (comb + k * logp[cand]) + nk * log1mp[cand]
+            assert np.array_equal(want, got), cand
+    assert np.isneginf(prior[19:]).all() and np.isfinite(prior[:19]).all()
+
+
+@pytest.fixture(scope='module')
+def solver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp('native') / 'solve_check')
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-o', exe,
+                           os.path.join(ROOT, 'tests', 'native', 'solve_check.cpp')])
+
+    def run(prior_q, errs, total):
+        prior_q = np.ascontiguousarray(prior_q, dtype=np.int64).ravel()
+        errs = np.ascontiguousarray(errs, dtype=np.int64).ravel()
+        total = np.ascontiguousarray(total, dtype=np.int64).ravel()
+        comb = _solve.combiln(errs, total)
+        rec = np.empty(len(errs), dtype=[('p', '<i8'), ('e', '<i8'), ('t', '<i8'), ('c', '<f8')])
+        rec['p'], rec['e'], rec['t'], rec['c'] = prior_q, errs, total, comb
+        blob = struct.pack('<q', len(errs)) + _solve.model_consts().tobytes() + rec.tobytes()
+        out = subprocess.run([exe], input=blob, capture_output=True, timeout=600)
+        assert out.returncode == 0
+        return np.frombuffer(out.stdout, dtype=np.int64) - prior_q
+    return run
+
+
+@pytest.mark.skipif(np.finfo(np.longdouble).nmant != 63, reason='np.longdouble is not x87 extended here')
+def test_solve_core_matches_reference_grid(solver, oracle):
+    _, gold = load_golden('numeric')
+    errs, tot = gold['grid_errs'], gold['grid_total']
+    prior_q = np.broadcast_to(np.arange(43)[:, None], (43, len(errs))).copy()
+    be = np.broadcast_to(errs, prior_q.shape).copy(); bt = np.broadcast_to(tot, prior_q.shape).copy()
+    assert np.array_equal(solver(prior_q, be, bt).reshape(prior_q.shape), gold['grid_dq'])
+    # adversarial cells against the oracle (which makes the reference's SciPy/longdouble calls)
+    rng = np.random.default_rng(7)
+    err, t = _cells(rng, 6000)
+    pq = rng.integers(0, 43, len(err))
+    assert np.array_equal(solver(pq, err, t), oracle.gatk_delta_q(pq, err, t))
+    # real tables
+    for name in ('c1_10k_1rg', 'c5cut_2k_mixed'):
+        _, g = load_golden(name)
+        prior2 = (g['meanq'] + g['rgdq'])[:, None] + g['qdq']
+        pp = np.broadcast_to(prior2[..., None], g['pos_total'].shape)
+        assert np.array_equal(solver(pp, g['pos_errs'], g['pos_total']).reshape(pp.shape), g['posdq'])
+        dd = np.broadcast_to(prior2[..., None], g['dinuc_total'].shape)
+        assert np.array_equal(solver(dd, g['dinuc_errs'], g['dinuc_total']).reshape(dd.shape),
+                              g['dinucdq'][..., :16])
