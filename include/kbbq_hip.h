@@ -21,7 +21,9 @@
  * Read layout ("padded SoA"): three byte planes seq / cseq / qual, one row of
  * `pitch` bytes per read, pitch a multiple of 16, rows 16-byte aligned.  Bytes
  * are the FASTQ characters (qual is phred+33).  Bytes at and beyond the read
- * length MUST be zero.  One uint32 of metadata per read:
+ * length MUST be zero in the qual plane and SHOULD be 'N' in seq / cseq (any other
+ * value is still handled correctly, through a slower exact check of that chunk).
+ * One uint32 of metadata per read:
  *     bits  0..15  length          (<= pitch)
  *     bits 16..30  read-group id   (first-appearance order, recalibrate.py:59-64)
  *     bit  31      second in pair  (compare_reads.py:304-306)
@@ -49,6 +51,10 @@ extern "C" {
 #define KBBQ_E_ARG      -4   /* bad argument (alignment, sizes, read too long for LDS)   */
 #define KBBQ_E_RANGE    -5   /* recalibrated quality + 33 outside 0..255     */
 #define KBBQ_E_NAME     -6   /* corrected read name does not start with the read name    */
+#define KBBQ_E_LUT      -7   /* a device-built LUT needs kbbq_apply_dev(KBBQ_APPLY_CHECKED)  */
+
+#define KBBQ_APPLY_CHECKED 0 /* per-base range test, int16 LUT                            */
+#define KBBQ_APPLY_FAST    1 /* table-driven int8 LUT, no per-base tests (LUT flags == 0) */
 
 #define KBBQ_NQ         43   /* maxscore + 1, recalibrate.py:36                          */
 #define KBBQ_NDINUC     16
@@ -115,28 +121,37 @@ int kbbq_accumulate(kbbq_ctx* ctx, const uint8_t* seq, const uint8_t* cseq,
 
 /* ---- K2: delta-Q table lookup / apply ----------------------------------
  * Replaces compare_reads.recalibrate_fastq (compare_reads.py:320-328) as driven
- * by recalibrate.py:141-152.  The five model arrays are folded on the host into
- * one int16 LUT (kbbq_build_lut), one row of kbbq_lut_row_stride(S2) entries per
- * (read group, quality):
+ * by recalibrate.py:141-152.  The five model arrays are folded into one LUT blob
+ * of kbbq_lut_bytes(R, Qt, S2) bytes (kbbq_build_lut on the host, kbbq_solve_dev on
+ * the device):
+ *   canonical part, int16, one row of kbbq_lut_row_stride(S2) entries per
+ *   (read group, quality):
  *     row[0 .. S2-1]    = meanq[rg] + rgdq[rg] + qdq[rg][q] + posdq[rg][q][cycle]
  *     row[S2 .. S2+24]  = dinucdq[rg][q][d] indexed by 5*code(prev)+code(cur), codes
  *                         A0 T1 G2 C3 (compare_reads.py:199) and 4 = N / no previous
  *                         base; entries involving code 4 hold dinucdq[rg][q][-1]
- * new_q = row[cycle] + row[S2 + context] for q >= minscore, q otherwise; the output
- * byte is new_q + 33 (no clipping, compare_reads.py:327; outside 0..255 ->
- * KBBQ_E_RANGE).  Cycle -(i+1) wraps on the final S2 (Python negative index).
- * q >= Qt, rg >= R or a cycle beyond S2 -> KBBQ_E_INDEX.  *range_safe is set when
- * no (cycle, context) combination of any row can leave 0..255; passing it to
- * kbbq_apply_dev selects the kernel variant without the per-base range test.  */
+ *   table-driven part, int8, indexed by the RAW quality byte (padding row, identity
+ *   rows below minscore, a mirrored copy of the cycle entries for second-in-pair
+ *   reads) -- see csrc/kbbq_kernels_v3.h; and an int of flags: bit 0 = a value
+ *   does not fit int8, bit 1 = some (cycle, context) pair can leave 0..255.
+ * new_q = cycle entry + context entry for q >= minscore, q otherwise; the output byte
+ * is new_q + 33 (no clipping, compare_reads.py:327; outside 0..255 -> KBBQ_E_RANGE).
+ * Cycle -(i+1) wraps on the final S2 (Python negative index).  q >= Qt, rg >= R or a
+ * cycle beyond S2 -> KBBQ_E_INDEX.
+ * mode KBBQ_APPLY_FAST may only be used when the blob's flags are 0 (known for a
+ * host-built blob; for a device-built one kbbq_ctx_status returns KBBQ_E_LUT after
+ * the fact and the caller re-runs with KBBQ_APPLY_CHECKED).                       */
 int    kbbq_lut_row_stride(int S2);
-int kbbq_build_lut(int R, int Qt, int S2, int D,
+size_t kbbq_full_lut_bytes(int R, int Qt, int S2);
+size_t kbbq_lut_bytes(int R, int Qt, int S2);
+int kbbq_build_lut(int R, int Qt, int S2, int D, int minscore,
                    const int64_t* meanq, const int64_t* rgdq, const int64_t* qdq,
-                   const int64_t* posdq, const int64_t* dinucdq, int16_t* lut_out,
-                   int* range_safe);
+                   const int64_t* posdq, const int64_t* dinucdq, void* lut_blob_out,
+                   int* flags_out);
 int kbbq_apply_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_qual,
                    const uint32_t* d_meta, int64_t nreads, int pitch,
                    int R, int Qt, int S2, int minscore,
-                   const int16_t* d_lut, int range_safe, uint8_t* d_qual_out);
+                   const void* d_lut_blob, int mode, uint8_t* d_qual_out);
 int kbbq_apply(kbbq_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint32_t* meta,
                int64_t nreads, int pitch, int R, int Qt, int S2, int D, int minscore,
                const int64_t* meanq, const int64_t* rgdq, const int64_t* qdq,
@@ -157,7 +172,7 @@ int kbbq_apply(kbbq_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uin
  * (prior_q must lie in 0..42).
  * kbbq_solve_dev: the whole hierarchy from the device count tables: marginals,
  * read-group and quality levels (d_post_q[R*43] scratch), then cycle and
- * dinucleotide levels, writing the K2 LUT (kbbq_lut_count elements) and, when
+ * dinucleotide levels, writing the K2 LUT blob (kbbq_lut_bytes bytes) and, when
  * d_dq != NULL, int32 [rgdq R | qdq R*43 | posdq R*43*S2 | dinucdq R*43*17].
  * d_aux (kbbq_solve_aux_count doubles) = [comb_rg | comb_q | comb_pos | comb_dn].  */
 int    kbbq_delta_q_dev(kbbq_ctx* ctx, const int64_t* d_prior_q, const int64_t* d_errs,
@@ -165,9 +180,9 @@ int    kbbq_delta_q_dev(kbbq_ctx* ctx, const int64_t* d_prior_q, const int64_t* 
                         const double* h_consts129, int64_t* d_dq);
 size_t kbbq_solve_aux_count(int R, int S2);
 size_t kbbq_solve_dq_count(int R, int S2);
-int    kbbq_solve_dev(kbbq_ctx* ctx, const int64_t* d_tables, int R, int S2,
+int    kbbq_solve_dev(kbbq_ctx* ctx, const int64_t* d_tables, int R, int S2, int minscore,
                       const int32_t* d_meanq, const double* d_aux, const double* h_consts129,
-                      int32_t* d_post_q, int16_t* d_lut, int32_t* d_dq);
+                      int32_t* d_post_q, void* d_lut_blob, int32_t* d_dq);
 
 /* ---- synthetic reads (bench / tests) -----------------------
  * Device twin of the generator documented in oracle/kbbq_oracle.c.          */

@@ -1,6 +1,7 @@
 // kbbq_hip.hip -- C ABI of libkbbq_hip.so (see include/kbbq_hip.h).
 // gfx950 only.  Host side: launch geometry, device staging, status decoding.
 #include "kbbq_kernels.h"
+#include "kbbq_kernels_v3.h"
 #include "kbbq_solve_kernels.h"
 #include "../../include/kbbq_hip.h"
 
@@ -87,6 +88,9 @@ int kbbq_ctx_create(int device, kbbq_ctx** out)
     // allow the full 160 KiB of LDS as dynamic shared memory
     (void)hipFuncSetAttribute((const void*)k1_accumulate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k1_accumulate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)k1v3_accumulate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)k1v3_accumulate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)k2v3_apply, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2_apply<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2_apply<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipGetLastError();
@@ -138,11 +142,13 @@ int kbbq_ctx_status(kbbq_ctx* c, int64_t* read_index)
     HIPCHK(hipMemcpyAsync(st, c->d_status, sizeof st, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (read_index) *read_index = -1;
-    if (st[0] == ~0ull && st[1] == ~0ull && st[2] == ~0ull) return KBBQ_OK;
+    if (st[0] == ~0ull && st[1] == ~0ull && st[2] == ~0ull && st[3] == ~0ull) return KBBQ_OK;
     HIPCHK(hipMemcpyAsync(c->d_status, ST_INIT, sizeof ST_INIT, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     // the reference stops at the FIRST offending read; within one read the dinucleotide
     // lookup (TypeError, recalibrate.py:94) runs before the table indexing (IndexError, :114)
+    if (st[0] == ~0ull && st[1] == ~0ull && st[2] == ~0ull)
+        return fail(KBBQ_E_LUT, "the device-built LUT can leave 0..255 or does not fit int8: re-run kbbq_apply_dev in checked mode");
     int code = KBBQ_E_TYPE; u64 best = st[ST_TYPE];
     if (st[ST_INDEX] < best) { best = st[ST_INDEX]; code = KBBQ_E_INDEX; }
     if (st[ST_RANGE] < best) { best = st[ST_RANGE]; code = KBBQ_E_RANGE; }
@@ -201,6 +207,12 @@ size_t kbbq_tables_count(int R, int S2)
 }
 
 int kbbq_lut_row_stride(int S2) { return lut_row_stride(S2); }
+
+static size_t align16(size_t n) { return (n + 15) & ~(size_t)15; }
+static size_t lut_full_offset(int R, int Qt, int S2) { return align16((size_t)R * Qt * lut_row_stride(S2) * 2); }
+size_t kbbq_full_lut_bytes(int R, int Qt, int S2) { return (size_t)R * (33 + Qt) * (size_t)full_lut_row_bytes(S2); }
+static size_t lut_flags_offset(int R, int Qt, int S2) { return lut_full_offset(R, Qt, S2) + align16(kbbq_full_lut_bytes(R, Qt, S2)); }
+size_t kbbq_lut_bytes(int R, int Qt, int S2) { return lut_flags_offset(R, Qt, S2) + 16; }
 
 size_t kbbq_lut_count(int R, int Qt, int S2)
 {
@@ -285,6 +297,35 @@ int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_c
     if (nreads == 0) return KBBQ_OK;
     HIPCHK(hipSetDevice(c->device));
 
+    const int64_t nblocks = (nreads + 63) / 64;
+    const int S = S2 / 2;
+    const bool split = dinuc_minscore > minscore;
+    const char* force = getenv("KBBQ_K1");              // "v1" forces the first kernel (A/B timing)
+    {
+        K1v3Params q;
+        q.seq = d_seq; q.cseq = d_cseq; q.qual = d_qual; q.meta = d_meta;
+        q.nreads = nreads; q.pitch = pitch; q.cpr = pitch / 16; q.cpr_magic = magic_for(q.cpr);
+        q.R = R; q.S = S; q.minscore = minscore; q.type_minscore = dinuc_minscore;
+        q.qlo_m1 = 32u + (u32)minscore; q.dlo = 33u + (u32)dinuc_minscore;
+        q.nrows = KQ + 1 - minscore;
+        q.row_bytes = (u32)((3 * S) | 1) * 4u;
+        q.slack_bytes = (u32)(S + 32) * 4u;              // x <= 4S + 12 for the padding of the shortest read
+        q.tables = reinterpret_cast<u64*>(d_tables); q.status = c->d_status;
+        const size_t lds3 = (size_t)q.nrows * 256 + (size_t)q.nrows * q.row_bytes + q.slack_bytes;
+        if (lds3 <= (size_t)c->lds_bytes && !(force && !strcmp(force, "v1"))) {
+            int per_cu = std::max(1, std::min<int>((int)(c->lds_bytes / lds3), 2048 / K1V3_THREADS));
+            const int64_t iters = (nblocks + (K1V3_THREADS / 64) - 1) / (K1V3_THREADS / 64);
+            int gx = (int)std::min<int64_t>(iters, std::max(1, c->cus * per_cu / R));
+            dim3 grid((unsigned)gx, (unsigned)R, 1), block(K1V3_THREADS, 1, 1);
+            {
+                Timed t(c, 0);
+                if (split) hipLaunchKernelGGL(k1v3_accumulate<true>, grid, block, lds3, c->stream, q);
+                else hipLaunchKernelGGL(k1v3_accumulate<false>, grid, block, lds3, c->stream, q);
+            }
+            HIPCHK(hipGetLastError());
+            return KBBQ_OK;
+        }
+    }
     K1Params p;
     p.seq = d_seq; p.cseq = d_cseq; p.qual = d_qual; p.meta = d_meta;
     p.nreads = nreads; p.pitch = pitch; p.cpr = pitch / 16; p.cpr_magic = magic_for(p.cpr);
@@ -297,22 +338,92 @@ int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_c
         return fail(KBBQ_E_ARG, "kbbq_accumulate_dev: reads of %d bases need %zu B of LDS (> %d)", S2 / 2, lds, c->lds_bytes);
     int per_cu = std::min<int>((int)(c->lds_bytes / lds), 2048 / K1_THREADS);
     per_cu = std::max(per_cu, 1);
-    const int64_t nblocks = (nreads + 63) / 64;
     const int64_t iters = (nblocks + (K1_THREADS / 64) - 1) / (K1_THREADS / 64);
     int gx = (int)std::min<int64_t>(iters, std::max(1, c->cus * per_cu / R));
     dim3 grid((unsigned)gx, (unsigned)R, 1), block(K1_THREADS, 1, 1);
     {
         Timed t(c, 0);
-        if (dinuc_minscore > minscore) hipLaunchKernelGGL(k1_accumulate<true>, grid, block, lds, c->stream, p);
+        if (split) hipLaunchKernelGGL(k1_accumulate<true>, grid, block, lds, c->stream, p);
         else hipLaunchKernelGGL(k1_accumulate<false>, grid, block, lds, c->stream, p);
     }
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
 }
 
+// host twin of k3_fill_full_lut (same rules; the GPU test compares the two blobs byte for byte)
+static int fill_full_lut_host(const int16_t* lut16, int rs16, int R, int Qt, int S2, int minscore, int8_t* full)
+{
+    const int rb = full_lut_row_bytes(S2);
+    const int NR = 33 + Qt;
+    int bad = 0;
+    for (int r = 0; r < R; ++r)
+        for (int qb = 0; qb < NR; ++qb) {
+            int8_t* row = full + ((size_t)r * NR + qb) * rb;
+            for (int x = 0; x < rb; ++x) {
+                const int W = full_lut_width(S2);
+                int v = 0;
+                if (qb < 33 + minscore) { if (x < 2 * W) v = qb == 0 ? -33 : qb - 33; }
+                else {
+                    const int16_t* src = lut16 + ((size_t)r * Qt + (qb - 33)) * rs16;
+                    if (x < S2) v = src[x];
+                    else if (x >= W && x < W + S2) v = src[S2 - 1 - (x - W)];
+                    else if (x >= 2 * W && x < 2 * W + 25) v = src[S2 + (x - 2 * W)];
+                }
+                if (v < -128 || v > 127) bad |= 1;
+                row[x] = (int8_t)v;
+            }
+        }
+    for (int r = 0; r < R; ++r)
+        for (int q = minscore; q < Qt; ++q) {
+            const int16_t* src = lut16 + ((size_t)r * Qt + q) * rs16;
+            int lo1 = 32767, hi1 = -32768, lo2 = 32767, hi2 = -32768;
+            for (int x = 0; x < S2; ++x) { lo1 = std::min<int>(lo1, src[x]); hi1 = std::max<int>(hi1, src[x]); }
+            for (int x = 0; x < 25; ++x) { lo2 = std::min<int>(lo2, src[S2 + x]); hi2 = std::max<int>(hi2, src[S2 + x]); }
+            if (lo1 + lo2 + 33 < 0 || hi1 + hi2 + 33 > 255) bad |= 2;
+        }
+    return bad;
+}
+
+int kbbq_build_lut(int R, int Qt, int S2, int D, int minscore, const int64_t* meanq, const int64_t* rgdq,
+                   const int64_t* qdq, const int64_t* posdq, const int64_t* dinucdq, void* blob,
+                   int* flags_out)
+{
+    // D = 17 is what get_delta_qs returns (applybqsr.py:98-101); D = 16 is accepted because the
+    // reference's own apply test passes an unpadded table (index -1 then aliases column 15)
+    if (R <= 0 || Qt <= 0 || Qt > 95 || S2 <= 0 || D < 16 || D > 17 || minscore < 0)
+        return fail(KBBQ_E_ARG, "kbbq_build_lut: bad shape R=%d Qt=%d S2=%d D=%d minscore=%d", R, Qt, S2, D, minscore);
+    memset(blob, 0, kbbq_lut_bytes(R, Qt, S2));
+    int16_t* out = reinterpret_cast<int16_t*>(blob);
+    const int rs = lut_row_stride(S2);
+    for (int r = 0; r < R; ++r)
+        for (int q = 0; q < Qt; ++q) {
+            const size_t cell = (size_t)r * Qt + q;
+            int16_t* row = out + cell * rs;
+            const int64_t base = meanq[r] + rgdq[r] + qdq[cell];
+            for (int s = 0; s < S2; ++s) {
+                const int64_t v = base + posdq[cell * S2 + s];
+                if (v < -32768 || v > 32767) return fail(KBBQ_E_RANGE, "kbbq_build_lut: value %lld does not fit the LUT", (long long)v);
+                row[s] = (int16_t)v;
+            }
+            // dinucleotide index 5 * prev + cur, codes A0 T1 G2 C3 and 4 = N / no previous base;
+            // anything involving code 4 is the reference's index -1, i.e. column D - 1
+            for (int a = 0; a < 5; ++a)
+                for (int b = 0; b < 5; ++b) {
+                    const int64_t v = (a < 4 && b < 4) ? dinucdq[cell * D + 4 * a + b] : dinucdq[cell * D + (D - 1)];
+                    if (v < -32768 || v > 32767) return fail(KBBQ_E_RANGE, "kbbq_build_lut: value %lld does not fit the LUT", (long long)v);
+                    row[S2 + 5 * a + b] = (int16_t)v;
+                }
+        }
+    int8_t* full = reinterpret_cast<int8_t*>(blob) + lut_full_offset(R, Qt, S2);
+    const int flags = fill_full_lut_host(out, rs, R, Qt, S2, std::min(minscore, Qt), full);
+    *reinterpret_cast<int*>(reinterpret_cast<char*>(blob) + lut_flags_offset(R, Qt, S2)) = flags;
+    if (flags_out) *flags_out = flags;
+    return KBBQ_OK;
+}
+
 int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta,
                    int64_t nreads, int pitch, int R, int Qt, int S2, int minscore,
-                   const int16_t* d_lut, int range_safe, uint8_t* d_out)
+                   const void* d_lut, int mode, uint8_t* d_out)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
     int rc = check_planes("kbbq_apply_dev", nreads, pitch, d_seq, d_qual, d_out);
@@ -320,15 +431,39 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
     if (R <= 0 || R > 32767 || Qt <= 0 || Qt > 95 || S2 <= 0 || S2 > 65536)
         return fail(KBBQ_E_ARG, "kbbq_apply_dev: bad table shape R=%d Qt=%d S2=%d (Qt <= 95)", R, Qt, S2);
     if (minscore < 0 || minscore > 222) return fail(KBBQ_E_ARG, "kbbq_apply_dev: minscore out of range");
-    if ((uintptr_t)d_lut & 3) return fail(KBBQ_E_ARG, "kbbq_apply_dev: LUT must be 4-byte aligned");
+    if ((uintptr_t)d_lut & 15) return fail(KBBQ_E_ARG, "kbbq_apply_dev: LUT must be 16-byte aligned");
+    if (mode != KBBQ_APPLY_CHECKED && mode != KBBQ_APPLY_FAST) return fail(KBBQ_E_ARG, "kbbq_apply_dev: bad mode %d", mode);
     if (nreads == 0) return KBBQ_OK;
     HIPCHK(hipSetDevice(c->device));
+    const int64_t nblocks = (nreads + 63) / 64;
+    const char* force = getenv("KBBQ_K2");              // "v1" forces the first kernel (A/B timing)
+
+    const size_t full_bytes = kbbq_full_lut_bytes(R, Qt, S2);
+    if (mode == KBBQ_APPLY_FAST && full_bytes <= (size_t)c->lds_bytes && !(force && !strcmp(force, "v1"))) {
+        K2v3Params q;
+        q.seq = d_seq; q.qual = d_qual; q.meta = d_meta; q.nreads = nreads; q.pitch = pitch;
+        q.cpr = pitch / 16; q.cpr_magic = magic_for(q.cpr);
+        q.R = R; q.Qt = Qt; q.S2 = S2; q.minscore = minscore; q.qlo = 33u + (u32)minscore;
+        q.lut16 = reinterpret_cast<const int16_t*>(d_lut); q.rs16 = lut_row_stride(S2);
+        q.full = reinterpret_cast<const int8_t*>(d_lut) + lut_full_offset(R, Qt, S2);
+        q.full_bytes = (int)full_bytes;
+        q.out = d_out; q.status = c->d_status;
+        int per_cu = std::max(1, std::min<int>((int)(c->lds_bytes / full_bytes), 2048 / K2V3_THREADS));
+        const int64_t want = (nblocks + (K2V3_THREADS / 64) - 1) / (K2V3_THREADS / 64);
+        int gx = (int)std::min<int64_t>(want, (int64_t)c->cus * per_cu);
+        {
+            Timed t(c, 1);
+            hipLaunchKernelGGL(k2v3_apply, dim3((unsigned)std::max(gx, 1)), dim3(K2V3_THREADS), full_bytes, c->stream, q);
+        }
+        HIPCHK(hipGetLastError());
+        return KBBQ_OK;
+    }
 
     K2Params p;
     p.seq = d_seq; p.qual = d_qual; p.meta = d_meta; p.nreads = nreads; p.pitch = pitch;
     p.cpr = pitch / 16; p.cpr_magic = magic_for(p.cpr);
     p.R = R; p.Qt = Qt; p.S2 = S2; p.minscore = minscore; p.qlo = 33u + (u32)minscore;
-    p.lut = d_lut; p.lut_count = (int)kbbq_lut_count(R, Qt, S2);
+    p.lut = reinterpret_cast<const int16_t*>(d_lut); p.lut_count = (int)kbbq_lut_count(R, Qt, S2);
     p.out = d_out; p.status = c->d_status;
     const size_t lut_bytes = (size_t)p.lut_count * 2;
     // stage the LUT in LDS when at least 2 workgroups per CU still fit
@@ -337,53 +472,16 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
     const size_t lds = in_lds ? lut_bytes : 0;
     int per_cu = in_lds ? std::min<int>((int)(c->lds_bytes / std::max<size_t>(lds, 1)), 2048 / K2_THREADS) : 2048 / K2_THREADS;
     per_cu = std::max(per_cu, 1);
-    const int64_t nblocks = (nreads + 63) / 64;
     const int64_t want = (nblocks + (K2_THREADS / 64) - 1) / (K2_THREADS / 64);
     int gx = (int)std::min<int64_t>(want, (int64_t)c->cus * per_cu);
     dim3 grid((unsigned)std::max(gx, 1), 1, 1), block(K2_THREADS, 1, 1);
     {
         Timed t(c, 1);
         if (!in_lds) hipLaunchKernelGGL((k2_apply<false, true>), grid, block, 0, c->stream, p);
-        else if (range_safe) hipLaunchKernelGGL((k2_apply<true, false>), grid, block, lds, c->stream, p);
+        else if (mode == KBBQ_APPLY_FAST) hipLaunchKernelGGL((k2_apply<true, false>), grid, block, lds, c->stream, p);
         else hipLaunchKernelGGL((k2_apply<true, true>), grid, block, lds, c->stream, p);
     }
     HIPCHK(hipGetLastError());
-    return KBBQ_OK;
-}
-
-int kbbq_build_lut(int R, int Qt, int S2, int D, const int64_t* meanq, const int64_t* rgdq,
-                   const int64_t* qdq, const int64_t* posdq, const int64_t* dinucdq, int16_t* out,
-                   int* range_safe)
-{
-    // D = 17 is what get_delta_qs returns (applybqsr.py:98-101); D = 16 is accepted because the
-    // reference's own apply test passes an unpadded table (index -1 then aliases column 15)
-    if (R <= 0 || Qt <= 0 || S2 <= 0 || D < 16 || D > 17)
-        return fail(KBBQ_E_ARG, "kbbq_build_lut: bad shape R=%d Qt=%d S2=%d D=%d", R, Qt, S2, D);
-    const int rs = lut_row_stride(S2);
-    bool safe = true;
-    for (int r = 0; r < R; ++r)
-        for (int q = 0; q < Qt; ++q) {
-            const size_t cell = (size_t)r * Qt + q;
-            int16_t* row = out + cell * rs;
-            const int64_t base = meanq[r] + rgdq[r] + qdq[cell];
-            int64_t lo1 = INT64_MAX, hi1 = INT64_MIN, lo2 = INT64_MAX, hi2 = INT64_MIN;
-            for (int s = 0; s < S2; ++s) {
-                const int64_t v = base + posdq[cell * S2 + s];
-                if (v < -32768 || v > 32767) return fail(KBBQ_E_RANGE, "kbbq_build_lut: value %lld does not fit the LUT", (long long)v);
-                row[s] = (int16_t)v; lo1 = std::min(lo1, v); hi1 = std::max(hi1, v);
-            }
-            // dinucleotide index 5 * prev + cur, codes A0 T1 G2 C3 and 4 = N / no previous base;
-            // anything involving code 4 is the reference's index -1, i.e. column D - 1
-            for (int a = 0; a < 5; ++a)
-                for (int b = 0; b < 5; ++b) {
-                    const int64_t v = (a < 4 && b < 4) ? dinucdq[cell * D + 4 * a + b] : dinucdq[cell * D + (D - 1)];
-                    if (v < -32768 || v > 32767) return fail(KBBQ_E_RANGE, "kbbq_build_lut: value %lld does not fit the LUT", (long long)v);
-                    row[S2 + 5 * a + b] = (int16_t)v; lo2 = std::min(lo2, v); hi2 = std::max(hi2, v);
-                }
-            for (int s = S2 + 25; s < rs; ++s) row[s] = 0;
-            if (lo1 + lo2 + 33 < 0 || hi1 + hi2 + 33 > 255) safe = false;
-        }
-    if (range_safe) *range_safe = safe ? 1 : 0;
     return KBBQ_OK;
 }
 
@@ -441,9 +539,9 @@ int kbbq_delta_q_dev(kbbq_ctx* c, const int64_t* d_prior_q, const int64_t* d_err
 size_t kbbq_solve_aux_count(int R, int S2) { return (size_t)R + (size_t)R * KQ + (size_t)R * KQ * S2 + (size_t)R * KQ * KND; }
 size_t kbbq_solve_dq_count(int R, int S2) { return (size_t)R + (size_t)R * KQ + (size_t)R * KQ * S2 + (size_t)R * KQ * 17; }
 
-int kbbq_solve_dev(kbbq_ctx* c, const int64_t* d_tables, int R, int S2, const int32_t* d_meanq,
+int kbbq_solve_dev(kbbq_ctx* c, const int64_t* d_tables, int R, int S2, int minscore, const int32_t* d_meanq,
                    const double* d_aux, const double* h_consts129, int32_t* d_post_q,
-                   int16_t* d_lut, int32_t* d_dq)
+                   void* d_lut, int32_t* d_dq)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
     if (R <= 0 || R > 32767 || S2 <= 0 || S2 > 65536) return fail(KBBQ_E_ARG, "kbbq_solve_dev: bad shape R=%d S2=%d", R, S2);
@@ -451,13 +549,23 @@ int kbbq_solve_dev(kbbq_ctx* c, const int64_t* d_tables, int R, int S2, const in
     HIPCHK(hipSetDevice(c->device));
     K3FusedParams p;
     p.tables = (const long long*)d_tables; p.R = R; p.S2 = S2; p.rs = lut_row_stride(S2);
-    p.meanq = d_meanq; p.aux = d_aux; p.post_q = d_post_q; p.lut = d_lut; p.dq = d_dq;
+    p.meanq = d_meanq; p.aux = d_aux; p.post_q = d_post_q; p.lut = reinterpret_cast<int16_t*>(d_lut); p.dq = d_dq;
     int rc = load_consts(p.c, h_consts129);
     if (rc) return rc;
     hipLaunchKernelGGL(k3_levels_ab, dim3((unsigned)R), dim3(64), 0, c->stream, p);
     const int64_t cells = (int64_t)R * KQ * ((int64_t)S2 + KND);
     int gx = (int)std::min<int64_t>((cells + 255) / 256, (int64_t)c->cus * 8);
     hipLaunchKernelGGL(k3_level_c, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    // derive the table-driven (int8) LUT and the flags the fast apply kernel relies on
+    LutFillParams f;
+    f.lut16 = p.lut; f.rs16 = p.rs; f.R = R; f.Qt = KQ; f.S2 = S2; f.minscore = std::min(std::max(minscore, 0), KQ);
+    f.full = reinterpret_cast<int8_t*>(d_lut) + lut_full_offset(R, KQ, S2);
+    f.flags = reinterpret_cast<int*>(reinterpret_cast<char*>(d_lut) + lut_flags_offset(R, KQ, S2));
+    f.status = c->d_status;
+    HIPCHK(hipMemsetAsync(f.flags, 0, 16, c->stream));
+    const int64_t fb = (int64_t)kbbq_full_lut_bytes(R, KQ, S2);
+    int gf = (int)std::min<int64_t>((fb + 255) / 256, (int64_t)c->cus * 8);
+    hipLaunchKernelGGL(k3_fill_full_lut, dim3((unsigned)std::max(gf, 1)), dim3(256), 0, c->stream, f);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
 }
@@ -507,20 +615,20 @@ int kbbq_apply(kbbq_ctx* c, const uint8_t* seq, const uint8_t* qual, const uint3
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
     if (nreads < 0 || pitch <= 0 || (pitch & 15)) return fail(KBBQ_E_ARG, "kbbq_apply: bad nreads/pitch");
     HIPCHK(hipSetDevice(c->device));
-    std::vector<int16_t> lut(kbbq_lut_count(R, Qt, S2));
-    int range_safe = 0;
-    int rc = kbbq_build_lut(R, Qt, S2, D, meanq, rgdq, qdq, posdq, dinucdq, lut.data(), &range_safe);
+    std::vector<int64_t> lut((kbbq_lut_bytes(R, Qt, S2) + 7) / 8);      // 8-byte words: aligned storage
+    int flags = 0;
+    int rc = kbbq_build_lut(R, Qt, S2, D, minscore, meanq, rgdq, qdq, posdq, dinucdq, lut.data(), &flags);
     if (rc) return rc;
     const size_t plane = (size_t)nreads * pitch;
     DevBuf ds, dq, dm, dl, dout;
     HIPCHK(ds.alloc(plane)); HIPCHK(dq.alloc(plane)); HIPCHK(dout.alloc(plane));
-    HIPCHK(dm.alloc((size_t)nreads * 4)); HIPCHK(dl.alloc(lut.size() * 2));
+    HIPCHK(dm.alloc((size_t)nreads * 4)); HIPCHK(dl.alloc(lut.size() * 8));
     HIPCHK(hipMemcpyAsync(ds.p, seq, plane, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(dq.p, qual, plane, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(dm.p, meta, (size_t)nreads * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dl.p, lut.data(), lut.size() * 2, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dl.p, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, c->stream));
     rc = kbbq_apply_dev(c, (const uint8_t*)ds.p, (const uint8_t*)dq.p, (const uint32_t*)dm.p, nreads, pitch,
-                        R, Qt, S2, minscore, (const int16_t*)dl.p, range_safe, (uint8_t*)dout.p);
+                        R, Qt, S2, minscore, dl.p, flags ? KBBQ_APPLY_CHECKED : KBBQ_APPLY_FAST, (uint8_t*)dout.p);
     if (rc) return rc;
     rc = kbbq_ctx_status(c, nullptr);
     if (rc) return rc;

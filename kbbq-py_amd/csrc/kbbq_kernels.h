@@ -25,6 +25,7 @@
 #define ST_INDEX 0
 #define ST_TYPE  1
 #define ST_RANGE 2
+#define ST_LUT   3   // set (to 0) when a device-built LUT needs the checked apply kernel
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
@@ -235,9 +236,10 @@ __global__ __launch_bounds__(K1_THREADS) void k1_accumulate(K1Params p)
                 carry_char = (u32)__builtin_amdgcn_readlane((int)last_char, 63);
                 if (j == 0) { prev_code = 0x10u; prev_char = 0u; }   // dinuc[0] = -1
                 if (act) {
-                    if (hiq) flag(p.status, ST_INDEX, read);          // recalibrate.py:114-115
+                    if (hiq || 2 * len > p.S2) flag(p.status, ST_INDEX, read);   // recalibrate.py:114-115; read longer than the tables
                     if (badbits && chunk_type_error(s[0], s[1], s[2], s[3], q[0], q[1], q[2], q[3], prev_char, nb, pos0, p.minscore))
                         flag(p.status, ST_TYPE, read);                // compare_reads.py:224,292
+                    if (2 * len <= p.S2) {
                     // LDS byte address of (q, column): qb*row_bytes + colbase, colbase steps by +-4
                     const int col0 = second ? (2 * len - 1 - pos0) : pos0;
                     const int dcol = second ? -4 : 4;
@@ -268,6 +270,7 @@ __global__ __launch_bounds__(K1_THREADS) void k1_accumulate(K1Params p)
                             }
                             colbase += dcol;
                         }
+                    }
                     }
                 }
             }
@@ -471,7 +474,8 @@ __global__ __launch_bounds__(256) void ks_synth(KSParams p)
         }
         const u64 hr = mix64(p.seed + read);
         const u64 nq = (u64)(p.qhi - p.qlo + 1);
-        u32 s[4] = {0u, 0u, 0u, 0u}, c[4] = {0u, 0u, 0u, 0u}, q[4] = {0u, 0u, 0u, 0u};
+        const u32 NNNN = 0x4E4E4E4Eu;      // bytes past the read: 'N' in seq / cseq, 0 in qual
+        u32 s[4] = {NNNN, NNNN, NNNN, NNNN}, c[4] = {NNNN, NNNN, NNNN, NNNN}, q[4] = {0u, 0u, 0u, 0u};
         for (int b = 0; b < 16; ++b) {
             const int i = 16 * j + b;
             if (i >= len) break;
@@ -484,8 +488,8 @@ __global__ __launch_bounds__(256) void ks_synth(KSParams p)
             const u32 acgt = 0x54474341u;   // 'A','C','G','T'
             const u32 sc = isn ? (u32)'N' : ((acgt >> (8 * bb)) & 0xFFu);
             const u32 cc = err ? (isn ? ((acgt >> (8 * bb)) & 0xFFu) : ((acgt >> (8 * sub)) & 0xFFu)) : sc;
-            s[b >> 2] |= sc << (8 * (b & 3));
-            c[b >> 2] |= cc << (8 * (b & 3));
+            s[b >> 2] = (s[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | (sc << (8 * (b & 3)));
+            c[b >> 2] = (c[b >> 2] & ~(0xFFu << (8 * (b & 3)))) | (cc << (8 * (b & 3)));
             q[b >> 2] |= (u32)(qq + 33) << (8 * (b & 3));
         }
         const size_t off = (size_t)k * p.pitch + (size_t)16 * j;

@@ -1,0 +1,397 @@
+// kbbq_kernels_v3.h -- table-driven, branch-free forms of K1 and K2 (the default path).
+//
+// Measured on MI355X (profiles/r01_pmc_v1.md): the first kernels (kbbq_kernels.h) were bound
+// by VALU issue -- ~24 (K1) / ~22 (K2) vector instructions per base at 4 cycles per wave64
+// integer instruction -- not by LDS (removing every LDS op bought 7 %) and not by HBM.
+// These versions move per-base decisions into table layout so that a base costs ~7 (K1) /
+// ~6 (K2) vector instructions:
+//   K1: no "counted?" / "context defined?" tests: the LDS histogram has a TRASH row (all
+//       qualities below minscore clamp onto it with one v_max) and TRASH context slots (the
+//       context index is 5*code(prev)+code(cur) with code 4 = N / no previous base, so it is
+//       always in range); trash is never flushed.  Second-in-pair columns are stored
+//       mirrored so that both mates walk upwards and the per-base column step is an
+//       instruction immediate.
+//   K2: the LUT is indexed by the RAW quality byte: row 0 (padding) yields 0, rows of
+//       uncounted qualities are identity rows, so there is no clamp, no "q >= minscore"
+//       test and no select; a mirrored copy of the cycle entries serves second-in-pair
+//       reads with ascending addresses.
+// Same read-block / 16-byte-chunk decomposition, same error semantics (rare exact paths)
+// and the same C ABI as the first kernels, which remain as the fallback for shapes these
+// layouts do not fit in LDS (very long reads, many read groups).
+#pragma once
+#include "kbbq_kernels.h"
+
+#define K1V3_THREADS 512
+#define K2V3_THREADS 512
+#define K1V3_FLUSH_ITERS 96          // as K1: 49,152 reads per workgroup between flushes
+
+struct K1v3Params {
+    const uint8_t* seq; const uint8_t* cseq; const uint8_t* qual; const u32* meta;
+    long long nreads; int pitch; int cpr; u32 cpr_magic; int R; int S;
+    int minscore;               // counting threshold: row r of the LDS tables is quality minscore + r - 1
+    int type_minscore;          // threshold of the dinucleotide lookup (TypeError rule); differs in SPLIT
+    u32 qlo_m1;                 // 32 + minscore: quality bytes <= this hit the trash row
+    u32 dlo;                    // SPLIT only: 33 + dinucleotide minscore
+    int nrows;                  // 44 - minscore: one row per counted quality (row = 42 - q) + the trash row LAST
+    u32 row_bytes;              // pos row stride in bytes ((3S | 1) words)
+    u32 slack_bytes;            // after the last (trash) row: padding bytes of short reads index past its end
+    u64* tables; u64* status;
+};
+
+// LDS: dn [nrows][32] u64  (errs << 32 | total), slot = 5*code(prev)+code(cur), at offset 0
+//      pos[nrows][row_bytes/4] u32 (errs << 16 | total): [0,S) first-in-pair cycle = position;
+//          [S, 3S) second-in-pair, index x = position + 2*(S - len)  <->  column 2S-1-x
+//      rows are ordered by the INVERTED quality byte (row = 42 - q, one v_min clamps every
+//      uncounted byte onto the trash row, which is last); bytes past the end of a short read
+//      (quality 0 -> trash) can index beyond the trash row's end: `slack_bytes` absorb that.
+template <bool SPLIT>
+__global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const int dn_words = p.nrows * 64;
+    const int pos_words = p.nrows * (int)(p.row_bytes >> 2) + (int)(p.slack_bytes >> 2);
+    u64* dn = reinterpret_cast<u64*>(lds);
+    u32* pos = lds + dn_words;
+    for (int i = threadIdx.x; i < dn_words + pos_words; i += blockDim.x) lds[i] = 0u;
+    __syncthreads();
+
+    const int g = blockIdx.y;
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const long long nblocks = (p.nreads + 63) >> 6;
+    const long long iters = (nblocks + nwaves - 1) / nwaves;
+    const int S = p.S, S2 = 2 * p.S;
+    const u32 row_bytes = p.row_bytes;
+    const u32 tclamp = 255u - p.qlo_m1;                                // inverted bytes >= this are uncounted
+    const u32 pos_base = (u32)dn_words * 4u - 180u * row_bytes;        // 180 = 255 - 'K': inverted byte of q = 42 is row 0
+    const u32 dn_base = 0u - 180u * 256u;
+    int since_flush = 0;
+
+    u64* pos_errs = p.tables;
+    u64* pos_total = p.tables + (size_t)p.R * KQ * S2;
+    u64* dn_errs = p.tables + 2 * (size_t)p.R * KQ * S2;
+    u64* dn_total = dn_errs + (size_t)p.R * KQ * KND;
+
+    auto flush = [&]() {
+        for (int r = wave; r < p.nrows - 1; r += nwaves) {           // the last row is trash
+            const int q = KQ - 1 - r;
+            const size_t grow = ((size_t)g * KQ + q) * S2;
+            u32* prow = pos + (size_t)r * (row_bytes >> 2);
+            for (int x = lane; x < 3 * S; x += 64) {
+                const u32 v = prow[x];
+                if (v) {
+                    prow[x] = 0u;
+                    const int col = x < S ? x : (S2 - 1 - (x - S));
+                    atomicAdd(&pos_total[grow + col], (u64)(v & 0xFFFFu));
+                    if (v >> 16) atomicAdd(&pos_errs[grow + col], (u64)(v >> 16));
+                }
+            }
+            if (lane < 25) {
+                const int a = lane / 5, b = lane - 5 * a;
+                if (a < 4 && b < 4) {
+                    const u64 v = dn[r * 32 + lane];
+                    if (v) {
+                        dn[r * 32 + lane] = 0ull;
+                        const size_t e = ((size_t)g * KQ + q) * KND + 4 * a + b;
+                        atomicAdd(&dn_total[e], v & 0xFFFFFFFFull);
+                        if (v >> 32) atomicAdd(&dn_errs[e], v >> 32);
+                    }
+                }
+            }
+        }
+    };
+
+    for (long long it = blockIdx.x; it < iters; it += gridDim.x) {
+        const long long blk = it * nwaves + wave;
+        if (blk < nblocks) {
+            const long long read0 = blk << 6;
+            const long long myread = read0 + lane;
+            const u32 m = myread < p.nreads ? p.meta[myread] : 0u;
+            const bool match = myread < p.nreads && (int)((m >> 16) & 0x7FFFu) == g && (m & 0xFFFFu) != 0u;
+            const u64 mask = __ballot(match);
+            const int n = __popcll(mask);
+            u32 cm = m, coff = (u32)lane;
+            if (n != 64 && n > 0) {            // compact the matching reads to lanes 0..n-1
+                const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+                const int dst = match ? rank : 63;
+                cm = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)(match ? m : 0u));
+                coff = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)(match ? (u32)lane : 0u));
+            }
+            const uint8_t* bseq = p.seq + (size_t)read0 * p.pitch;
+            const uint8_t* bcseq = p.cseq + (size_t)read0 * p.pitch;
+            const uint8_t* bqual = p.qual + (size_t)read0 * p.pitch;
+            const int total = n * p.cpr;
+            u32 carry_code = 4u, carry_char = 0u;
+            for (int w0 = 0; w0 < total; w0 += 64) {
+                const int w = w0 + lane;
+                const bool act0 = w < total;
+                const int k = act0 ? (p.cpr == 1 ? w : (int)__umulhi((u32)w, p.cpr_magic)) : 0;
+                const int j = w - k * p.cpr;
+                const u32 mk = bperm(cm, k);
+                const u32 off = n == 64 ? (u32)k : bperm(coff, k);
+                const int len = (int)(mk & 0xFFFFu);
+                const bool second = (mk >> 31) != 0u;
+                const int pos0 = 16 * j;
+                const int nb = act0 ? (len - pos0) : 0;
+                const bool act = nb > 0;
+                u32 s[4] = {0u, 0u, 0u, 0u}, c[4] = {0u, 0u, 0u, 0u}, q[4] = {0u, 0u, 0u, 0u};
+                if (act) {
+                    const u32 rowoff = off * (u32)p.pitch + (u32)pos0;      // < 64 * pitch
+                    const uint4 sv = *reinterpret_cast<const uint4*>(bseq + rowoff);
+                    const uint4 cv = *reinterpret_cast<const uint4*>(bcseq + rowoff);
+                    const uint4 qv = *reinterpret_cast<const uint4*>(bqual + rowoff);
+                    s[0] = sv.x; s[1] = sv.y; s[2] = sv.z; s[3] = sv.w;
+                    c[0] = cv.x; c[1] = cv.y; c[2] = cv.z; c[3] = cv.w;
+                    q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+                }
+                // byte-parallel decode; alphabet and q-range screening (no byte masks: bytes past
+                // the read are 'N' in seq/cseq and 0 in qual by the layout contract; anything else
+                // only costs a visit to the exact checker)
+                u32 code[4], badbits = 0u, hiq = 0u;
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd) {
+                    const u32 h = (s[wd] >> 1) & 0x07070707u;
+                    const u32 expect = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, h);
+                    code[wd] = __builtin_amdgcn_perm(0x04040404u, 0x02010300u, h);   // A0 T1 G2 C3, N/other 4
+                    badbits |= expect ^ s[wd];
+                    hiq |= (q[wd] + 0x34343434u) | q[wd];                            // bit 7 of a byte: q > 42
+                }
+                hiq &= 0x80808080u;
+                const u32 last_code = code[3] >> 24;
+                const u32 last_char = s[3] >> 24;
+                u32 prev_code = wave_shr1(last_code, carry_code);
+                u32 prev_char = wave_shr1(last_char, carry_char);
+                carry_code = (u32)__builtin_amdgcn_readlane((int)last_code, 63);
+                carry_char = (u32)__builtin_amdgcn_readlane((int)last_char, 63);
+                if (j == 0) { prev_code = 4u; prev_char = 0u; }                      // dinuc[0] = -1
+                if (act) {
+                    const long long read = read0 + off;
+                    if (hiq || len > S) flag(p.status, ST_INDEX, read);              // recalibrate.py:114-115; read longer than the tables
+                    if (badbits && chunk_type_error(s[0], s[1], s[2], s[3], q[0], q[1], q[2], q[3],
+                                                    prev_char, nb, pos0, p.type_minscore))
+                        flag(p.status, ST_TYPE, read);                               // compare_reads.py:224,292
+                    if (!hiq && len <= S) {
+                        // A: pos address less the row term; both mates ascend with the base index
+                        const u32 half = second ? (u32)(S + 2 * (S - len)) : 0u;     // column 2*len-1-pos
+                        const u32 A = pos_base + (half + (u32)pos0) * 4u;
+                        u32 pc = prev_code << 24;
+#pragma unroll
+                        for (int wd = 0; wd < 4; ++wd) {
+                            const u32 pw = __builtin_amdgcn_alignbyte(code[wd], pc, 3);
+                            const u32 d5x8 = ((pw << 2) + pw + code[wd]) << 3;        // 8 * (5*prev + cur) per byte, <= 192
+                            pc = code[wd];
+                            const u32 xw = s[wd] ^ c[wd];
+                            const u32 qn = ~q[wd];
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const u32 qi = (qn >> (8 * b)) & 0xFFu;                 // 255 - quality byte
+                                const u32 tq = qi < tclamp ? qi : tclamp;              // below minscore (and padding): trash row
+                                const bool err = ((xw >> (8 * b)) & 0xFFu) != 0u;      // recalibrate.py:13-20
+                                const u32 a = __umul24(tq, row_bytes) + A + (u32)(4 * (4 * wd + b));
+                                atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + a),
+                                          err ? 0x10001u : 1u);                       // recalibrate.py:116-117
+                                u32 slot = (d5x8 >> (8 * b)) & 0xFFu;
+                                if (SPLIT) slot = qi <= 255u - p.dlo ? slot : (u32)(24 * 8);   // context needs q >= its own threshold
+                                const u32 ad = (tq << 8) + dn_base + slot;
+                                atomicAdd(reinterpret_cast<u64*>(reinterpret_cast<char*>(lds) + ad),
+                                          err ? 0x100000001ull : 1ull);               // recalibrate.py:118-119
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (++since_flush == K1V3_FLUSH_ITERS) {
+            __syncthreads(); flush(); __syncthreads();
+            since_flush = 0;
+        }
+    }
+    __syncthreads();
+    flush();
+}
+
+// ---------------------------------------------------------------- K2 (table-driven)
+// "Full" LUT, int8, one row per (read group, RAW quality byte qb in [0, 33+Qt)):
+//     row[0 .. W)         cycle entry for first-in-pair reads, index = position   (W = S2 + 16:
+//     row[W .. 2W)        the same entries mirrored: W + position <-> column S2-1-position
+//     row[2W .. +32)      context entry, index 5*code(prev)+code(cur) (25 used)
+// the 16 extra entries per region keep the padding positions of a 16-byte chunk in-region)
+// qb = 0 (padding): cycle entries -33, contexts 0  -> output byte 0
+// qb below 33 + minscore: identity rows (cycle entry = qb - 33, contexts 0) -> byte unchanged
+// otherwise the model rows.  new byte = cycle entry + context entry + 33.
+__host__ __device__ __forceinline__ int full_lut_width(int S2) { return S2 + 16; }
+__host__ __device__ __forceinline__ int full_lut_row_bytes(int S2)
+{
+    int rb = (2 * full_lut_width(S2) + 32 + 3) & ~3;
+    if (((rb >> 2) & 1) == 0) rb += 4;        // odd number of dwords per row: rows start on different banks
+    return rb;
+}
+
+struct K2v3Params {
+    const uint8_t* seq; const uint8_t* qual; const u32* meta;
+    long long nreads; int pitch; int cpr; u32 cpr_magic; int R; int Qt; int S2; int minscore; u32 qlo;
+    const int16_t* lut16;      // canonical LUT (exact path)
+    const int8_t* full;        // full LUT (global copy, staged into LDS)
+    int full_bytes; int rs16;
+    uint8_t* out; u64* status;
+};
+
+__global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    {
+        const u32* src = reinterpret_cast<const u32*>(p.full);
+        const int nw = p.full_bytes >> 2;
+        for (int i = threadIdx.x; i < nw; i += blockDim.x) lds[i] = src[i];
+        __syncthreads();
+    }
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const long long nblocks = (p.nreads + 63) >> 6;
+    const u32 rb = (u32)full_lut_row_bytes(p.S2);
+    const u32 rg_bytes = (u32)(33 + p.Qt) * rb;
+    const u32 hi_add = (u32)(0x80 - (p.Qt + 33)) * 0x01010101u;   // byte >= Qt+33 <=> bit 7 after the add
+
+    for (long long blk = (long long)blockIdx.x * nwaves + wave; blk < nblocks;
+         blk += (long long)gridDim.x * nwaves) {
+        const long long read0 = blk << 6;
+        const long long myread = read0 + lane;
+        const u32 m = myread < p.nreads ? p.meta[myread] : 0u;
+        const int n = (int)((p.nreads - read0) < 64 ? (p.nreads - read0) : 64);
+        const int total = n * p.cpr;
+        const uint8_t* bseq = p.seq + (size_t)read0 * p.pitch;
+        const uint8_t* bqual = p.qual + (size_t)read0 * p.pitch;
+        uint8_t* bout = p.out + (size_t)read0 * p.pitch;
+        u32 carry_code = 4u, carry_char = 0u;
+        for (int w0 = 0; w0 < total; w0 += 64) {
+            const int w = w0 + lane;
+            const bool act0 = w < total;
+            const int k = act0 ? (p.cpr == 1 ? w : (int)__umulhi((u32)w, p.cpr_magic)) : 0;
+            const int j = w - k * p.cpr;
+            const u32 mk = bperm(m, k);
+            const int len = (int)(mk & 0xFFFFu);
+            const int rg = (int)((mk >> 16) & 0x7FFFu);
+            const bool second = (mk >> 31) != 0u;
+            const int pos0 = 16 * j;
+            const int nb = act0 ? (len - pos0) : 0;
+            const bool act = nb > 0;
+            const u32 rowoff = (u32)k * (u32)p.pitch + (u32)pos0;
+            u32 s[4] = {0u, 0u, 0u, 0u}, q[4] = {0u, 0u, 0u, 0u};
+            if (act) {
+                const uint4 sv = *reinterpret_cast<const uint4*>(bseq + rowoff);
+                const uint4 qv = *reinterpret_cast<const uint4*>(bqual + rowoff);
+                s[0] = sv.x; s[1] = sv.y; s[2] = sv.z; s[3] = sv.w;
+                q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+            }
+            u32 code[4], badbits = 0u, hiq = 0u;
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd) {
+                const u32 h = (s[wd] >> 1) & 0x07070707u;
+                const u32 expect = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, h);
+                code[wd] = __builtin_amdgcn_perm(0x04040404u, 0x02010300u, h);
+                badbits |= expect ^ s[wd];
+                hiq |= ((q[wd] & 0x7F7F7F7Fu) + hi_add) | q[wd];
+            }
+            hiq &= 0x80808080u;
+            const u32 last_code = code[3] >> 24;
+            const u32 last_char = s[3] >> 24;
+            u32 prev_code = wave_shr1(last_code, carry_code);
+            u32 prev_char = wave_shr1(last_char, carry_char);
+            carry_code = (u32)__builtin_amdgcn_readlane((int)last_code, 63);
+            carry_char = (u32)__builtin_amdgcn_readlane((int)last_char, 63);
+            if (j == 0) { prev_code = 4u; prev_char = 0u; }
+            if (act0) {
+                u32 o[4] = {0u, 0u, 0u, 0u};
+                if (act) {
+                    const long long read = read0 + k;
+                    if (badbits && chunk_type_error(s[0], s[1], s[2], s[3], q[0], q[1], q[2], q[3],
+                                                    prev_char, nb, pos0, p.minscore))
+                        flag(p.status, ST_TYPE, read);
+                    u32 d5[4];
+                    u32 pc = prev_code << 24;
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) {
+                        const u32 pw = __builtin_amdgcn_alignbyte(code[wd], pc, 3);
+                        d5[wd] = (pw << 2) + pw + code[wd];
+                        pc = code[wd];
+                    }
+                    const bool trouble = hiq != 0u || rg >= p.R || len > p.S2;
+                    if (trouble) {
+                        const uint4 e = chunk_apply_exact(p.lut16, p.rs16, p.R, p.Qt, p.S2, p.qlo, rg, second, pos0, nb,
+                                                          q[0], q[1], q[2], q[3], d5[0], d5[1], d5[2], d5[3],
+                                                          p.status, read);
+                        o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = e.w;
+                    } else {
+                        const u32 rgb = (u32)rg * rg_bytes;
+                        const u32 W = (u32)full_lut_width(p.S2);
+                        const u32 A = rgb + (second ? W : 0u) + (u32)pos0;
+                        const u32 C = rgb + 2u * W;
+#pragma unroll
+                        for (int wd = 0; wd < 4; ++wd) {
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const u32 qb = (q[wd] >> (8 * b)) & 0xFFu;
+                                const u32 rowq = __umul24(qb, rb);
+                                const u32 dd = (d5[wd] >> (8 * b)) & 0xFFu;
+                                const int v1 = *reinterpret_cast<const int8_t*>(reinterpret_cast<const char*>(lds) + (rowq + A + (u32)(4 * wd + b)));
+                                const int v2 = *reinterpret_cast<const int8_t*>(reinterpret_cast<const char*>(lds) + (rowq + C + dd));
+                                o[wd] |= ((u32)(v1 + v2 + 33) & 0xFFu) << (8 * b);
+                            }
+                        }
+                    }
+                }
+                *reinterpret_cast<uint4*>(bout + rowoff) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
+// Builds the full int8 LUT from the canonical int16 LUT and reports whether it is usable:
+// flags[0] |= 1 when some value does not fit int8, flags[0] |= 2 when some (cycle, context)
+// combination of a row could leave 0..255 (then the checked kernel must be used).
+struct LutFillParams {
+    const int16_t* lut16; int rs16; int R; int Qt; int S2; int minscore;
+    int8_t* full; int* flags; u64* status;
+};
+
+__global__ __launch_bounds__(256) void k3_fill_full_lut(LutFillParams p)
+{
+    const int rb = full_lut_row_bytes(p.S2);
+    const int NR = 33 + p.Qt;
+    const long long total = (long long)p.R * NR * rb;
+    int bad = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / rb;
+        const int x = (int)(i - row * rb);
+        const int r = (int)(row / NR);
+        const int qb = (int)(row - (long long)r * NR);
+        const int W = full_lut_width(p.S2);
+        int v = 0;
+        if (qb < 33 + p.minscore) {
+            if (x < 2 * W) v = qb == 0 ? -33 : qb - 33;               // padding -> 0 ; uncounted -> unchanged
+        } else {
+            const int16_t* src = p.lut16 + ((size_t)r * p.Qt + (qb - 33)) * p.rs16;
+            if (x < p.S2) v = src[x];
+            else if (x >= W && x < W + p.S2) v = src[p.S2 - 1 - (x - W)];   // mirrored copy for second-in-pair
+            else if (x >= 2 * W && x < 2 * W + 25) v = src[p.S2 + (x - 2 * W)];
+        }
+        if (v < -128 || v > 127) bad |= 1;
+        p.full[i] = (int8_t)v;
+    }
+    // range safety per model row: min/max over cycles + min/max over contexts
+    const long long rows = (long long)p.R * p.Qt;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < rows;
+         c += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(c % p.Qt);
+        if (q < p.minscore) continue;
+        const int16_t* src = p.lut16 + (size_t)c * p.rs16;
+        int lo1 = 32767, hi1 = -32768, lo2 = 32767, hi2 = -32768;
+        for (int x = 0; x < p.S2; ++x) { const int v = src[x]; lo1 = v < lo1 ? v : lo1; hi1 = v > hi1 ? v : hi1; }
+        for (int x = 0; x < 25; ++x) { const int v = src[p.S2 + x]; lo2 = v < lo2 ? v : lo2; hi2 = v > hi2 ? v : hi2; }
+        if (lo1 + lo2 + 33 < 0 || hi1 + hi2 + 33 > 255) bad |= 2;
+    }
+    if (bad) { atomicOr(p.flags, bad); atomicMin(&p.status[ST_LUT], 0ull); }
+}

@@ -121,8 +121,9 @@ def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None
         ctx.status()
 
 
-def build_lut(meanq, rgdq, qdq, posdq, dinucdq):
-    """Fold the five model arrays into the int16 apply LUT (host, tiny)."""
+def build_lut(meanq, rgdq, qdq, posdq, dinucdq, minscore=MINSCORE):
+    """Fold the five model arrays into the apply LUT blob (host, tiny).  Returns
+    (blob uint8 ndarray, (R, Qt, S2, mode))."""
     a = [np.ascontiguousarray(np.asarray(x), dtype=np.int64) for x in (meanq, rgdq, qdq, posdq, dinucdq)]
     if a[3].ndim != 3 or a[4].ndim != 3:
         raise ValueError('positiondeltaq / dinucdeltaq must be 3-d')
@@ -130,25 +131,35 @@ def build_lut(meanq, rgdq, qdq, posdq, dinucdq):
     D = a[4].shape[2]
     if a[0].shape != (R,) or a[1].shape != (R,) or a[2].shape != (R, Qt) or a[4].shape[:2] != (R, Qt):
         raise IndexError('delta-Q tables have inconsistent shapes')
-    lut = np.zeros(N.load().kbbq_lut_count(R, Qt, S2), dtype=np.int16)
-    safe = ctypes.c_int(0)
-    N.check(N.load().kbbq_build_lut(R, Qt, S2, D, N.ptr(a[0]), N.ptr(a[1]), N.ptr(a[2]), N.ptr(a[3]),
-                                    N.ptr(a[4]), N.ptr(lut), ctypes.byref(safe)))
-    return lut, (R, Qt, S2, safe.value)
+    lib = N.load()
+    blob = np.zeros((lib.kbbq_lut_bytes(R, Qt, S2) + 7) // 8, dtype=np.int64).view(np.uint8)
+    flags = ctypes.c_int(0)
+    N.check(lib.kbbq_build_lut(R, Qt, S2, D, minscore, N.ptr(a[0]), N.ptr(a[1]), N.ptr(a[2]), N.ptr(a[3]),
+                               N.ptr(a[4]), N.ptr(blob), ctypes.byref(flags)))
+    return blob, (R, Qt, S2, N.APPLY_FAST if flags.value == 0 else N.APPLY_CHECKED)
 
 
 def apply(batch, lut_dev, shape, out=None, minscore=MINSCORE, check=True):
-    """K2 over a device batch: new quality bytes [n, pitch] (compare_reads.py:320-328)."""
+    """K2 over a device batch: new quality bytes [n, pitch] (compare_reads.py:320-328).
+    With check=False the caller must call context().status() itself (and re-run with
+    mode APPLY_CHECKED on LutNeedsCheckedApply)."""
     torch = _torch()
-    R, Qt, S2, range_safe = shape
+    R, Qt, S2, mode = shape
     ctx = context(batch.seq.device.index)
     if out is None:
         out = torch.empty_like(batch.qual)
-    N.check(N.load().kbbq_apply_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.qual), N.ptr(batch.meta),
-                                    batch.n, batch.pitch, R, Qt, S2, minscore, N.ptr(lut_dev),
-                                    range_safe, N.ptr(out)))
+
+    def launch(m):
+        N.check(N.load().kbbq_apply_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.qual), N.ptr(batch.meta),
+                                        batch.n, batch.pitch, R, Qt, S2, minscore, N.ptr(lut_dev), m,
+                                        N.ptr(out)))
+    launch(mode)
     if check:
-        ctx.status()
+        try:
+            ctx.status()
+        except N.LutNeedsCheckedApply:
+            launch(N.APPLY_CHECKED)
+            ctx.status()
     return out
 
 
@@ -190,7 +201,7 @@ def delta_q(prior_q, numerrs, numtotal):
     return out.cpu().numpy().reshape(pq.shape).astype(np.int_)
 
 
-def solve(tables, want_dq=False):
+def solve(tables, want_dq=False, minscore=MINSCORE):
     """K3, fused form: count tables (device) -> apply LUT (device), the whole of
     applybqsr.get_delta_qs.  Host work: marginals, meanq and the gammaln terms.
     Returns (lut_dev, shape, vectors, dqs) -- dqs is None unless want_dq."""
@@ -207,10 +218,10 @@ def solve(tables, want_dq=False):
     d_aux = torch.from_numpy(np.ascontiguousarray(aux, dtype=np.float64)).to(dev)
     d_meanq = torch.from_numpy(np.ascontiguousarray(meanq, dtype=np.int32)).to(dev)
     post_q = torch.empty(R * NQ, dtype=torch.int32, device=dev)
-    lut = torch.empty(lib.kbbq_lut_count(R, NQ, S2), dtype=torch.int16, device=dev)
+    lut = torch.zeros(lib.kbbq_lut_bytes(R, NQ, S2), dtype=torch.uint8, device=dev)
     dq = torch.empty(lib.kbbq_solve_dq_count(R, S2), dtype=torch.int32, device=dev) if want_dq else None
     ctx = context(dev.index)
-    N.check(lib.kbbq_solve_dev(ctx.handle, N.ptr(tables.buf), R, S2, N.ptr(d_meanq), N.ptr(d_aux),
+    N.check(lib.kbbq_solve_dev(ctx.handle, N.ptr(tables.buf), R, S2, minscore, N.ptr(d_meanq), N.ptr(d_aux),
                                N.ptr(_model_consts()), N.ptr(post_q), N.ptr(lut), N.ptr(dq)))
     dqs = None
     if want_dq:
@@ -218,4 +229,4 @@ def solve(tables, want_dq=False):
         o1, o2, o3 = R, R + R * NQ, R + R * NQ + R * NQ * S2
         dqs = (h[:o1].copy(), h[o1:o2].reshape(R, NQ).copy(), h[o2:o3].reshape(R, NQ, S2).copy(),
                h[o3:].reshape(R, NQ, 17).copy())
-    return lut, (R, NQ, S2, 0), vectors, dqs
+    return lut, (R, NQ, S2, N.APPLY_FAST), vectors, dqs

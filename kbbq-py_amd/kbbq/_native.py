@@ -19,6 +19,8 @@ KBBQ_E_TYPE = -3
 KBBQ_E_ARG = -4
 KBBQ_E_RANGE = -5
 KBBQ_E_NAME = -6
+KBBQ_E_LUT = -7
+APPLY_CHECKED, APPLY_FAST = 0, 1
 
 NQ = 43
 NDINUC = 16
@@ -48,14 +50,16 @@ PROTOTYPES = {
     'kbbq_accumulate_ex_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     'kbbq_accumulate': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'kbbq_lut_row_stride': (_i, [_i]),
-    'kbbq_build_lut': (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(_i)]),
+    'kbbq_full_lut_bytes': (_sz, [_i, _i, _i]),
+    'kbbq_lut_bytes': (_sz, [_i, _i, _i]),
+    'kbbq_build_lut': (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(_i)]),
     'kbbq_apply_dev': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'kbbq_apply': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i,
                         _vp, _vp, _vp, _vp, _vp, _vp]),
     'kbbq_delta_q_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'kbbq_solve_aux_count': (_sz, [_i, _i]),
     'kbbq_solve_dq_count': (_sz, [_i, _i]),
-    'kbbq_solve_dev': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'kbbq_solve_dev': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kbbq_synth_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _u64,
                             _i, _i, _i, _i, _i, _vp]),
     'kbbq_ctx_timing': (_i, [_vp, _i]),
@@ -67,6 +71,10 @@ _lib = None
 
 class KbbqHipError(RuntimeError):
     """A HIP runtime failure or a bad argument reported by libkbbq_hip."""
+
+
+class LutNeedsCheckedApply(KbbqHipError):
+    """kbbq_ctx_status: the device-built LUT is not usable by the table-driven apply kernel."""
 
 
 def load():
@@ -113,6 +121,8 @@ def check(rc):
         raise AssertionError(msg)
     if rc == KBBQ_E_ARG:
         raise ValueError(msg)
+    if rc == KBBQ_E_LUT:
+        raise LutNeedsCheckedApply(msg)
     raise KbbqHipError(msg or ('libkbbq_hip error %d' % rc))
 
 

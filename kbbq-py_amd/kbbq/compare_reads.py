@@ -170,7 +170,7 @@ def recalibrate_fastq(read, meanq, globaldeltaq, qscoredeltaq, positiondeltaq, d
     if np.any(q + 33 < 0) or np.any(q + 33 > 255):
         raise ValueError('quality outside the byte range')
     pitch = max(16, (L + 15) // 16 * 16)
-    sp = np.zeros((1, pitch), dtype=np.uint8)
+    sp = np.full((1, pitch), ord('N'), dtype=np.uint8)
     qp = np.zeros((1, pitch), dtype=np.uint8)
     sp[0, :L] = np.frombuffer(seq, dtype=np.uint8)
     qp[0, :L] = (q + 33).astype(np.uint8)

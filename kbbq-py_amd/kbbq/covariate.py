@@ -180,7 +180,7 @@ class CovariateData():
         if np.any(codes > 255):
             raise TypeError('non-ASCII base')
         pitch = max(16, (L + 15) // 16 * 16)
-        seq = np.zeros((1, pitch), dtype=np.uint8); seq[0, :L] = codes
+        seq = np.full((1, pitch), ord('N'), dtype=np.uint8); seq[0, :L] = codes
         cseq = seq.copy()
         err = np.asarray(read.errors, dtype=bool)
         cseq[0, :L][err] = np.where(seq[0, :L][err] == ord('A'), ord('C'), ord('A'))

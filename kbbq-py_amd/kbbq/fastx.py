@@ -83,10 +83,11 @@ class FastqText:
                               head[1].decode('ascii') if len(head) > 1 else None)
 
     def plane(self, which, n, pitch):
-        """Rows [0, n) of the seq ('s') or qual ('q') lines as a zero-padded [n, pitch] plane."""
+        """Rows [0, n) of the seq ('s') or qual ('q') lines as a padded [n, pitch] plane
+        (padding: 'N' for sequences, 0 for qualities -- include/kbbq_hip.h)."""
         a0 = (self.s0 if which == 's' else self.q0)[:n]
         lens = (self.s1 - self.s0)[:n]
-        out = np.zeros((n, pitch), dtype=np.uint8)
+        out = np.full((n, pitch), ord('N') if which == 's' else 0, dtype=np.uint8)
         if n == 0:
             return out
         if np.all(lens == lens[0]) and n > 1 and np.all(np.diff(a0) == a0[1] - a0[0]):

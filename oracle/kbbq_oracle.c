@@ -218,7 +218,7 @@ int kbbq_oracle_apply(const uint8_t* seq, const uint8_t* qual, const uint32_t* m
  *   length   = len_lo + (read * (len_hi - len_lo + 1)) / total_reads
  *              (non-decreasing ramp: the only order the reference survives, H2)
  *   rg       = (read >> 1) % nrg  ; second = read & 1
- * Row bytes at and beyond the read length are zero.
+ * Row bytes at and beyond the read length: 'N' in seq / cseq, 0 in qual.
  * ------------------------------------------------------------------------ */
 static inline uint64_t mix64(uint64_t x)
 {
@@ -253,6 +253,6 @@ void kbbq_oracle_synth(uint8_t* seq, uint8_t* cseq, uint8_t* qual, uint32_t* met
             c[i]  = err ? (isn ? ACGT[b] : ACGT[sub]) : s[i];
             ql[i] = (uint8_t)(q + 33);
         }
-        for (int64_t i = len; i < pitch; ++i) { s[i] = 0; c[i] = 0; ql[i] = 0; }
+        for (int64_t i = len; i < pitch; ++i) { s[i] = 'N'; c[i] = 'N'; ql[i] = 0; }
     }
 }

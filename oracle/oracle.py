@@ -169,9 +169,9 @@ def pack_records(uncorr, corr, infer_rg_flag, pitch=None):
     maxlen = max([len(r[1]) for r in uncorr[:n]] + [1])
     if pitch is None:
         pitch = (maxlen + 15) // 16 * 16
-    seq = np.zeros((n, pitch), dtype=np.uint8)
-    cseq = np.zeros((n, pitch), dtype=np.uint8)
-    qual = np.zeros((n, pitch), dtype=np.uint8)
+    seq = np.full((n, pitch), ord('N'), dtype=np.uint8)     # layout contract: 'N' past the read ...
+    cseq = np.full((n, pitch), ord('N'), dtype=np.uint8)
+    qual = np.zeros((n, pitch), dtype=np.uint8)              # ... and 0 in the quality plane
     meta = np.zeros(n, dtype=np.uint32)
     rg_to_int = {}
     for i in range(n):

@@ -96,7 +96,7 @@ def test_accumulate_and_apply_match_oracle(dev, oracle, shape, minscore):
     rng = np.random.default_rng(s['seed'])
     meanq = rng.integers(10, 30, R); rgdq = rng.integers(-2, 3, R); qdq = rng.integers(-3, 4, (R, 43))
     posdq = rng.integers(-6, 7, (R, 43, 2 * S)); ddq = rng.integers(-6, 7, (R, 43, 17)); ddq[..., 16] = 0
-    lut, shp = dev.build_lut(meanq, rgdq, qdq, posdq, ddq)
+    lut, shp = dev.build_lut(meanq, rgdq, qdq, posdq, ddq, minscore=minscore)
     batch = dev.ReadBatch.from_host(seq, qual, meta)
     out = dev.apply(batch, dev.lut_to_device(lut), shp, minscore=minscore)[:s['n']].cpu().numpy()
     ref = oracle.apply(seq, qual, meta, meanq, rgdq, qdq, posdq, ddq, minscore=minscore)
@@ -104,6 +104,9 @@ def test_accumulate_and_apply_match_oracle(dev, oracle, shape, minscore):
     inside = np.arange(seq.shape[1])[None, :] < lens[:, None]
     assert np.array_equal(out[inside].astype(np.int32) - 33, ref[inside])
     assert not out[~inside].any()
+    # the checked kernel (int16 LUT, per-base range test) gives the same bytes
+    chk = dev.apply(batch, dev.lut_to_device(lut), shp[:3] + (0,), minscore=minscore)[:s['n']].cpu().numpy()
+    assert np.array_equal(chk, out)
 
 
 def test_accumulate_adds_into_tables_and_is_linear(dev, oracle):
@@ -191,8 +194,8 @@ def test_k3_get_delta_qs_and_fused_solve_match_reference(dev, name):
     for k, v in zip(DQ, fdq):
         assert np.array_equal(v, g[k]), k
     want_lut, want_shape = dev.build_lut(g['meanq'], g['rgdq'], g['qdq'], g['posdq'], g['dinucdq'])
-    assert shape[:3] == want_shape[:3]
-    assert np.array_equal(lut.cpu().numpy(), want_lut)
+    assert shape == want_shape
+    assert np.array_equal(lut.cpu().numpy(), want_lut)     # canonical + table-driven parts + flags, byte for byte
 
 
 def test_get_delta_qs_known_answer(dev):

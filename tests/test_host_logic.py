@@ -47,7 +47,7 @@ def test_no_cpu_fallback_without_gpu():
 
 def test_build_lut_host():
     lib = _native.load()
-    R, Qt, S2, D = 2, 5, 6, 17
+    R, Qt, S2, D, minscore = 2, 5, 6, 17, 2
     rng = np.random.default_rng(0)
     meanq = rng.integers(0, 40, R); rgdq = rng.integers(-3, 3, R)
     qdq = rng.integers(-3, 3, (R, Qt)); posdq = rng.integers(-5, 5, (R, Qt, S2))
@@ -55,25 +55,39 @@ def test_build_lut_host():
     rs = lib.kbbq_lut_row_stride(S2)
     assert rs >= S2 + 25 and rs % 2 == 0 and (rs // 2) % 2 == 1
     assert lib.kbbq_lut_count(R, Qt, S2) == R * Qt * rs
-    lut = np.zeros(lib.kbbq_lut_count(R, Qt, S2), dtype=np.int16)
+    nbytes = lib.kbbq_lut_bytes(R, Qt, S2)
+    blob = np.zeros((nbytes + 7) // 8, dtype=np.int64).view(np.uint8)
     a = [np.ascontiguousarray(x, dtype=np.int64) for x in (meanq, rgdq, qdq, posdq, ddq)]
-    safe = ctypes.c_int(-1)
-    _native.check(lib.kbbq_build_lut(R, Qt, S2, D, *[_native.ptr(x) for x in a], _native.ptr(lut),
-                                     ctypes.byref(safe)))
-    rows = lut.reshape(R, Qt, rs)
-    assert np.array_equal(rows[..., :S2], (meanq + rgdq)[:, None, None] + qdq[..., None] + posdq)
+    flags = ctypes.c_int(-1)
+    _native.check(lib.kbbq_build_lut(R, Qt, S2, D, minscore, *[_native.ptr(x) for x in a], _native.ptr(blob),
+                                     ctypes.byref(flags)))
+    rows = blob[:R * Qt * rs * 2].view(np.int16).reshape(R, Qt, rs)
+    lut1 = (meanq + rgdq)[:, None, None] + qdq[..., None] + posdq
+    assert np.array_equal(rows[..., :S2], lut1)
     for pa in range(5):
         for pb in range(5):
             want = ddq[..., 4 * pa + pb] if pa < 4 and pb < 4 else ddq[..., 16]
             assert np.array_equal(rows[..., S2 + 5 * pa + pb], want)
-    assert safe.value == 1
-    a[3][0, 0, 0] = 300
-    _native.check(lib.kbbq_build_lut(R, Qt, S2, D, *[_native.ptr(x) for x in a], _native.ptr(lut),
-                                     ctypes.byref(safe)))
-    assert safe.value == 0
+    assert flags.value == 0
+    # table-driven part: rows by raw quality byte
+    fb = lib.kbbq_full_lut_bytes(R, Qt, S2)
+    off = (R * Qt * rs * 2 + 15) // 16 * 16
+    full = blob[off:off + fb].view(np.int8).reshape(R, 33 + Qt, -1)
+    W = S2 + 16
+    assert np.all(full[:, 0, :2 * W] == -33) and np.all(full[:, 0, 2 * W:] == 0)
+    for qb in range(1, 33 + minscore):
+        assert np.all(full[:, qb, :2 * W] == qb - 33) and np.all(full[:, qb, 2 * W:] == 0)
+    for q in range(minscore, Qt):
+        assert np.array_equal(full[:, 33 + q, :S2], lut1[:, q])
+        assert np.array_equal(full[:, 33 + q, W:W + S2], lut1[:, q, ::-1])
+        assert np.array_equal(full[:, 33 + q, 2 * W:2 * W + 25], rows[:, q, S2:S2 + 25])
+    a[3][0, 3, 0] = 300
+    _native.check(lib.kbbq_build_lut(R, Qt, S2, D, minscore, *[_native.ptr(x) for x in a], _native.ptr(blob),
+                                     ctypes.byref(flags)))
+    assert flags.value == 3           # does not fit int8 and can leave 0..255
     with pytest.raises(ValueError):
-        _native.check(lib.kbbq_build_lut(R, Qt, S2, 3, *[_native.ptr(x) for x in a], _native.ptr(lut),
-                                         ctypes.byref(safe)))
+        _native.check(lib.kbbq_build_lut(R, Qt, S2, 3, minscore, *[_native.ptr(x) for x in a], _native.ptr(blob),
+                                         ctypes.byref(flags)))
 
 
 # ---------------------------------------------------------------- FASTQ packer
