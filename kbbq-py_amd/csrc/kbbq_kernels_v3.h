@@ -21,9 +21,10 @@
 #pragma once
 #include "kbbq_kernels.h"
 
-#define K1V3_THREADS 512
+#define K1V3_THREADS 1024        // one workgroup per CU: the replicated context table needs ~150 KB of LDS
+#define K1V3_DNREP 16            // copies of the context-total table (copy = lane & 15)
 #define K2V3_THREADS 512
-#define K1V3_FLUSH_ITERS 96          // as K1: 49,152 reads per workgroup between flushes
+#define K1V3_FLUSH_ITERS 48          // 48 * 16 waves * 64 reads = 49,152 reads per workgroup between flushes (< 65,535)
 
 struct K1v3Params {
     const uint8_t* seq; const uint8_t* cseq; const uint8_t* qual; const u32* meta;
@@ -38,7 +39,12 @@ struct K1v3Params {
     u64* tables; u64* status;
 };
 
-// LDS: dn [nrows][32] u64  (errs << 32 | total), slot = 5*code(prev)+code(cur), at offset 0
+struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int j; int nb; };
+
+// LDS: dnt[nrows][32][16] u32 context totals, 16 copies (copy = lane & 15: the table is tiny and
+//          hot -- measured 15 LDS cycles per wave-atomic unreplicated -- copies cut the bank and
+//          same-address collisions), dne[nrows][32] u32 context errors (errors are ~3 % of the
+//          bases: added only by the lanes that have one), slot = 5*code(prev)+code(cur)
 //      pos[nrows][row_bytes/4] u32 (errs << 16 | total): [0,S) first-in-pair cycle = position;
 //          [S, 3S) second-in-pair, index x = position + 2*(S - len)  <->  column 2S-1-x
 //      rows are ordered by the INVERTED quality byte (row = 42 - q, one v_min clamps every
@@ -48,16 +54,17 @@ template <bool SPLIT>
 __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
-    const int dn_words = p.nrows * 64;
+    const int dn_words = p.nrows * 32 * (K1V3_DNREP + 1);   // replicated totals + one errors table
     const int pos_words = p.nrows * (int)(p.row_bytes >> 2) + (int)(p.slack_bytes >> 2);
-    u64* dn = reinterpret_cast<u64*>(lds);
+    u32* dnt = lds;
+    u32* dne = lds + p.nrows * 32 * K1V3_DNREP;
     u32* pos = lds + dn_words;
     for (int i = threadIdx.x; i < dn_words + pos_words; i += blockDim.x) lds[i] = 0u;
     __syncthreads();
 
     const int g = blockIdx.y;
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block bases live in SGPRs
     const int nwaves = blockDim.x >> 6;
     const long long nblocks = (p.nreads + 63) >> 6;
     const long long iters = (nblocks + nwaves - 1) / nwaves;
@@ -65,7 +72,9 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
     const u32 row_bytes = p.row_bytes;
     const u32 tclamp = 255u - p.qlo_m1;                                // inverted bytes >= this are uncounted
     const u32 pos_base = (u32)dn_words * 4u - 180u * row_bytes;        // 180 = 255 - 'K': inverted byte of q = 42 is row 0
-    const u32 dn_base = 0u - 180u * 256u;
+    const u32 dnt_row = 128u * K1V3_DNREP;                             // bytes per row of the replicated totals
+    const u32 dnt_base = 0u - 180u * dnt_row + 4u * (u32)(lane_id() & (K1V3_DNREP - 1));
+    const u32 dne_base = (u32)p.nrows * dnt_row - 180u * 128u;         // errors table: rows of 32 u32, after the totals
     int since_flush = 0;
 
     u64* pos_errs = p.tables;
@@ -90,12 +99,17 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
             if (lane < 25) {
                 const int a = lane / 5, b = lane - 5 * a;
                 if (a < 4 && b < 4) {
-                    const u64 v = dn[r * 32 + lane];
-                    if (v) {
-                        dn[r * 32 + lane] = 0ull;
+                    u32 vt = 0u;
+                    for (int cpy = 0; cpy < K1V3_DNREP; ++cpy) {
+                        vt += dnt[(r * 32 + lane) * K1V3_DNREP + cpy];
+                        dnt[(r * 32 + lane) * K1V3_DNREP + cpy] = 0u;
+                    }
+                    const u32 ve = dne[r * 32 + lane];
+                    if (vt) {
+                        dne[r * 32 + lane] = 0u;
                         const size_t e = ((size_t)g * KQ + q) * KND + 4 * a + b;
-                        atomicAdd(&dn_total[e], v & 0xFFFFFFFFull);
-                        if (v >> 32) atomicAdd(&dn_errs[e], v >> 32);
+                        atomicAdd(&dn_total[e], (u64)vt);
+                        if (ve) atomicAdd(&dn_errs[e], (u64)ve);
                     }
                 }
             }
@@ -123,52 +137,60 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
             const uint8_t* bqual = p.qual + (size_t)read0 * p.pitch;
             const int total = n * p.cpr;
             u32 carry_code = 4u, carry_char = 0u;
-            for (int w0 = 0; w0 < total; w0 += 64) {
+
+            // fetch: issue the three 16-byte loads of one step (no wait); process: bin them.
+            // The loop below keeps one step in flight while the previous one is binned.
+            auto fetch = [&](int w0, K1Chunk& ch) {
                 const int w = w0 + lane;
                 const bool act0 = w < total;
                 const int k = act0 ? (p.cpr == 1 ? w : (int)__umulhi((u32)w, p.cpr_magic)) : 0;
-                const int j = w - k * p.cpr;
-                const u32 mk = bperm(cm, k);
-                const u32 off = n == 64 ? (u32)k : bperm(coff, k);
-                const int len = (int)(mk & 0xFFFFu);
-                const bool second = (mk >> 31) != 0u;
-                const int pos0 = 16 * j;
-                const int nb = act0 ? (len - pos0) : 0;
+                ch.j = w - k * p.cpr;
+                ch.mk = bperm(cm, k);
+                ch.off = n == 64 ? (u32)k : bperm(coff, k);
+                ch.nb = act0 ? ((int)(ch.mk & 0xFFFFu) - 16 * ch.j) : 0;
+                // lanes without work re-read the block's first chunk (valid memory, result unused)
+#ifndef KBBQ_ABL_NOLOAD
+                const u32 rowoff = ch.nb > 0 ? ch.off * (u32)p.pitch + (u32)(16 * ch.j) : 0u;
+#else
+                const u32 rowoff = (u32)lane * 16u;      // timing only: every step re-reads the same cached KiB
+#endif
+                const uint4 sv = *reinterpret_cast<const uint4*>(bseq + rowoff);
+                const uint4 cv = *reinterpret_cast<const uint4*>(bcseq + rowoff);
+                const uint4 qv = *reinterpret_cast<const uint4*>(bqual + rowoff);
+                ch.s[0] = sv.x; ch.s[1] = sv.y; ch.s[2] = sv.z; ch.s[3] = sv.w;
+                ch.c[0] = cv.x; ch.c[1] = cv.y; ch.c[2] = cv.z; ch.c[3] = cv.w;
+                ch.q[0] = qv.x; ch.q[1] = qv.y; ch.q[2] = qv.z; ch.q[3] = qv.w;
+            };
+            auto process = [&](const K1Chunk& ch) {
+                const int j = ch.j, nb = ch.nb;
                 const bool act = nb > 0;
-                u32 s[4] = {0u, 0u, 0u, 0u}, c[4] = {0u, 0u, 0u, 0u}, q[4] = {0u, 0u, 0u, 0u};
-                if (act) {
-                    const u32 rowoff = off * (u32)p.pitch + (u32)pos0;      // < 64 * pitch
-                    const uint4 sv = *reinterpret_cast<const uint4*>(bseq + rowoff);
-                    const uint4 cv = *reinterpret_cast<const uint4*>(bcseq + rowoff);
-                    const uint4 qv = *reinterpret_cast<const uint4*>(bqual + rowoff);
-                    s[0] = sv.x; s[1] = sv.y; s[2] = sv.z; s[3] = sv.w;
-                    c[0] = cv.x; c[1] = cv.y; c[2] = cv.z; c[3] = cv.w;
-                    q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
-                }
+                const int len = (int)(ch.mk & 0xFFFFu);
+                const bool second = (ch.mk >> 31) != 0u;
+                const int pos0 = 16 * j;
                 // byte-parallel decode; alphabet and q-range screening (no byte masks: bytes past
                 // the read are 'N' in seq/cseq and 0 in qual by the layout contract; anything else
                 // only costs a visit to the exact checker)
                 u32 code[4], badbits = 0u, hiq = 0u;
 #pragma unroll
                 for (int wd = 0; wd < 4; ++wd) {
-                    const u32 h = (s[wd] >> 1) & 0x07070707u;
+                    const u32 h = (ch.s[wd] >> 1) & 0x07070707u;
                     const u32 expect = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, h);
                     code[wd] = __builtin_amdgcn_perm(0x04040404u, 0x02010300u, h);   // A0 T1 G2 C3, N/other 4
-                    badbits |= expect ^ s[wd];
-                    hiq |= (q[wd] + 0x34343434u) | q[wd];                            // bit 7 of a byte: q > 42
+                    badbits |= expect ^ ch.s[wd];
+                    hiq |= (ch.q[wd] + 0x34343434u) | ch.q[wd];                      // bit 7 of a byte: q > 42
                 }
                 hiq &= 0x80808080u;
                 const u32 last_code = code[3] >> 24;
-                const u32 last_char = s[3] >> 24;
+                const u32 last_char = ch.s[3] >> 24;
                 u32 prev_code = wave_shr1(last_code, carry_code);
                 u32 prev_char = wave_shr1(last_char, carry_char);
                 carry_code = (u32)__builtin_amdgcn_readlane((int)last_code, 63);
                 carry_char = (u32)__builtin_amdgcn_readlane((int)last_char, 63);
                 if (j == 0) { prev_code = 4u; prev_char = 0u; }                      // dinuc[0] = -1
                 if (act) {
-                    const long long read = read0 + off;
+                    const long long read = read0 + ch.off;
                     if (hiq || len > S) flag(p.status, ST_INDEX, read);              // recalibrate.py:114-115; read longer than the tables
-                    if (badbits && chunk_type_error(s[0], s[1], s[2], s[3], q[0], q[1], q[2], q[3],
+                    if (badbits && chunk_type_error(ch.s[0], ch.s[1], ch.s[2], ch.s[3], ch.q[0], ch.q[1], ch.q[2], ch.q[3],
                                                     prev_char, nb, pos0, p.type_minscore))
                         flag(p.status, ST_TYPE, read);                               // compare_reads.py:224,292
                     if (!hiq && len <= S) {
@@ -179,25 +201,49 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
 #pragma unroll
                         for (int wd = 0; wd < 4; ++wd) {
                             const u32 pw = __builtin_amdgcn_alignbyte(code[wd], pc, 3);
-                            const u32 d5x8 = ((pw << 2) + pw + code[wd]) << 3;        // 8 * (5*prev + cur) per byte, <= 192
+                            const u32 d5 = (pw << 2) + pw + code[wd];                // 5*prev + cur per byte, <= 24
                             pc = code[wd];
-                            const u32 xw = s[wd] ^ c[wd];
-                            const u32 qn = ~q[wd];
+                            const u32 xw = ch.s[wd] ^ ch.c[wd];
+                            const u32 qn = ~ch.q[wd];
 #pragma unroll
                             for (int b = 0; b < 4; ++b) {
                                 const u32 qi = (qn >> (8 * b)) & 0xFFu;                 // 255 - quality byte
                                 const u32 tq = qi < tclamp ? qi : tclamp;              // below minscore (and padding): trash row
                                 const bool err = ((xw >> (8 * b)) & 0xFFu) != 0u;      // recalibrate.py:13-20
                                 const u32 a = __umul24(tq, row_bytes) + A + (u32)(4 * (4 * wd + b));
+#ifndef KBBQ_ABL_NOPOS
                                 atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + a),
                                           err ? 0x10001u : 1u);                       // recalibrate.py:116-117
-                                u32 slot = (d5x8 >> (8 * b)) & 0xFFu;
-                                if (SPLIT) slot = qi <= 255u - p.dlo ? slot : (u32)(24 * 8);   // context needs q >= its own threshold
-                                const u32 ad = (tq << 8) + dn_base + slot;
-                                atomicAdd(reinterpret_cast<u64*>(reinterpret_cast<char*>(lds) + ad),
-                                          err ? 0x100000001ull : 1ull);               // recalibrate.py:118-119
+#else
+                                asm volatile("" :: "v"(a), "v"(err ? 0x10001u : 1u));
+#endif
+                                u32 slot = (d5 >> (8 * b)) & 0xFFu;
+                                if (SPLIT) slot = qi <= 255u - p.dlo ? slot : 24u;             // context needs q >= its own threshold
+                                const u32 ad = tq * dnt_row + slot * (4u * K1V3_DNREP) + dnt_base;
+#ifndef KBBQ_ABL_NODN
+                                atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + ad), 1u);   // recalibrate.py:119
+                                if (err) atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + ((tq << 7) + (slot << 2) + dne_base)), 1u);   // :118
+#else
+                                asm volatile("" :: "v"(ad), "v"(err ? 1u : 0u));
+#endif
                             }
                         }
+                    }
+                }
+            };
+
+            if (total > 0) {
+                // one step in flight while the previous one is binned; fetches are unconditional
+                // (past the end they re-read the block's first chunk) so that the outstanding
+                // loads can be counted (s_waitcnt vmcnt(3)) instead of drained
+                K1Chunk ca, cb;
+                fetch(0, ca);
+                for (int w0 = 0; w0 < total; w0 += 128) {
+                    fetch(w0 + 64, cb);
+                    process(ca);
+                    if (w0 + 64 < total) {
+                        fetch(w0 + 128, ca);
+                        process(cb);
                     }
                 }
             }
@@ -228,6 +274,8 @@ __host__ __device__ __forceinline__ int full_lut_row_bytes(int S2)
     return rb;
 }
 
+struct K2Chunk { u32 s[4], q[4]; u32 mk; int k; int j; int nb; bool act0; };
+
 struct K2v3Params {
     const uint8_t* seq; const uint8_t* qual; const u32* meta;
     long long nreads; int pitch; int cpr; u32 cpr_magic; int R; int Qt; int S2; int minscore; u32 qlo;
@@ -247,7 +295,7 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
         __syncthreads();
     }
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = blockDim.x >> 6;
     const long long nblocks = (p.nreads + 63) >> 6;
     const u32 rb = (u32)full_lut_row_bytes(p.S2);
@@ -265,48 +313,53 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
         const uint8_t* bqual = p.qual + (size_t)read0 * p.pitch;
         uint8_t* bout = p.out + (size_t)read0 * p.pitch;
         u32 carry_code = 4u, carry_char = 0u;
-        for (int w0 = 0; w0 < total; w0 += 64) {
+
+        auto fetch = [&](int w0, K2Chunk& ch) {
             const int w = w0 + lane;
-            const bool act0 = w < total;
-            const int k = act0 ? (p.cpr == 1 ? w : (int)__umulhi((u32)w, p.cpr_magic)) : 0;
-            const int j = w - k * p.cpr;
-            const u32 mk = bperm(m, k);
-            const int len = (int)(mk & 0xFFFFu);
-            const int rg = (int)((mk >> 16) & 0x7FFFu);
-            const bool second = (mk >> 31) != 0u;
-            const int pos0 = 16 * j;
-            const int nb = act0 ? (len - pos0) : 0;
+            ch.act0 = w < total;
+            ch.k = ch.act0 ? (p.cpr == 1 ? w : (int)__umulhi((u32)w, p.cpr_magic)) : 0;
+            ch.j = w - ch.k * p.cpr;
+            ch.mk = bperm(m, ch.k);
+            ch.nb = ch.act0 ? ((int)(ch.mk & 0xFFFFu) - 16 * ch.j) : 0;
+#ifndef KBBQ_ABL_NOLOAD
+            const u32 rowoff = ch.nb > 0 ? (u32)ch.k * (u32)p.pitch + (u32)(16 * ch.j) : 0u;
+#else
+            const u32 rowoff = (u32)lane * 16u;
+#endif
+            const uint4 sv = *reinterpret_cast<const uint4*>(bseq + rowoff);
+            const uint4 qv = *reinterpret_cast<const uint4*>(bqual + rowoff);
+            ch.s[0] = sv.x; ch.s[1] = sv.y; ch.s[2] = sv.z; ch.s[3] = sv.w;
+            ch.q[0] = qv.x; ch.q[1] = qv.y; ch.q[2] = qv.z; ch.q[3] = qv.w;
+        };
+        auto process = [&](const K2Chunk& ch) {
+            const int j = ch.j, nb = ch.nb, k = ch.k;
             const bool act = nb > 0;
-            const u32 rowoff = (u32)k * (u32)p.pitch + (u32)pos0;
-            u32 s[4] = {0u, 0u, 0u, 0u}, q[4] = {0u, 0u, 0u, 0u};
-            if (act) {
-                const uint4 sv = *reinterpret_cast<const uint4*>(bseq + rowoff);
-                const uint4 qv = *reinterpret_cast<const uint4*>(bqual + rowoff);
-                s[0] = sv.x; s[1] = sv.y; s[2] = sv.z; s[3] = sv.w;
-                q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
-            }
+            const int len = (int)(ch.mk & 0xFFFFu);
+            const int rg = (int)((ch.mk >> 16) & 0x7FFFu);
+            const bool second = (ch.mk >> 31) != 0u;
+            const int pos0 = 16 * j;
             u32 code[4], badbits = 0u, hiq = 0u;
 #pragma unroll
             for (int wd = 0; wd < 4; ++wd) {
-                const u32 h = (s[wd] >> 1) & 0x07070707u;
+                const u32 h = (ch.s[wd] >> 1) & 0x07070707u;
                 const u32 expect = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, h);
                 code[wd] = __builtin_amdgcn_perm(0x04040404u, 0x02010300u, h);
-                badbits |= expect ^ s[wd];
-                hiq |= ((q[wd] & 0x7F7F7F7Fu) + hi_add) | q[wd];
+                badbits |= expect ^ ch.s[wd];
+                hiq |= ((ch.q[wd] & 0x7F7F7F7Fu) + hi_add) | ch.q[wd];
             }
             hiq &= 0x80808080u;
             const u32 last_code = code[3] >> 24;
-            const u32 last_char = s[3] >> 24;
+            const u32 last_char = ch.s[3] >> 24;
             u32 prev_code = wave_shr1(last_code, carry_code);
             u32 prev_char = wave_shr1(last_char, carry_char);
             carry_code = (u32)__builtin_amdgcn_readlane((int)last_code, 63);
             carry_char = (u32)__builtin_amdgcn_readlane((int)last_char, 63);
             if (j == 0) { prev_code = 4u; prev_char = 0u; }
-            if (act0) {
+            if (ch.act0) {
                 u32 o[4] = {0u, 0u, 0u, 0u};
                 if (act) {
                     const long long read = read0 + k;
-                    if (badbits && chunk_type_error(s[0], s[1], s[2], s[3], q[0], q[1], q[2], q[3],
+                    if (badbits && chunk_type_error(ch.s[0], ch.s[1], ch.s[2], ch.s[3], ch.q[0], ch.q[1], ch.q[2], ch.q[3],
                                                     prev_char, nb, pos0, p.minscore))
                         flag(p.status, ST_TYPE, read);
                     u32 d5[4];
@@ -320,7 +373,7 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
                     const bool trouble = hiq != 0u || rg >= p.R || len > p.S2;
                     if (trouble) {
                         const uint4 e = chunk_apply_exact(p.lut16, p.rs16, p.R, p.Qt, p.S2, p.qlo, rg, second, pos0, nb,
-                                                          q[0], q[1], q[2], q[3], d5[0], d5[1], d5[2], d5[3],
+                                                          ch.q[0], ch.q[1], ch.q[2], ch.q[3], d5[0], d5[1], d5[2], d5[3],
                                                           p.status, read);
                         o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = e.w;
                     } else {
@@ -332,17 +385,34 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
                         for (int wd = 0; wd < 4; ++wd) {
 #pragma unroll
                             for (int b = 0; b < 4; ++b) {
-                                const u32 qb = (q[wd] >> (8 * b)) & 0xFFu;
+                                const u32 qb = (ch.q[wd] >> (8 * b)) & 0xFFu;
                                 const u32 rowq = __umul24(qb, rb);
                                 const u32 dd = (d5[wd] >> (8 * b)) & 0xFFu;
+#ifndef KBBQ_ABL_NOLUT
                                 const int v1 = *reinterpret_cast<const int8_t*>(reinterpret_cast<const char*>(lds) + (rowq + A + (u32)(4 * wd + b)));
                                 const int v2 = *reinterpret_cast<const int8_t*>(reinterpret_cast<const char*>(lds) + (rowq + C + dd));
+#else
+                                const int v1 = (int)(rowq + A), v2 = (int)(C + dd);
+#endif
                                 o[wd] |= ((u32)(v1 + v2 + 33) & 0xFFu) << (8 * b);
                             }
                         }
                     }
                 }
-                *reinterpret_cast<uint4*>(bout + rowoff) = make_uint4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<uint4*>(bout + ((u32)k * (u32)p.pitch + (u32)pos0)) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        };
+
+        if (total > 0) {
+            K2Chunk ca, cb;
+            fetch(0, ca);
+            for (int w0 = 0; w0 < total; w0 += 128) {
+                fetch(w0 + 64, cb);
+                process(ca);
+                if (w0 + 64 < total) {
+                    fetch(w0 + 128, ca);
+                    process(cb);
+                }
             }
         }
     }

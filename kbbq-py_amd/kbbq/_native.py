@@ -10,7 +10,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libkbbq_hip.so')
+# KBBQ_HIP_LIB selects another build of the same ABI (timing-only ablation builds, scripts/)
+LIB_PATH = os.environ.get('KBBQ_HIP_LIB') or os.path.join(HERE, 'libkbbq_hip.so')
 
 KBBQ_OK = 0
 KBBQ_E_HIP = -1
