@@ -39,6 +39,16 @@ struct K1v3Params {
     u64* tables; u64* status;
 };
 
+// nucleotide decode of 4 bases: code (A0 T1 G2 C3, N/other 4), 5*code, and the character each
+// code stands for (alphabet check), all by v_perm_b32 with the data as selector
+__device__ __forceinline__ void decode4x(u32 w, u32& code, u32& code5, u32& expect)
+{
+    const u32 h = (w >> 1) & 0x07070707u;                                // A->0 C->1 T->2 G->3 N->7
+    code   = __builtin_amdgcn_perm(0x04040404u, 0x02010300u, h);
+    code5  = __builtin_amdgcn_perm(0x14141414u, 0x0A050F00u, h);         // 5 * code: A0 C15 T5 G10, N/other 20
+    expect = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, h);
+}
+
 struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int j; int nb; };
 
 // LDS: dnt[nrows][32][16] u32 context totals, 16 copies (copy = lane & 15: the table is tiny and
@@ -136,7 +146,7 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
             const uint8_t* bcseq = p.cseq + (size_t)read0 * p.pitch;
             const uint8_t* bqual = p.qual + (size_t)read0 * p.pitch;
             const int total = n * p.cpr;
-            u32 carry_code = 4u, carry_char = 0u;
+            u32 carry_code = 20u, carry_char = 0u;      // 5 * code of the previous chunk's last base
 
             // fetch: issue the three 16-byte loads of one step (no wait); process: bin them.
             // The loop below keeps one step in flight while the previous one is binned.
@@ -170,23 +180,22 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                 // byte-parallel decode; alphabet and q-range screening (no byte masks: bytes past
                 // the read are 'N' in seq/cseq and 0 in qual by the layout contract; anything else
                 // only costs a visit to the exact checker)
-                u32 code[4], badbits = 0u, hiq = 0u;
+                u32 code[4], code5[4], badbits = 0u, hiq = 0u;
 #pragma unroll
                 for (int wd = 0; wd < 4; ++wd) {
-                    const u32 h = (ch.s[wd] >> 1) & 0x07070707u;
-                    const u32 expect = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, h);
-                    code[wd] = __builtin_amdgcn_perm(0x04040404u, 0x02010300u, h);   // A0 T1 G2 C3, N/other 4
+                    u32 expect;
+                    decode4x(ch.s[wd], code[wd], code5[wd], expect);
                     badbits |= expect ^ ch.s[wd];
                     hiq |= (ch.q[wd] + 0x34343434u) | ch.q[wd];                      // bit 7 of a byte: q > 42
                 }
                 hiq &= 0x80808080u;
-                const u32 last_code = code[3] >> 24;
+                const u32 last_code5 = code5[3] >> 24;
                 const u32 last_char = ch.s[3] >> 24;
-                u32 prev_code = wave_shr1(last_code, carry_code);
+                u32 prev_code5 = wave_shr1(last_code5, carry_code);
                 u32 prev_char = wave_shr1(last_char, carry_char);
-                carry_code = (u32)__builtin_amdgcn_readlane((int)last_code, 63);
+                carry_code = (u32)__builtin_amdgcn_readlane((int)last_code5, 63);
                 carry_char = (u32)__builtin_amdgcn_readlane((int)last_char, 63);
-                if (j == 0) { prev_code = 4u; prev_char = 0u; }                      // dinuc[0] = -1
+                if (j == 0) { prev_code5 = 20u; prev_char = 0u; }                    // dinuc[0] = -1
                 if (act) {
                     const long long read = read0 + ch.off;
                     if (hiq || len > S) flag(p.status, ST_INDEX, read);              // recalibrate.py:114-115; read longer than the tables
@@ -197,12 +206,12 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                         // A: pos address less the row term; both mates ascend with the base index
                         const u32 half = second ? (u32)(S + 2 * (S - len)) : 0u;     // column 2*len-1-pos
                         const u32 A = pos_base + (half + (u32)pos0) * 4u;
-                        u32 pc = prev_code << 24;
+                        u32 pc5 = prev_code5 << 24;
 #pragma unroll
                         for (int wd = 0; wd < 4; ++wd) {
-                            const u32 pw = __builtin_amdgcn_alignbyte(code[wd], pc, 3);
-                            const u32 d5 = (pw << 2) + pw + code[wd];                // 5*prev + cur per byte, <= 24
-                            pc = code[wd];
+                            const u32 pw5 = __builtin_amdgcn_alignbyte(code5[wd], pc5, 3);
+                            const u32 d5 = pw5 + code[wd];                            // 5*prev + cur per byte, <= 24
+                            pc5 = code5[wd];
                             const u32 xw = ch.s[wd] ^ ch.c[wd];
                             const u32 qn = ~ch.q[wd];
 #pragma unroll
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
 #endif
                                 u32 slot = (d5 >> (8 * b)) & 0xFFu;
                                 if (SPLIT) slot = qi <= 255u - p.dlo ? slot : 24u;             // context needs q >= its own threshold
-                                const u32 ad = tq * dnt_row + slot * (4u * K1V3_DNREP) + dnt_base;
+                                const u32 ad = slot * (4u * K1V3_DNREP) + tq * dnt_row + dnt_base;     // constant powers of two: shifts
 #ifndef KBBQ_ABL_NODN
                                 atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + ad), 1u);   // recalibrate.py:119
                                 if (err) atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + ((tq << 7) + (slot << 2) + dne_base)), 1u);   // :118
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
         const uint8_t* bseq = p.seq + (size_t)read0 * p.pitch;
         const uint8_t* bqual = p.qual + (size_t)read0 * p.pitch;
         uint8_t* bout = p.out + (size_t)read0 * p.pitch;
-        u32 carry_code = 4u, carry_char = 0u;
+        u32 carry_code = 20u, carry_char = 0u;
 
         auto fetch = [&](int w0, K2Chunk& ch) {
             const int w = w0 + lane;
@@ -338,23 +347,22 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
             const int rg = (int)((ch.mk >> 16) & 0x7FFFu);
             const bool second = (ch.mk >> 31) != 0u;
             const int pos0 = 16 * j;
-            u32 code[4], badbits = 0u, hiq = 0u;
+            u32 code[4], code5[4], badbits = 0u, hiq = 0u;
 #pragma unroll
             for (int wd = 0; wd < 4; ++wd) {
-                const u32 h = (ch.s[wd] >> 1) & 0x07070707u;
-                const u32 expect = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, h);
-                code[wd] = __builtin_amdgcn_perm(0x04040404u, 0x02010300u, h);
+                u32 expect;
+                decode4x(ch.s[wd], code[wd], code5[wd], expect);
                 badbits |= expect ^ ch.s[wd];
                 hiq |= ((ch.q[wd] & 0x7F7F7F7Fu) + hi_add) | ch.q[wd];
             }
             hiq &= 0x80808080u;
-            const u32 last_code = code[3] >> 24;
+            const u32 last_code5 = code5[3] >> 24;
             const u32 last_char = ch.s[3] >> 24;
-            u32 prev_code = wave_shr1(last_code, carry_code);
+            u32 prev_code5 = wave_shr1(last_code5, carry_code);
             u32 prev_char = wave_shr1(last_char, carry_char);
-            carry_code = (u32)__builtin_amdgcn_readlane((int)last_code, 63);
+            carry_code = (u32)__builtin_amdgcn_readlane((int)last_code5, 63);
             carry_char = (u32)__builtin_amdgcn_readlane((int)last_char, 63);
-            if (j == 0) { prev_code = 4u; prev_char = 0u; }
+            if (j == 0) { prev_code5 = 20u; prev_char = 0u; }
             if (ch.act0) {
                 u32 o[4] = {0u, 0u, 0u, 0u};
                 if (act) {
@@ -363,12 +371,11 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
                                                     prev_char, nb, pos0, p.minscore))
                         flag(p.status, ST_TYPE, read);
                     u32 d5[4];
-                    u32 pc = prev_code << 24;
+                    u32 pc5 = prev_code5 << 24;
 #pragma unroll
                     for (int wd = 0; wd < 4; ++wd) {
-                        const u32 pw = __builtin_amdgcn_alignbyte(code[wd], pc, 3);
-                        d5[wd] = (pw << 2) + pw + code[wd];
-                        pc = code[wd];
+                        d5[wd] = __builtin_amdgcn_alignbyte(code5[wd], pc5, 3) + code[wd];   // 5*prev + cur per byte
+                        pc5 = code5[wd];
                     }
                     const bool trouble = hiq != 0u || rg >= p.R || len > p.S2;
                     if (trouble) {
@@ -383,19 +390,23 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
                         const u32 C = rgb + 2u * W;
 #pragma unroll
                         for (int wd = 0; wd < 4; ++wd) {
+                            // issue the word's eight LDS reads before combining any of them
+                            int v1[4], v2[4];
 #pragma unroll
                             for (int b = 0; b < 4; ++b) {
                                 const u32 qb = (ch.q[wd] >> (8 * b)) & 0xFFu;
                                 const u32 rowq = __umul24(qb, rb);
                                 const u32 dd = (d5[wd] >> (8 * b)) & 0xFFu;
 #ifndef KBBQ_ABL_NOLUT
-                                const int v1 = *reinterpret_cast<const int8_t*>(reinterpret_cast<const char*>(lds) + (rowq + A + (u32)(4 * wd + b)));
-                                const int v2 = *reinterpret_cast<const int8_t*>(reinterpret_cast<const char*>(lds) + (rowq + C + dd));
+                                v1[b] = *reinterpret_cast<const int8_t*>(reinterpret_cast<const char*>(lds) + (rowq + A + (u32)(4 * wd + b)));
+                                v2[b] = *reinterpret_cast<const int8_t*>(reinterpret_cast<const char*>(lds) + (rowq + C + dd));
 #else
-                                const int v1 = (int)(rowq + A), v2 = (int)(C + dd);
+                                v1[b] = (int)(rowq + A); v2[b] = (int)(C + dd);
 #endif
-                                o[wd] |= ((u32)(v1 + v2 + 33) & 0xFFu) << (8 * b);
                             }
+                            // FAST mode is only legal for range-safe LUTs (flags == 0): every sum is 0..255
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) o[wd] |= (u32)(v1[b] + v2[b] + 33) << (8 * b);
                         }
                     }
                 }
