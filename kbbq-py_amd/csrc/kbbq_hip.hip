@@ -91,8 +91,8 @@ int kbbq_ctx_create(int device, kbbq_ctx** out)
     (void)hipFuncSetAttribute((const void*)k1v3_accumulate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k1v3_accumulate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2v3_apply, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)k2_apply<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)k2_apply<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)k2_apply<int16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)k2_apply<int8_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipGetLastError();
     *out = c;
     return KBBQ_OK;
@@ -211,7 +211,9 @@ int kbbq_lut_row_stride(int S2) { return lut_row_stride(S2); }
 static size_t align16(size_t n) { return (n + 15) & ~(size_t)15; }
 static size_t lut_full_offset(int R, int Qt, int S2) { return align16((size_t)R * Qt * lut_row_stride(S2) * 2); }
 size_t kbbq_full_lut_bytes(int R, int Qt, int S2) { return (size_t)R * (33 + Qt) * (size_t)full_lut_row_bytes(S2); }
-static size_t lut_flags_offset(int R, int Qt, int S2) { return lut_full_offset(R, Qt, S2) + align16(kbbq_full_lut_bytes(R, Qt, S2)); }
+static size_t lut_compact8_offset(int R, int Qt, int S2) { return lut_full_offset(R, Qt, S2) + align16(kbbq_full_lut_bytes(R, Qt, S2)); }
+static size_t lut_compact8_bytes(int R, int Qt, int S2) { return (size_t)R * Qt * lut_row_stride(S2); }
+static size_t lut_flags_offset(int R, int Qt, int S2) { return lut_compact8_offset(R, Qt, S2) + align16(lut_compact8_bytes(R, Qt, S2)); }
 size_t kbbq_lut_bytes(int R, int Qt, int S2) { return lut_flags_offset(R, Qt, S2) + 16; }
 
 size_t kbbq_lut_count(int R, int Qt, int S2)
@@ -351,7 +353,8 @@ int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_c
 }
 
 // host twin of k3_fill_full_lut (same rules; the GPU test compares the two blobs byte for byte)
-static int fill_full_lut_host(const int16_t* lut16, int rs16, int R, int Qt, int S2, int minscore, int8_t* full)
+static int fill_full_lut_host(const int16_t* lut16, int rs16, int R, int Qt, int S2, int minscore, int8_t* full,
+                              int8_t* compact8)
 {
     const int rb = full_lut_row_bytes(S2);
     const int NR = 33 + Qt;
@@ -373,6 +376,10 @@ static int fill_full_lut_host(const int16_t* lut16, int rs16, int R, int Qt, int
                 row[x] = (int8_t)v;
             }
         }
+    for (size_t i = 0; i < (size_t)R * Qt * rs16; ++i) {
+        if (lut16[i] < -128 || lut16[i] > 127) bad |= 1;
+        compact8[i] = (int8_t)lut16[i];
+    }
     for (int r = 0; r < R; ++r)
         for (int q = minscore; q < Qt; ++q) {
             const int16_t* src = lut16 + ((size_t)r * Qt + q) * rs16;
@@ -415,7 +422,8 @@ int kbbq_build_lut(int R, int Qt, int S2, int D, int minscore, const int64_t* me
                 }
         }
     int8_t* full = reinterpret_cast<int8_t*>(blob) + lut_full_offset(R, Qt, S2);
-    const int flags = fill_full_lut_host(out, rs, R, Qt, S2, std::min(minscore, Qt), full);
+    int8_t* compact8 = reinterpret_cast<int8_t*>(blob) + lut_compact8_offset(R, Qt, S2);
+    const int flags = fill_full_lut_host(out, rs, R, Qt, S2, std::min(minscore, Qt), full, compact8);
     *reinterpret_cast<int*>(reinterpret_cast<char*>(blob) + lut_flags_offset(R, Qt, S2)) = flags;
     if (flags_out) *flags_out = flags;
     return KBBQ_OK;
@@ -465,21 +473,30 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
     p.R = R; p.Qt = Qt; p.S2 = S2; p.minscore = minscore; p.qlo = 33u + (u32)minscore;
     p.lut = reinterpret_cast<const int16_t*>(d_lut); p.lut_count = (int)kbbq_lut_count(R, Qt, S2);
     p.out = d_out; p.status = c->d_status;
-    const size_t lut_bytes = (size_t)p.lut_count * 2;
-    // stage the LUT in LDS when at least 2 workgroups per CU still fit
-    const bool in_lds = lut_bytes <= (size_t)c->lds_bytes / 2;
+    // FAST (flags == 0): every value fits int8 -> stage the one-byte copy; CHECKED: the int16 LUT.
+    // Too big for LDS either way: per-base exact path from global memory.
+    const bool fast = mode == KBBQ_APPLY_FAST;
+    const size_t stage_bytes = fast ? lut_compact8_bytes(R, Qt, S2) : (size_t)p.lut_count * 2;
+    const bool in_lds = stage_bytes + 16 <= (size_t)c->lds_bytes;
     p.lut_in_lds = in_lds ? 1 : 0;
-    const size_t lds = in_lds ? lut_bytes : 0;
-    int per_cu = in_lds ? std::min<int>((int)(c->lds_bytes / std::max<size_t>(lds, 1)), 2048 / K2_THREADS) : 2048 / K2_THREADS;
-    per_cu = std::max(per_cu, 1);
-    const int64_t want = (nblocks + (K2_THREADS / 64) - 1) / (K2_THREADS / 64);
+    p.stage = fast ? (const void*)(reinterpret_cast<const char*>(d_lut) + lut_compact8_offset(R, Qt, S2)) : d_lut;
+    p.stage_bytes = (int)stage_bytes;
+    const size_t lds = in_lds ? ((stage_bytes + 15) & ~(size_t)15) : 0;
+    // 256-thread workgroups while >= 4 of them fit a CU, else 1024-thread ones (same waves per CU)
+    int threads = 256, per_cu = 8;
+    if (in_lds) {
+        per_cu = (int)(c->lds_bytes / lds);
+        if (per_cu < 4) { threads = 1024; per_cu = std::min(per_cu, 2); }
+        per_cu = std::max(1, std::min(per_cu, 2048 / threads));
+    }
+    const int64_t want = (nblocks + (threads / 64) - 1) / (threads / 64);
     int gx = (int)std::min<int64_t>(want, (int64_t)c->cus * per_cu);
-    dim3 grid((unsigned)std::max(gx, 1), 1, 1), block(K2_THREADS, 1, 1);
+    dim3 grid((unsigned)std::max(gx, 1), 1, 1), block((unsigned)threads, 1, 1);
     {
         Timed t(c, 1);
-        if (!in_lds) hipLaunchKernelGGL((k2_apply<false, true>), grid, block, 0, c->stream, p);
-        else if (mode == KBBQ_APPLY_FAST) hipLaunchKernelGGL((k2_apply<true, false>), grid, block, lds, c->stream, p);
-        else hipLaunchKernelGGL((k2_apply<true, true>), grid, block, lds, c->stream, p);
+        if (!in_lds) hipLaunchKernelGGL((k2_apply<int16_t, false, true>), grid, block, 0, c->stream, p);
+        else if (fast) hipLaunchKernelGGL((k2_apply<int8_t, true, false>), grid, block, lds, c->stream, p);
+        else hipLaunchKernelGGL((k2_apply<int16_t, true, true>), grid, block, lds, c->stream, p);
     }
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
@@ -560,6 +577,7 @@ int kbbq_solve_dev(kbbq_ctx* c, const int64_t* d_tables, int R, int S2, int mins
     LutFillParams f;
     f.lut16 = p.lut; f.rs16 = p.rs; f.R = R; f.Qt = KQ; f.S2 = S2; f.minscore = std::min(std::max(minscore, 0), KQ);
     f.full = reinterpret_cast<int8_t*>(d_lut) + lut_full_offset(R, KQ, S2);
+    f.compact8 = reinterpret_cast<int8_t*>(d_lut) + lut_compact8_offset(R, KQ, S2);
     f.flags = reinterpret_cast<int*>(reinterpret_cast<char*>(d_lut) + lut_flags_offset(R, KQ, S2));
     f.status = c->d_status;
     HIPCHK(hipMemsetAsync(f.flags, 0, 16, c->stream));

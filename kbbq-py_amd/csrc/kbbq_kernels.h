@@ -17,7 +17,7 @@
 #define KQ      43          // maxscore + 1 (recalibrate.py:36)
 #define KND     16          // dinucleotides
 #define K1_THREADS 512
-#define K2_THREADS 256
+#define K2_THREADS 1024     // launch bound; launched with 256 or 1024 threads depending on the LUT's LDS footprint
 #define K1_FLUSH_ITERS 96   // WG iterations between LDS flushes: 96 * 8 waves * 64 reads
                             // = 49,152 reads < 65,535 (16-bit packed LDS counters)
 
@@ -44,6 +44,7 @@ struct K2Params {
     long long nreads; int pitch; int cpr; u32 cpr_magic; int R; int Qt; int S2; int minscore;
     u32 qlo;
     const int16_t* lut; int lut_in_lds; int lut_count;
+    const void* stage; int stage_bytes;    // what the LDS variant stages: the int16 LUT or its int8 copy
     uint8_t* out; u64* status;
 };
 
@@ -330,13 +331,15 @@ __device__ __noinline__ uint4 chunk_apply_exact(const int16_t* lut, int rs, int 
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-template <bool LDS_LUT, bool CHECK_RANGE>
+// ELEM: element type of the staged LUT (int16_t canonical, or int8_t copy when every value fits:
+// half the LDS, which is what lets 8 read groups of 2x150 tables stay on chip).
+template <typename ELEM, bool LDS_LUT, bool CHECK_RANGE>
 __global__ __launch_bounds__(K2_THREADS) void k2_apply(K2Params p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     if (LDS_LUT) {
-        const u32* src = reinterpret_cast<const u32*>(p.lut);
-        const int nw = p.lut_count >> 1;
+        const u32* src = reinterpret_cast<const u32*>(p.stage);
+        const int nw = (p.stage_bytes + 3) >> 2;
         for (int i = threadIdx.x; i < nw; i += blockDim.x) lds[i] = src[i];
         __syncthreads();
     }
@@ -346,7 +349,8 @@ __global__ __launch_bounds__(K2_THREADS) void k2_apply(K2Params p)
     const long long nblocks = (p.nreads + 63) >> 6;
     const u32 qlo = p.qlo;
     const int rs = lut_row_stride(p.S2);
-    const u32 rs2 = (u32)rs * 2u;                               // row stride in bytes
+    const u32 E = (u32)sizeof(ELEM);
+    const u32 rs2 = (u32)rs * E;                                // row stride in bytes
     const u32 hi_add = (u32)(0x80 - (p.Qt + 33)) * 0x01010101u; // byte >= Qt+33  <=>  bit 7 of byte + hi_add
 
     for (long long blk = (long long)blockIdx.x * nwaves + wave; blk < nblocks;
@@ -418,9 +422,9 @@ __global__ __launch_bounds__(K2_THREADS) void k2_apply(K2Params p)
                     } else {
                         // fast path: every index is in range; bytes beyond the read are 0 (< qlo) and pass through
                         const u32 rowbase = (u32)rg * (u32)p.Qt * rs2 - 33u * rs2;
-                        u32 colb = rowbase + (u32)(second ? (p.S2 - 1 - pos0) : pos0) * 2u;
-                        const u32 dcol = second ? (u32)-2 : 2u;
-                        const u32 dnb = rowbase + (u32)p.S2 * 2u;
+                        u32 colb = rowbase + (u32)(second ? (p.S2 - 1 - pos0) : pos0) * E;
+                        const u32 dcol = second ? 0u - E : E;
+                        const u32 dnb = rowbase + (u32)p.S2 * E;
                         bool range_err = false;
 #pragma unroll
                         for (int wd = 0; wd < 4; ++wd) {
@@ -430,8 +434,8 @@ __global__ __launch_bounds__(K2_THREADS) void k2_apply(K2Params p)
                                 const u32 qc = qb > 33u ? qb : 33u;               // keep the address inside the LUT
                                 const u32 rowq = __umul24(qc, rs2);
                                 const u32 dd = (d5[wd] >> (8 * b)) & 0xFFu;
-                                const int v1 = *reinterpret_cast<const int16_t*>(reinterpret_cast<const char*>(lds) + (rowq + colb));
-                                const int v2 = *reinterpret_cast<const int16_t*>(reinterpret_cast<const char*>(lds) + (rowq + dnb + dd * 2u));
+                                const int v1 = *reinterpret_cast<const ELEM*>(reinterpret_cast<const char*>(lds) + (rowq + colb));
+                                const int v2 = *reinterpret_cast<const ELEM*>(reinterpret_cast<const char*>(lds) + (rowq + dnb + dd * E));
                                 const int v = v1 + v2 + 33;
                                 const bool counted = qb >= qlo;
                                 if (CHECK_RANGE) range_err |= counted && (u32)v > 255u;

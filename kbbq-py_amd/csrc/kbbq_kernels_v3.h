@@ -434,7 +434,7 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
 // combination of a row could leave 0..255 (then the checked kernel must be used).
 struct LutFillParams {
     const int16_t* lut16; int rs16; int R; int Qt; int S2; int minscore;
-    int8_t* full; int* flags; u64* status;
+    int8_t* full; int8_t* compact8; int* flags; u64* status;
 };
 
 __global__ __launch_bounds__(256) void k3_fill_full_lut(LutFillParams p)
@@ -461,6 +461,14 @@ __global__ __launch_bounds__(256) void k3_fill_full_lut(LutFillParams p)
         }
         if (v < -128 || v > 127) bad |= 1;
         p.full[i] = (int8_t)v;
+    }
+    // int8 copy of the canonical LUT (same row stride, one byte per entry)
+    const long long n16 = (long long)p.R * p.Qt * p.rs16;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int v = p.lut16[i];
+        if (v < -128 || v > 127) bad |= 1;
+        p.compact8[i] = (int8_t)v;
     }
     // range safety per model row: min/max over cycles + min/max over contexts
     const long long rows = (long long)p.R * p.Qt;
