@@ -313,7 +313,8 @@ int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_c
         q.row_bytes = (u32)((3 * S) | 1) * 4u;
         q.slack_bytes = (u32)(S + 32) * 4u;              // x <= 4S + 12 for the padding of the shortest read
         q.tables = reinterpret_cast<u64*>(d_tables); q.status = c->d_status;
-        const size_t lds3 = (size_t)q.nrows * 128 * (K1V3_DNREP + 1) + (size_t)q.nrows * q.row_bytes + q.slack_bytes;
+        q.dn_flush_iters = std::max(1, 65535 / ((K1V3_THREADS / K1V3_DNREP) * 16 * q.cpr));
+        const size_t lds3 = (size_t)q.nrows * 128 * K1V3_DNREP + (size_t)q.nrows * q.row_bytes + q.slack_bytes;
         if (lds3 <= (size_t)c->lds_bytes && !(force && !strcmp(force, "v1"))) {
             int per_cu = std::max(1, std::min<int>((int)(c->lds_bytes / lds3), 2048 / K1V3_THREADS));
             const int64_t iters = (nblocks + (K1V3_THREADS / 64) - 1) / (K1V3_THREADS / 64);

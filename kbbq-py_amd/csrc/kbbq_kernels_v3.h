@@ -36,6 +36,7 @@ struct K1v3Params {
     int nrows;                  // 44 - minscore: one row per counted quality (row = 42 - q) + the trash row LAST
     u32 row_bytes;              // pos row stride in bytes ((3S | 1) words)
     u32 slack_bytes;            // after the last (trash) row: padding bytes of short reads index past its end
+    int dn_flush_iters;         // workgroup iterations between flushes of the (16-bit packed) context table
     u64* tables; u64* status;
 };
 
@@ -51,10 +52,12 @@ __device__ __forceinline__ void decode4x(u32 w, u32& code, u32& code5, u32& expe
 
 struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int j; int nb; };
 
-// LDS: dnt[nrows][32][16] u32 context totals, 16 copies (copy = lane & 15: the table is tiny and
-//          hot -- measured 15 LDS cycles per wave-atomic unreplicated -- copies cut the bank and
-//          same-address collisions), dne[nrows][32] u32 context errors (errors are ~3 % of the
-//          bases: added only by the lanes that have one), slot = 5*code(prev)+code(cur)
+// LDS: dn [nrows][32][16] u32 context counts (errs << 16 | total), 16 copies (copy = lane & 15:
+//          the table is tiny and hot -- measured 15 LDS cycles per wave-atomic unreplicated --
+//          copies cut the bank and same-address collisions), slot = 5*code(prev)+code(cur).
+//          16-bit halves: a copy can receive 64 lanes x 16*cpr bases per workgroup iteration in
+//          the worst case (every base the same bin), so this table alone is flushed every
+//          dn_flush_iters = 65535 / (1024 * cpr) iterations (6 for 2x150): ~1 % of the time.
 //      pos[nrows][row_bytes/4] u32 (errs << 16 | total): [0,S) first-in-pair cycle = position;
 //          [S, 3S) second-in-pair, index x = position + 2*(S - len)  <->  column 2S-1-x
 //      rows are ordered by the INVERTED quality byte (row = 42 - q, one v_min clamps every
@@ -64,10 +67,9 @@ template <bool SPLIT>
 __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
-    const int dn_words = p.nrows * 32 * (K1V3_DNREP + 1);   // replicated totals + one errors table
+    const int dn_words = p.nrows * 32 * K1V3_DNREP;
     const int pos_words = p.nrows * (int)(p.row_bytes >> 2) + (int)(p.slack_bytes >> 2);
     u32* dnt = lds;
-    u32* dne = lds + p.nrows * 32 * K1V3_DNREP;
     u32* pos = lds + dn_words;
     for (int i = threadIdx.x; i < dn_words + pos_words; i += blockDim.x) lds[i] = 0u;
     __syncthreads();
@@ -84,16 +86,36 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
     const u32 pos_base = (u32)dn_words * 4u - 180u * row_bytes;        // 180 = 255 - 'K': inverted byte of q = 42 is row 0
     const u32 dnt_row = 128u * K1V3_DNREP;                             // bytes per row of the replicated totals
     const u32 dnt_base = 0u - 180u * dnt_row + 4u * (u32)(lane_id() & (K1V3_DNREP - 1));
-    const u32 dne_base = (u32)p.nrows * dnt_row - 180u * 128u;         // errors table: rows of 32 u32, after the totals
-    int since_flush = 0;
+    int since_flush = 0, since_dn_flush = 0;
 
     u64* pos_errs = p.tables;
     u64* pos_total = p.tables + (size_t)p.R * KQ * S2;
     u64* dn_errs = p.tables + 2 * (size_t)p.R * KQ * S2;
     u64* dn_total = dn_errs + (size_t)p.R * KQ * KND;
 
-    auto flush = [&]() {
+    auto flush_dn = [&]() {
         for (int r = wave; r < p.nrows - 1; r += nwaves) {           // the last row is trash
+            const int q = KQ - 1 - r;
+            if (lane < 25) {
+                const int a = lane / 5, b = lane - 5 * a;
+                if (a < 4 && b < 4) {
+                    u32 vt = 0u, ve = 0u;
+                    for (int cpy = 0; cpy < K1V3_DNREP; ++cpy) {
+                        const u32 v = dnt[(r * 32 + lane) * K1V3_DNREP + cpy];
+                        dnt[(r * 32 + lane) * K1V3_DNREP + cpy] = 0u;
+                        vt += v & 0xFFFFu; ve += v >> 16;
+                    }
+                    if (vt) {
+                        const size_t e = ((size_t)g * KQ + q) * KND + 4 * a + b;
+                        atomicAdd(&dn_total[e], (u64)vt);
+                        if (ve) atomicAdd(&dn_errs[e], (u64)ve);
+                    }
+                }
+            }
+        }
+    };
+    auto flush_pos = [&]() {
+        for (int r = wave; r < p.nrows - 1; r += nwaves) {
             const int q = KQ - 1 - r;
             const size_t grow = ((size_t)g * KQ + q) * S2;
             u32* prow = pos + (size_t)r * (row_bytes >> 2);
@@ -104,23 +126,6 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                     const int col = x < S ? x : (S2 - 1 - (x - S));
                     atomicAdd(&pos_total[grow + col], (u64)(v & 0xFFFFu));
                     if (v >> 16) atomicAdd(&pos_errs[grow + col], (u64)(v >> 16));
-                }
-            }
-            if (lane < 25) {
-                const int a = lane / 5, b = lane - 5 * a;
-                if (a < 4 && b < 4) {
-                    u32 vt = 0u;
-                    for (int cpy = 0; cpy < K1V3_DNREP; ++cpy) {
-                        vt += dnt[(r * 32 + lane) * K1V3_DNREP + cpy];
-                        dnt[(r * 32 + lane) * K1V3_DNREP + cpy] = 0u;
-                    }
-                    const u32 ve = dne[r * 32 + lane];
-                    if (vt) {
-                        dne[r * 32 + lane] = 0u;
-                        const size_t e = ((size_t)g * KQ + q) * KND + 4 * a + b;
-                        atomicAdd(&dn_total[e], (u64)vt);
-                        if (ve) atomicAdd(&dn_errs[e], (u64)ve);
-                    }
                 }
             }
         }
@@ -219,21 +224,20 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                                 const u32 qi = (qn >> (8 * b)) & 0xFFu;                 // 255 - quality byte
                                 const u32 tq = qi < tclamp ? qi : tclamp;              // below minscore (and padding): trash row
                                 const bool err = ((xw >> (8 * b)) & 0xFFu) != 0u;      // recalibrate.py:13-20
+                                const u32 inc = err ? 0x10001u : 1u;                   // errs << 16 | total, both tables
                                 const u32 a = __umul24(tq, row_bytes) + A + (u32)(4 * (4 * wd + b));
 #ifndef KBBQ_ABL_NOPOS
-                                atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + a),
-                                          err ? 0x10001u : 1u);                       // recalibrate.py:116-117
+                                atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + a), inc);   // recalibrate.py:116-117
 #else
-                                asm volatile("" :: "v"(a), "v"(err ? 0x10001u : 1u));
+                                asm volatile("" :: "v"(a), "v"(inc));
 #endif
                                 u32 slot = (d5 >> (8 * b)) & 0xFFu;
                                 if (SPLIT) slot = qi <= 255u - p.dlo ? slot : 24u;             // context needs q >= its own threshold
                                 const u32 ad = slot * (4u * K1V3_DNREP) + tq * dnt_row + dnt_base;     // constant powers of two: shifts
 #ifndef KBBQ_ABL_NODN
-                                atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + ad), 1u);   // recalibrate.py:119
-                                if (err) atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + ((tq << 7) + (slot << 2) + dne_base)), 1u);   // :118
+                                atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + ad), inc); // recalibrate.py:118-119
 #else
-                                asm volatile("" :: "v"(ad), "v"(err ? 1u : 0u));
+                                asm volatile("" :: "v"(ad), "v"(inc));
 #endif
                             }
                         }
@@ -257,13 +261,16 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                 }
             }
         }
-        if (++since_flush == K1V3_FLUSH_ITERS) {
-            __syncthreads(); flush(); __syncthreads();
-            since_flush = 0;
+        ++since_flush; ++since_dn_flush;
+        if (since_flush == K1V3_FLUSH_ITERS || since_dn_flush == p.dn_flush_iters) {
+            __syncthreads();
+            flush_dn(); since_dn_flush = 0;
+            if (since_flush == K1V3_FLUSH_ITERS) { flush_pos(); since_flush = 0; }
+            __syncthreads();
         }
     }
     __syncthreads();
-    flush();
+    flush_dn(); flush_pos();
 }
 
 // ---------------------------------------------------------------- K2 (table-driven)
