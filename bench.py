@@ -120,6 +120,14 @@ def main():
         k1_gbs = 3.0 * bases_per_rank / k1_avg / 1e9
         k2_gbs = 3.0 * bases_per_rank / k2_avg / 1e9
         dom, dom_gbs = ('k1_accumulate', k1_gbs) if k1_avg >= k2_avg else ('k2_apply', k2_gbs)
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE,
+        # collected separately with rocprofv3 --pmc; see profiles/pmc_traffic.json) scaled to this launch
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
+                traffic = json.load(fh)[dom]['hbm_bytes_per_base'] * bases_per_rank
+        except Exception:
+            pass
         res = {
             'metric': 'bases/sec recalibrated (2x150 bp)', 'value': total_bases / elapsed,
             'unit': 'bases/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -130,7 +138,7 @@ def main():
                        'reads_per_gpu': n, 'read_len': S, 'read_groups': R,
                        'parallelism': 'reads sharded x%d, 1 allreduce of count tables' % world},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': dom_gbs, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': dom_gbs / HBM_PEAK_GBS, 'traffic': None},
+                         'unit': 'GB/s', 'frac': dom_gbs / HBM_PEAK_GBS, 'traffic': traffic},
             'kernels': {'k1_accumulate': {'avg_ms': k1_avg * 1e3, 'launches': k1_n, 'GB/s': k1_gbs,
                                           'frac': k1_gbs / HBM_PEAK_GBS, 'bytes_per_base': 3},
                         'k2_apply': {'avg_ms': k2_avg * 1e3, 'launches': k2_n, 'GB/s': k2_gbs,

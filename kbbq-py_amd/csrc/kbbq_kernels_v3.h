@@ -50,7 +50,7 @@ __device__ __forceinline__ void decode4x(u32 w, u32& code, u32& code5, u32& expe
     expect = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, h);
 }
 
-struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int j; int nb; };
+struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int k; int j; int nb; };
 
 // LDS: dn [nrows][32][16] u32 context counts (errs << 16 | total), 16 copies (copy = lane & 15:
 //          the table is tiny and hot -- measured 15 LDS cycles per wave-atomic unreplicated --
@@ -87,6 +87,11 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
     const u32 dnt_row = 128u * K1V3_DNREP;                             // bytes per row of the replicated totals
     const u32 dnt_base = 0u - 180u * dnt_row + 4u * (u32)(lane_id() & (K1V3_DNREP - 1));
     int since_flush = 0, since_dn_flush = 0;
+    // work item of this lane at step 0 and the per-step advances (64 / 128 items)
+    const int lane_k0 = p.cpr == 1 ? lane : (int)__umulhi((u32)lane, p.cpr_magic);
+    const int lane_j0 = lane - lane_k0 * p.cpr;
+    const int dk1 = 64 / p.cpr, dj1 = 64 - dk1 * p.cpr;
+    const int dk2 = 128 / p.cpr, dj2 = 128 - dk2 * p.cpr;
 
     u64* pos_errs = p.tables;
     u64* pos_total = p.tables + (size_t)p.R * KQ * S2;
@@ -155,17 +160,22 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
 
             // fetch: issue the three 16-byte loads of one step (no wait); process: bin them.
             // The loop below keeps one step in flight while the previous one is binned.
-            auto fetch = [&](int w0, K1Chunk& ch) {
-                const int w = w0 + lane;
-                const bool act0 = w < total;
-                const int k = act0 ? (p.cpr == 1 ? w : (int)__umulhi((u32)w, p.cpr_magic)) : 0;
-                ch.j = w - k * p.cpr;
+            // (k, j) = (read slot, chunk) of the lane's work item; advanced incrementally.
+            auto advance = [&](K1Chunk& ch, int dk, int dj) {
+                const int jj = ch.j + dj;
+                const bool wrap = jj >= p.cpr;
+                ch.j = wrap ? jj - p.cpr : jj;
+                ch.k = ch.k + dk + (wrap ? 1 : 0);
+            };
+            auto fetch = [&](K1Chunk& ch) {
+                const bool act0 = ch.k < n;
+                const int k = act0 ? ch.k : 0;
                 ch.mk = bperm(cm, k);
                 ch.off = n == 64 ? (u32)k : bperm(coff, k);
                 ch.nb = act0 ? ((int)(ch.mk & 0xFFFFu) - 16 * ch.j) : 0;
                 // lanes without work re-read the block's first chunk (valid memory, result unused)
 #ifndef KBBQ_ABL_NOLOAD
-                const u32 rowoff = ch.nb > 0 ? ch.off * (u32)p.pitch + (u32)(16 * ch.j) : 0u;
+                const u32 rowoff = ch.nb > 0 ? __umul24(ch.off, (u32)p.pitch) + (u32)(16 * ch.j) : 0u;
 #else
                 const u32 rowoff = (u32)lane * 16u;      // timing only: every step re-reads the same cached KiB
 #endif
@@ -250,13 +260,17 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                 // (past the end they re-read the block's first chunk) so that the outstanding
                 // loads can be counted (s_waitcnt vmcnt(3)) instead of drained
                 K1Chunk ca, cb;
-                fetch(0, ca);
+                ca.k = lane_k0; ca.j = lane_j0;
+                cb.k = lane_k0; cb.j = lane_j0; advance(cb, dk1, dj1);
+                fetch(ca);
                 for (int w0 = 0; w0 < total; w0 += 128) {
-                    fetch(w0 + 64, cb);
+                    fetch(cb);
                     process(ca);
                     if (w0 + 64 < total) {
-                        fetch(w0 + 128, ca);
+                        advance(ca, dk2, dj2);
+                        fetch(ca);
                         process(cb);
+                        advance(cb, dk2, dj2);
                     }
                 }
             }
@@ -290,7 +304,7 @@ __host__ __device__ __forceinline__ int full_lut_row_bytes(int S2)
     return rb;
 }
 
-struct K2Chunk { u32 s[4], q[4]; u32 mk; int k; int j; int nb; bool act0; };
+struct K2Chunk { u32 s[4], q[4]; u32 mk; int kk; int k; int j; int nb; bool act0; };
 
 struct K2v3Params {
     const uint8_t* seq; const uint8_t* qual; const u32* meta;
@@ -317,6 +331,10 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
     const u32 rb = (u32)full_lut_row_bytes(p.S2);
     const u32 rg_bytes = (u32)(33 + p.Qt) * rb;
     const u32 hi_add = (u32)(0x80 - (p.Qt + 33)) * 0x01010101u;   // byte >= Qt+33 <=> bit 7 after the add
+    const int lane_k0 = p.cpr == 1 ? lane : (int)__umulhi((u32)lane, p.cpr_magic);
+    const int lane_j0 = lane - lane_k0 * p.cpr;
+    const int dk1 = 64 / p.cpr, dj1 = 64 - dk1 * p.cpr;
+    const int dk2 = 128 / p.cpr, dj2 = 128 - dk2 * p.cpr;
 
     for (long long blk = (long long)blockIdx.x * nwaves + wave; blk < nblocks;
          blk += (long long)gridDim.x * nwaves) {
@@ -330,15 +348,19 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
         uint8_t* bout = p.out + (size_t)read0 * p.pitch;
         u32 carry_code = 20u, carry_char = 0u;
 
-        auto fetch = [&](int w0, K2Chunk& ch) {
-            const int w = w0 + lane;
-            ch.act0 = w < total;
-            ch.k = ch.act0 ? (p.cpr == 1 ? w : (int)__umulhi((u32)w, p.cpr_magic)) : 0;
-            ch.j = w - ch.k * p.cpr;
+        auto advance = [&](K2Chunk& ch, int dk, int dj) {
+            const int jj = ch.j + dj;
+            const bool wrap = jj >= p.cpr;
+            ch.j = wrap ? jj - p.cpr : jj;
+            ch.kk = ch.kk + dk + (wrap ? 1 : 0);
+        };
+        auto fetch = [&](K2Chunk& ch) {
+            ch.act0 = ch.kk < n;
+            ch.k = ch.act0 ? ch.kk : 0;
             ch.mk = bperm(m, ch.k);
             ch.nb = ch.act0 ? ((int)(ch.mk & 0xFFFFu) - 16 * ch.j) : 0;
 #ifndef KBBQ_ABL_NOLOAD
-            const u32 rowoff = ch.nb > 0 ? (u32)ch.k * (u32)p.pitch + (u32)(16 * ch.j) : 0u;
+            const u32 rowoff = ch.nb > 0 ? __umul24((u32)ch.k, (u32)p.pitch) + (u32)(16 * ch.j) : 0u;
 #else
             const u32 rowoff = (u32)lane * 16u;
 #endif
@@ -417,19 +439,23 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
                         }
                     }
                 }
-                *reinterpret_cast<uint4*>(bout + ((u32)k * (u32)p.pitch + (u32)pos0)) = make_uint4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<uint4*>(bout + (__umul24((u32)k, (u32)p.pitch) + (u32)pos0)) = make_uint4(o[0], o[1], o[2], o[3]);
             }
         };
 
         if (total > 0) {
             K2Chunk ca, cb;
-            fetch(0, ca);
+            ca.kk = lane_k0; ca.j = lane_j0;
+            cb.kk = lane_k0; cb.j = lane_j0; advance(cb, dk1, dj1);
+            fetch(ca);
             for (int w0 = 0; w0 < total; w0 += 128) {
-                fetch(w0 + 64, cb);
+                fetch(cb);
                 process(ca);
                 if (w0 + 64 < total) {
-                    fetch(w0 + 128, ca);
+                    advance(ca, dk2, dj2);
+                    fetch(ca);
                     process(cb);
+                    advance(cb, dk2, dj2);
                 }
             }
         }
