@@ -340,6 +340,31 @@ def test_covariatedata_consume_read(dev, oracle):
         read.ReadData.rg_to_pu = dict(); read.ReadData.rg_to_int = dict(); read.ReadData.numrgs = 0
 
 
+def test_adversarial_single_bin_does_not_overflow_lds_counters(dev):
+    """Every base of every read falls into ONE (q, context) bin and ONE bin per cycle: the worst
+    case for the 16-bit packed LDS counters of K1 (flush cadences in DESIGN.md)."""
+    import torch
+    n, L, pitch = 400_000, 150, 160
+    b = dev.ReadBatch(n, pitch)
+    row = torch.full((pitch,), ord('N'), dtype=torch.uint8, device='cuda'); row[:L] = ord('A')
+    crow = row.clone(); crow[:L:7] = ord('C')                       # an error every 7th base
+    qrow = torch.zeros(pitch, dtype=torch.uint8, device='cuda'); qrow[:L] = 33 + 40
+    b.seq[:] = row; b.cseq[:] = crow; b.qual[:] = qrow
+    meta = torch.full((n,), L, dtype=torch.int64, device='cuda')
+    meta[1::2] += 1 << 31                                            # alternate mates
+    b.meta[:] = torch.where(meta >= 2 ** 31, meta - 2 ** 32, meta).to(torch.int32)
+    t = dev.Tables(1, 2 * L)
+    dev.accumulate(b, t)
+    pe, pt, de, dt = t.to_host()
+    assert pt.sum() == n * L and pt[0, 40].sum() == n * L
+    assert np.all(pt[0, 40, :L] == n // 2) and np.all(pt[0, 40, L:] == n // 2)
+    nerr = len(range(0, L, 7))
+    assert pe.sum() == n * nerr
+    assert np.all(pe[0, 40, 0:L:7] == n // 2)
+    assert dt.sum() == n * (L - 1) and dt[0, 40, 0] == n * (L - 1)   # context 'AA' = 0 for every base but the first
+    assert de[0, 40, 0] == n * (nerr - 1)                            # position 0 has no context
+
+
 # ------------------------------------------------------------------ large: properties
 def test_large_batch_properties(dev):
     """4 M synthetic 2x150 reads (600 M bases) generated on the device: counts vs independent
