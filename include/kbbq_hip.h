@@ -184,6 +184,30 @@ int    kbbq_solve_dev(kbbq_ctx* ctx, const int64_t* d_tables, int R, int S2, int
                       const int32_t* d_meanq, const double* d_aux, const double* h_consts129,
                       int32_t* d_post_q, void* d_lut_blob, int32_t* d_dq);
 
+/* ---- host FASTQ ingest / egress (no GPU) ----------------------------------
+ * Replaces, for this path, pysam.FastxFile iteration (recalibrate.py:56-57,141-142),
+ * the name parsing of compare_reads.py:304-318 / recalibrate.py:59-64 and the print()
+ * calls of recalibrate.py:153-156.  4-line records; name = header up to whitespace.
+ * kbbq_fastq_scan(a, b|NULL, infer_rg, info[5]) validates in the reference's order and
+ * returns info = { usable reads, longest read S, read groups R, error kind, error index }
+ * with kinds 1 RG inference IndexError, 2 RG AssertionError, 3 name prefix
+ * (AssertionError), 4 length mismatch (ValueError), 5 shorter than the running maximum
+ * (IndexError; that read is still included so the device can check it first).
+ * kbbq_fastq_fill packs reads [0, n) into the padded planes (multi-threaded);
+ * kbbq_fastq_format renders "@name\nseq\n+\nqual\n" records with the new qualities.  */
+typedef struct kbbq_fastq kbbq_fastq;
+int         kbbq_fastq_open(const char* path, kbbq_fastq** out);
+int         kbbq_fastq_close(kbbq_fastq* f);
+int64_t     kbbq_fastq_count(const kbbq_fastq* f);
+int         kbbq_fastq_name(const kbbq_fastq* f, int64_t i, const char** name, int* len);
+int         kbbq_fastq_rg_count(const kbbq_fastq* f);
+const char* kbbq_fastq_rg_name(const kbbq_fastq* f, int i);
+int         kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* info5);
+int         kbbq_fastq_fill(const kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t n, int pitch,
+                            uint8_t* seq, uint8_t* cseq, uint8_t* qual, uint32_t* meta);
+int64_t     kbbq_fastq_format(const kbbq_fastq* a, int64_t first, int64_t n, int pitch,
+                              const uint8_t* newqual, char* out, int64_t cap);
+
 /* ---- synthetic reads (bench / tests) -----------------------
  * Device twin of the generator documented in oracle/kbbq_oracle.c.          */
 int kbbq_synth_dev(kbbq_ctx* ctx, uint8_t* d_seq, uint8_t* d_cseq, uint8_t* d_qual,

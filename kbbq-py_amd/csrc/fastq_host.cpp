@@ -1,0 +1,295 @@
+// fastq_host.cpp -- host-side FASTQ ingest / egress for the hot path (no GPU code).
+//
+// Replaces, for this path, what the reference gets from pysam (FastxFile iteration,
+// recalibrate.py:56-57,141-142), its per-read name parsing (compare_reads.py:304-318,
+// recalibrate.py:59-64) and the print() calls of recalibrate.py:153-156.  4-line FASTQ
+// records; `name` is the header up to the first whitespace (pysam/kseq semantics).
+//
+// Error ORDER is part of the behaviour: the reference stops at the first offending read,
+// and within one read checks run in the order  read-group inference (:59) -> name prefix
+// (:91 -> :17) -> sequence lengths (:20) -> [device: alphabet :94] -> shorter than the
+// running maximum (:97) -> [device: q > 42 :114].  kbbq_fastq_scan_pair reports the first
+// host-detectable offender and its kind; the caller lets the device look at the reads before
+// it (and at it, for kind 5) before raising.
+#include "../../include/kbbq_hip.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+extern "C" const char* kbbq_last_error(void);
+int kbbq_set_error_(int code, const char* msg);      // defined in kbbq_hip.hip
+
+struct kbbq_fastq {
+    const uint8_t* buf = nullptr; size_t size = 0; bool mapped = false;
+    std::vector<uint64_t> h0, s0, q0;      // start offsets of header / sequence / quality lines
+    std::vector<uint32_t> hlen, slen;      // header line length (without '@', up to whitespace = name), sequence length
+    std::vector<std::string> rg_names;     // first-appearance order (filled by scan / fill with infer_rg)
+    ~kbbq_fastq() { if (mapped && buf) munmap((void*)buf, size); else free((void*)buf); }
+};
+
+static unsigned nthreads_for(size_t work)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 4;
+    const char* e = getenv("KBBQ_HOST_THREADS");
+    if (e && atoi(e) > 0) hw = (unsigned)atoi(e);
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(hw, work / (1 << 20) + 1));
+}
+
+template <typename F> static void parallel_for(int64_t n, unsigned nt, F f)
+{
+    if (nt <= 1 || n < 4096) { f(0, n); return; }
+    std::vector<std::thread> th;
+    const int64_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const int64_t lo = std::min<int64_t>(n, t * per), hi = std::min<int64_t>(n, lo + per);
+        if (lo < hi) th.emplace_back([=]() { f(lo, hi); });
+    }
+    for (auto& t : th) t.join();
+}
+
+extern "C" {
+
+int kbbq_fastq_open(const char* path, kbbq_fastq** out)
+{
+    if (!path || !out) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_open: NULL argument");
+    *out = nullptr;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return kbbq_set_error_(KBBQ_E_ARG, (std::string("cannot open ") + path).c_str());
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return kbbq_set_error_(KBBQ_E_ARG, "fstat failed"); }
+    kbbq_fastq* f = new kbbq_fastq();
+    f->size = (size_t)st.st_size;
+    if (f->size) {
+        void* m = mmap(nullptr, f->size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); delete f; return kbbq_set_error_(KBBQ_E_ARG, "mmap failed"); }
+        f->buf = (const uint8_t*)m; f->mapped = true;
+        madvise(m, f->size, MADV_SEQUENTIAL);
+    }
+    close(fd);
+    // line starts, in parallel: each thread scans a byte range for '\n'
+    const unsigned nt = nthreads_for(f->size);
+    std::vector<std::vector<uint64_t>> parts(nt);
+    {
+        std::vector<std::thread> th;
+        const size_t per = (f->size + nt - 1) / nt;
+        for (unsigned t = 0; t < nt; ++t) {
+            const size_t lo = std::min(f->size, t * per), hi = std::min(f->size, lo + per);
+            th.emplace_back([f, lo, hi, &parts, t]() {
+                auto& v = parts[t];
+                const uint8_t* p = f->buf + lo; const uint8_t* e = f->buf + hi;
+                while (p < e) {
+                    const uint8_t* nl = (const uint8_t*)memchr(p, '\n', (size_t)(e - p));
+                    if (!nl) break;
+                    v.push_back((uint64_t)(nl - f->buf));
+                    p = nl + 1;
+                }
+            });
+        }
+        for (auto& t : th) t.join();
+    }
+    std::vector<uint64_t> nl;
+    size_t tot = 0; for (auto& v : parts) tot += v.size();
+    nl.reserve(tot + 1);
+    for (auto& v : parts) nl.insert(nl.end(), v.begin(), v.end());
+    if (f->size && (nl.empty() || nl.back() != f->size - 1)) nl.push_back(f->size);   // last line without '\n'
+    if (nl.size() % 4 != 0) { delete f; return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": not a 4-line-per-record FASTQ file").c_str()); }
+    const int64_t n = (int64_t)(nl.size() / 4);
+    f->h0.resize(n); f->s0.resize(n); f->q0.resize(n); f->hlen.resize(n); f->slen.resize(n);
+    std::atomic<int> bad(0);
+    parallel_for(n, nt, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const uint64_t hs = i == 0 ? 0 : nl[4 * i - 1] + 1;
+            uint64_t he = nl[4 * i], ss = he + 1, se = nl[4 * i + 1], qs = nl[4 * i + 2] + 1, qe = nl[4 * i + 3];
+            auto trim = [&](uint64_t s, uint64_t& e) { if (e > s && f->buf[e - 1] == '\r') --e; };
+            trim(hs, he); trim(ss, se); trim(qs, qe);
+            if (he <= hs || f->buf[hs] != '@') { bad = 1; continue; }
+            if (se - ss != qe - qs) { bad = 2; continue; }
+            if (se - ss > 65535) { bad = 3; continue; }
+            uint64_t ne = hs + 1;                                   // name: up to the first whitespace
+            while (ne < he && f->buf[ne] != ' ' && f->buf[ne] != '\t') ++ne;
+            f->h0[i] = hs + 1; f->hlen[i] = (uint32_t)(ne - hs - 1);
+            f->s0[i] = ss; f->slen[i] = (uint32_t)(se - ss); f->q0[i] = qs;
+        }
+    });
+    if (bad.load()) {
+        const int b = bad.load(); delete f;
+        return kbbq_set_error_(KBBQ_E_ARG, b == 1 ? "record header does not start with @"
+                                          : b == 2 ? "sequence and quality lengths differ" : "read longer than 65535 bases");
+    }
+    *out = f;
+    return KBBQ_OK;
+}
+
+int kbbq_fastq_close(kbbq_fastq* f) { delete f; return KBBQ_OK; }
+int64_t kbbq_fastq_count(const kbbq_fastq* f) { return f ? (int64_t)f->h0.size() : 0; }
+
+int kbbq_fastq_name(const kbbq_fastq* f, int64_t i, const char** name, int* len)
+{
+    if (!f || i < 0 || i >= (int64_t)f->h0.size()) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_name: bad index");
+    *name = (const char*)f->buf + f->h0[i]; *len = (int)f->hlen[i];
+    return KBBQ_OK;
+}
+
+int kbbq_fastq_rg_count(const kbbq_fastq* f) { return f ? (int)f->rg_names.size() : 0; }
+const char* kbbq_fastq_rg_name(const kbbq_fastq* f, int i)
+{
+    return (f && i >= 0 && i < (int)f->rg_names.size()) ? f->rg_names[(size_t)i].c_str() : "";
+}
+
+} // extern "C"
+
+// compare_reads.py:304-306: the first '_' field ends with "/2"
+static inline bool name_second(const char* s, int n)
+{
+    int e = 0; while (e < n && s[e] != '_') ++e;
+    return e >= 2 && s[e - 2] == '/' && s[e - 1] == '2';
+}
+
+// compare_reads.py:308-318: field 1 of the '_' split must start with "RG"; the id is the text after
+// its last ':'.  Returns 0 ok, 1 IndexError (no second field), 2 AssertionError.
+static inline int name_rg(const char* s, int n, const char** rg, int* rglen)
+{
+    int a = 0; while (a < n && s[a] != '_') ++a;
+    if (a >= n) return 1;                              // split('_')[1] does not exist
+    const int fs = a + 1; int fe = fs; while (fe < n && s[fe] != '_') ++fe;
+    if (fe - fs < 2 || s[fs] != 'R' || s[fs + 1] != 'G') return 2;
+    int c = fe; while (c > fs && s[c - 1] != ':') --c;
+    *rg = s + c; *rglen = fe - c;
+    return 0;
+}
+
+extern "C" {
+
+// Scan reads [0, min(na, nb)) of the pair.  info: [0] n usable (cut at the first error), [1] S,
+// [2] R, [3] error kind (0 none, 1 RG IndexError, 2 RG AssertionError, 3 name prefix, 4 length
+// mismatch, 5 shorter than the running maximum), [4] error index.  b may be NULL (single file:
+// kinds 3-5 are not checked -- pass 2 of the reference accepts any lengths).
+int kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* info)
+{
+    if (!a || !info) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_scan: NULL argument");
+    int64_t n = (int64_t)a->h0.size();
+    if (b) n = std::min<int64_t>(n, (int64_t)b->h0.size());
+    int64_t err_idx = -1; int err_kind = 0;
+    auto consider = [&](int64_t idx, int kind) {         // lowest index wins; kinds are in check order
+        if (err_idx < 0 || idx < err_idx || (idx == err_idx && kind < err_kind)) { err_idx = idx; err_kind = kind; }
+    };
+    a->rg_names.clear();
+    std::unordered_map<std::string, int> rgmap;
+    if (infer_rg) {
+        const char* last = nullptr; int lastlen = -1;          // consecutive reads mostly share a read group
+        for (int64_t i = 0; i < n; ++i) {
+            const char* rg; int rl;
+            const int rc = name_rg((const char*)a->buf + a->h0[i], (int)a->hlen[i], &rg, &rl);
+            if (rc) { consider(i, rc); break; }
+            if (rl == lastlen && memcmp(rg, last, (size_t)rl) == 0) continue;
+            last = rg; lastlen = rl;
+            auto it = rgmap.find(std::string(rg, (size_t)rl));
+            if (it == rgmap.end()) { rgmap.emplace(std::string(rg, (size_t)rl), (int)a->rg_names.size()); a->rg_names.emplace_back(rg, (size_t)rl); }
+        }
+    } else if (n > 0) a->rg_names.emplace_back("0");
+    if (b) {
+        uint32_t runmax = 0;
+        for (int64_t i = 0; i < n && (err_idx < 0 || i <= err_idx); ++i) {
+            const uint32_t la = a->hlen[i], lb = b->hlen[i];
+            if (lb < la || memcmp(a->buf + a->h0[i], b->buf + b->h0[i], la) != 0) { consider(i, 3); break; }
+            if (a->slen[i] != b->slen[i]) { consider(i, 4); break; }
+            if (a->slen[i] < runmax) { consider(i, 5); break; }
+            runmax = std::max(runmax, a->slen[i]);
+        }
+    }
+    int64_t usable = n;
+    if (err_idx >= 0) usable = err_idx + (err_kind == 5 ? 1 : 0);
+    uint32_t S = 0;
+    for (int64_t i = 0; i < usable; ++i) S = std::max(S, a->slen[i]);
+    // read groups among the usable reads only
+    int R = 0;
+    if (usable > 0) {
+        if (!infer_rg) R = 1;
+        else {
+            std::unordered_map<std::string, int> seen;
+            for (int64_t i = 0; i < usable; ++i) {
+                const char* rg; int rl;
+                if (name_rg((const char*)a->buf + a->h0[i], (int)a->hlen[i], &rg, &rl)) break;
+                seen.emplace(std::string(rg, (size_t)rl), 0);
+            }
+            R = (int)seen.size();
+        }
+    }
+    info[0] = usable; info[1] = S; info[2] = R; info[3] = err_kind; info[4] = err_idx;
+    return KBBQ_OK;
+}
+
+// Fill the padded planes for reads [0, n): seq / qual from `a`, cseq from `b` (b, cseq may be NULL).
+// Padding: 'N' in seq / cseq, 0 in qual (include/kbbq_hip.h).  Call kbbq_fastq_scan first (it
+// builds the read-group table used here).
+int kbbq_fastq_fill(const kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t n, int pitch,
+                    uint8_t* seq, uint8_t* cseq, uint8_t* qual, uint32_t* meta)
+{
+    if (!a || !seq || !qual || !meta || (b && !cseq)) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_fill: NULL argument");
+    if (n < 0 || n > (int64_t)a->h0.size() || (b && n > (int64_t)b->h0.size())) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_fill: n out of range");
+    std::unordered_map<std::string, int> rgmap;
+    for (size_t i = 0; i < a->rg_names.size(); ++i) rgmap.emplace(a->rg_names[i], (int)i);
+    std::atomic<int> bad(0);
+    parallel_for(n, nthreads_for((size_t)n * (size_t)pitch * 3), [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const uint32_t L = a->slen[i];
+            if ((int)L > pitch || (b && b->slen[i] != L)) { bad = 1; continue; }
+            uint8_t* s = seq + (size_t)i * pitch; uint8_t* q = qual + (size_t)i * pitch;
+            memcpy(s, a->buf + a->s0[i], L); memset(s + L, 'N', (size_t)pitch - L);
+            memcpy(q, a->buf + a->q0[i], L); memset(q + L, 0, (size_t)pitch - L);
+            if (b) {
+                uint8_t* c = cseq + (size_t)i * pitch;
+                memcpy(c, b->buf + b->s0[i], L); memset(c + L, 'N', (size_t)pitch - L);
+            }
+            const char* nm = (const char*)a->buf + a->h0[i]; const int nl = (int)a->hlen[i];
+            uint32_t rgid = 0;
+            if (infer_rg) {
+                const char* rg; int rl;
+                if (name_rg(nm, nl, &rg, &rl)) { bad = 2; continue; }
+                auto it = rgmap.find(std::string(rg, (size_t)rl));
+                if (it == rgmap.end()) { bad = 2; continue; }
+                rgid = (uint32_t)it->second;
+            }
+            meta[i] = L | (rgid << 16) | ((uint32_t)name_second(nm, nl) << 31);
+        }
+    });
+    if (bad.load()) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_fill: input does not match the scan (call kbbq_fastq_scan first)");
+    return KBBQ_OK;
+}
+
+// recalibrate.py:153-156 for reads [first, first + n): "@name\nsequence\n+\nquality\n" with the
+// quality characters taken from rows [0, n) of `newqual` (pitch bytes each).  Returns the number of
+// bytes written into out (capacity cap) or -needed when cap is too small.
+int64_t kbbq_fastq_format(const kbbq_fastq* a, int64_t first, int64_t n, int pitch, const uint8_t* newqual,
+                          char* out, int64_t cap)
+{
+    if (!a || first < 0 || n < 0 || first + n > (int64_t)a->h0.size()) { kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_format: bad range"); return 0; }
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) off[(size_t)i + 1] = off[(size_t)i] + 1 + a->hlen[first + i] + 1 + a->slen[first + i] + 3 + a->slen[first + i] + 1;
+    if (off[(size_t)n] > cap) return -off[(size_t)n];
+    parallel_for(n, nthreads_for((size_t)off[(size_t)n]), [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            char* p = out + off[(size_t)i];
+            const int64_t r = first + i; const uint32_t L = a->slen[r];
+            *p++ = '@'; memcpy(p, a->buf + a->h0[r], a->hlen[r]); p += a->hlen[r]; *p++ = '\n';
+            memcpy(p, a->buf + a->s0[r], L); p += L; *p++ = '\n'; *p++ = '+'; *p++ = '\n';
+            memcpy(p, newqual + (size_t)i * pitch, L); p += L; *p++ = '\n';
+        }
+    });
+    return off[(size_t)n];
+}
+
+} // extern "C"

@@ -24,6 +24,9 @@ static int fail(int code, const char* fmt, ...)
     return code;
 }
 
+// used by fastq_host.cpp
+int kbbq_set_error_(int code, const char* msg) { g_err = msg ? msg : ""; return code; }
+
 #define HIPCHK(expr)                                                                   \
     do {                                                                               \
         hipError_t e_ = (expr);                                                        \

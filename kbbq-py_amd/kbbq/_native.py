@@ -61,6 +61,15 @@ PROTOTYPES = {
     'kbbq_solve_aux_count': (_sz, [_i, _i]),
     'kbbq_solve_dq_count': (_sz, [_i, _i]),
     'kbbq_solve_dev': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'kbbq_fastq_open': (_i, [_c.c_char_p, _c.POINTER(_vp)]),
+    'kbbq_fastq_close': (_i, [_vp]),
+    'kbbq_fastq_count': (_i64, [_vp]),
+    'kbbq_fastq_name': (_i, [_vp, _i64, _c.POINTER(_vp), _c.POINTER(_i)]),
+    'kbbq_fastq_rg_count': (_i, [_vp]),
+    'kbbq_fastq_rg_name': (_c.c_char_p, [_vp, _i]),
+    'kbbq_fastq_scan': (_i, [_vp, _vp, _i, _vp]),
+    'kbbq_fastq_fill': (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
+    'kbbq_fastq_format': (_i64, [_vp, _i64, _i64, _i, _vp, _vp, _i64]),
     'kbbq_synth_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _u64,
                             _i, _i, _i, _i, _i, _vp]),
     'kbbq_ctx_timing': (_i, [_vp, _i]),

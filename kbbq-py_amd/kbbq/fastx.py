@@ -152,8 +152,11 @@ def pitch_for(maxlen):
     return max(16, (int(maxlen) + 15) // 16 * 16)
 
 
-def pack_pair(path_a, path_b, infer_rg_flag):
-    """Pass-1 input: reads of file A zipped with file B (recalibrate.py:56-57).
+def pack_pair_py(path_a, path_b, infer_rg_flag):
+    """Pure-NumPy twin of pack_pair (kept as the readable statement of the rules and used by
+    the tests to check the C++ packer).
+
+    Pass-1 input: reads of file A zipped with file B (recalibrate.py:56-57).
 
     Host-detectable input errors do not raise here: the reference fails at the FIRST
     offending read, and a device-detected error (TypeError / IndexError) on an earlier
@@ -200,7 +203,7 @@ def pack_pair(path_a, path_b, infer_rg_flag):
                 names=names_a, text=A, pending_error=pending)
 
 
-def pack_single(text, infer_rg_flag):
+def pack_single_py(text, infer_rg_flag):
     """Pass-2 input: every read of file A with its own first-appearance RG map
     (recalibrate.py:141-148)."""
     names = text.names()
@@ -229,3 +232,107 @@ def format_fastq(names, seq_plane, qual_plane, lens):
         parts.append('@' + names[i] + '\n' + sb[o:o + L].decode('latin-1') + '\n+\n'
                      + qb[o:o + L].decode('latin-1') + '\n')
     return ''.join(parts)
+
+
+# ---------------------------------------------------------------------------
+# C++ packer / writer (csrc/fastq_host.cpp through the C ABI): multi-threaded, mmap-based.
+# Same rules and the same result dictionaries as the NumPy twins above.
+# ---------------------------------------------------------------------------
+import ctypes as _ct
+
+from . import _native as _N
+
+
+class NativeFastq:
+    """A FASTQ file opened by libkbbq_hip's host reader (kbbq_fastq_*)."""
+
+    def __init__(self, path):
+        self._h = _ct.c_void_p()
+        _N.check(_N.load().kbbq_fastq_open(str(path).encode(), _ct.byref(self._h)))
+        self.n = int(_N.load().kbbq_fastq_count(self._h))
+
+    def close(self):
+        if getattr(self, '_h', None):
+            _N.load().kbbq_fastq_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def name(self, i):
+        p, ln = _ct.c_void_p(), _ct.c_int(0)
+        _N.check(_N.load().kbbq_fastq_name(self._h, i, _ct.byref(p), _ct.byref(ln)))
+        return _ct.string_at(p, ln.value).decode('ascii')
+
+    def names(self):
+        return [self.name(i) for i in range(self.n)]
+
+    def rg_names(self):
+        lib = _N.load()
+        return [lib.kbbq_fastq_rg_name(self._h, i).decode('ascii') for i in range(lib.kbbq_fastq_rg_count(self._h))]
+
+    def scan(self, other, infer_rg_flag):
+        info = np.zeros(5, dtype=np.int64)
+        _N.check(_N.load().kbbq_fastq_scan(self._h, other._h if other is not None else None,
+                                           1 if infer_rg_flag else 0, _N.ptr(info)))
+        return [int(x) for x in info]
+
+    def fill(self, other, infer_rg_flag, n, pitch):
+        seq = np.empty((n, pitch), dtype=np.uint8)
+        qual = np.empty((n, pitch), dtype=np.uint8)
+        cseq = np.empty((n, pitch), dtype=np.uint8) if other is not None else None
+        meta = np.empty(n, dtype=np.uint32)
+        _N.check(_N.load().kbbq_fastq_fill(self._h, other._h if other is not None else None,
+                                           1 if infer_rg_flag else 0, n, pitch, _N.ptr(seq), _N.ptr(cseq),
+                                           _N.ptr(qual), _N.ptr(meta)))
+        return seq, cseq, qual, meta
+
+    def format(self, first, n, newqual):
+        """FASTQ text (bytes) of reads [first, first+n) with qualities from rows of `newqual`."""
+        newqual = np.ascontiguousarray(newqual)
+        pitch = newqual.shape[1]
+        lib = _N.load()
+        need = -lib.kbbq_fastq_format(self._h, first, n, pitch, _N.ptr(newqual), None, 0)
+        buf = _ct.create_string_buffer(max(int(need), 1))
+        got = lib.kbbq_fastq_format(self._h, first, n, pitch, _N.ptr(newqual), buf, need)
+        assert got == need
+        return buf.raw[:need]
+
+
+_SCAN_ERRORS = {
+    1: lambda i: IndexError('list index out of range'),                       # name.split('_')[1]
+    2: lambda i: AssertionError('read %d: second name field does not start with RG' % i),
+    3: lambda i: AssertionError('read %d: corrected read name does not start with the read name' % i),
+    4: lambda i: ValueError('operands could not be broadcast together: read %d and its correction '
+                            'differ in length' % i),
+    5: lambda i: IndexError('boolean index did not match indexed array: read %d is shorter than an '
+                            'earlier read (reference recalibrate.py:89-101)' % i),
+}
+
+
+def pack_pair(path_a, path_b, infer_rg_flag):
+    """Pass-1 input (recalibrate.py:56-57) through the C++ packer; same dictionary as pack_pair_py
+    except that `text` is the NativeFastq of file A and `names` is filled lazily by callers."""
+    A, B = NativeFastq(path_a), NativeFastq(path_b)
+    n, S, R, kind, idx = A.scan(B, infer_rg_flag)
+    pending = (idx, _SCAN_ERRORS[kind](idx), kind == 5) if kind else None
+    pitch = pitch_for(S)
+    seq, cseq, qual, meta = A.fill(B, infer_rg_flag, n, pitch)
+    rgs = A.rg_names()
+    return dict(seq=seq, cseq=cseq, qual=qual, meta=meta, n=n, pitch=pitch, S=S, R=R,
+                rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)},
+                text=A, pending_error=pending)
+
+
+def pack_single(text, infer_rg_flag):
+    """Pass-2 input: every read of file A with its own first-appearance RG map
+    (recalibrate.py:141-148)."""
+    n, S, R, kind, idx = text.scan(None, infer_rg_flag)
+    if kind:
+        raise _SCAN_ERRORS[kind](idx)
+    pitch = pitch_for(S)
+    seq, _, qual, meta = text.fill(None, infer_rg_flag, n, pitch)
+    return dict(seq=seq, qual=qual, meta=meta, n=n, pitch=pitch, S=S, R=R)

@@ -87,9 +87,13 @@ def recalibrate_fastq(fastq, infer_rg=False):
     lut, shape, _, _ = dev.solve(tables)
     batch = dev.ReadBatch.from_host(single['seq'], single['qual'], single['meta'])
     out = dev.apply(batch, lut, shape)
-    newq = out[:single['n']].cpu().numpy()
-    lens = (single['meta'] & 0xFFFF).astype(np.int64)
-    print(fastx.format_fastq(single['names'], single['seq'], newq, lens), end='')
+    # recalibrate.py:153-156: '@' + name, sequence, '+', qualities -- rendered by the C++ writer in
+    # slabs, written through print() like the reference
+    step = 1 << 20
+    for first in range(0, single['n'], step):
+        m = min(step, single['n'] - first)
+        newq = out[first:first + m].cpu().numpy()
+        print(packed['text'].format(first, m, newq).decode('latin-1'), end='')
 
 
 def recalibrate_bam(bam, use_oq=False, set_oq=False):

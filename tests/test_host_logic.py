@@ -105,15 +105,24 @@ def test_pack_pair_matches_oracle(oracle, tmp_path):
     fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
     oracle.write_fastq(fa, names, seq, qual, meta)
     oracle.write_fastq(fb, names, cseq, qual, meta)
-    got = fastx.pack_pair(fa, fb, True)
     want = oracle.pack_records(oracle.read_fastq(fa), oracle.read_fastq(fb), True)
-    assert got['pending_error'] is None
-    assert (got['n'], got['S'], got['R'], got['pitch']) == (want['n'], want['S'], want['R'], want['pitch'])
-    for k in ('seq', 'cseq', 'qual', 'meta'):
-        assert np.array_equal(got[k], want[k]), k
-    assert list(got['rg_to_int']) == want['rg_names']
+    for packer in (fastx.pack_pair, fastx.pack_pair_py):        # C++ packer and its NumPy twin
+        got = packer(fa, fb, True)
+        assert got['pending_error'] is None
+        assert (got['n'], got['S'], got['R'], got['pitch']) == (want['n'], want['S'], want['R'], want['pitch'])
+        for k in ('seq', 'cseq', 'qual', 'meta'):
+            assert np.array_equal(got[k], want[k]), k
+        assert list(got['rg_to_int']) == want['rg_names']
+    got = fastx.pack_pair(fa, fb, True)
     single = fastx.pack_single(got['text'], True)
     assert np.array_equal(single['seq'], want['seq']) and np.array_equal(single['meta'], want['meta'])
+    single = fastx.pack_single_py(fastx.FastqText(fa), True)
+    assert np.array_equal(single['seq'], want['seq']) and np.array_equal(single['meta'], want['meta'])
+    # the C++ writer renders exactly the reference's four lines per record
+    text = got['text'].format(0, got['n'], got['qual']).decode('ascii')
+    assert text == open(fa).read()
+    assert got['text'].format(7, 3, got['qual'][7:10]).decode('ascii') == ''.join(
+        '@%s\n%s\n+\n%s\n' % r for r in oracle.read_fastq(fa)[7:10])
 
 
 def test_fastq_reader_names_comments_and_endings(tmp_path):
@@ -131,23 +140,56 @@ def test_fastq_reader_names_comments_and_endings(tmp_path):
     assert err is None and list(m) == [4, 2 | (1 << 31)]
 
 
-def test_pack_pair_error_ordering(tmp_path):
+@pytest.mark.parametrize('packer', ['native', 'numpy'])
+def test_pack_pair_error_ordering(tmp_path, packer):
+    pack = fastx.pack_pair if packer == 'native' else fastx.pack_pair_py
     # name mismatch (read 1) comes before the short read (read 2)
     a = _write(tmp_path, 'a.fq', [('x', 'ACGT', 'IIII'), ('y', 'ACGT', 'IIII'), ('z', 'AC', 'II')])
     b = _write(tmp_path, 'b.fq', [('x', 'ACGT', 'IIII'), ('q', 'ACGT', 'IIII'), ('z', 'AC', 'II')])
-    p = fastx.pack_pair(a, b, False)
+    p = pack(a, b, False)
     idx, exc, inclusive = p['pending_error']
     assert idx == 1 and isinstance(exc, AssertionError) and not inclusive and p['n'] == 1
     # short read: IndexError, the read itself still goes to the device (its TypeError would win)
-    p = fastx.pack_pair(a, a, False)
+    p = pack(a, a, False)
     idx, exc, inclusive = p['pending_error']
     assert idx == 2 and isinstance(exc, IndexError) and inclusive and p['n'] == 3
     # RG inference failure on read 0 wins over everything later
-    p = fastx.pack_pair(a, b, True)
+    p = pack(a, b, True)
     assert p['pending_error'][0] == 0 and isinstance(p['pending_error'][1], IndexError)
+    # a second field that is not an RG field: AssertionError; length mismatch: ValueError
+    r = _write(tmp_path, 'r.fq', [('x/1_RG:Z:a', 'ACGT', 'IIII'), ('y/1_XX:Z:a', 'ACGT', 'IIII')])
+    p = pack(r, r, True)
+    assert p['pending_error'][0] == 1 and isinstance(p['pending_error'][1], AssertionError) and p['n'] == 1
+    m = _write(tmp_path, 'm.fq', [('x', 'ACGT', 'IIII'), ('y', 'ACG', 'III'), ('z', 'AC', 'II')])
+    p = pack(a, m, False)
+    assert p['pending_error'][0] == 1 and isinstance(p['pending_error'][1], ValueError) and p['n'] == 1
     # zip() truncation
     c = _write(tmp_path, 'c.fq', [('x', 'ACGT', 'IIII')])
-    assert fastx.pack_pair(a, c, False)['n'] == 1
+    assert pack(a, c, False)['n'] == 1
+    # RG ids in first-appearance order, text after the last ':' of the RG field
+    g = _write(tmp_path, 'g.fq', [('a/1_RG:Z:b', 'AC', 'II'), ('a/2_RG:Z:b', 'AC', 'II'),
+                                   ('c/1_RG:a', 'AC', 'II'), ('d/2_RG:Z:b_x', 'AC', 'II')])
+    p = pack(g, g, True)
+    assert p['pending_error'] is None and list(p['rg_to_int']) == ['b', 'a']
+    assert [int(x) for x in p['meta']] == [2, 2 | (1 << 31), 2 | (1 << 16), 2 | (1 << 31)]
+
+
+def test_native_fastq_reader_edge_cases(tmp_path):
+    p = tmp_path / 'x.fq'
+    p.write_bytes(b'@r1/1 some comment\nACGT\n+r1\nIIII\r\n@r2/2_RG:Z:foo\tcomment\nAC\n+\nII')
+    f = fastx.NativeFastq(str(p))
+    assert f.n == 2 and f.names() == ['r1/1', 'r2/2_RG:Z:foo']
+    n, S, R, kind, idx = f.scan(None, False)
+    assert (n, S, R, kind) == (2, 4, 1, 0)
+    seq, _, qual, meta = f.fill(None, False, 2, 16)
+    assert bytes(seq[0]) == b'ACGT' + b'N' * 12 and bytes(qual[1]) == b'II' + bytes(14)
+    assert list(meta) == [4, 2 | (1 << 31)]
+    assert f.format(0, 2, qual) == b'@r1/1\nACGT\n+\nIIII\n@r2/2_RG:Z:foo\nAC\n+\nII\n'
+    empty = tmp_path / 'e.fq'; empty.write_bytes(b'')
+    assert fastx.NativeFastq(str(empty)).n == 0
+    bad = tmp_path / 'b.fq'; bad.write_bytes(b'@r\nAC\n+\n')
+    with pytest.raises(ValueError):
+        fastx.NativeFastq(str(bad))
 
 
 # ---------------------------------------------------------------- model numerics
