@@ -47,6 +47,7 @@ def _tally(packed, minscore, maxscore, upto=None):
                                     cseq=packed['cseq'][:n])
     tables = dev.Tables(R, 2 * S)
     dev.accumulate(batch, tables, minscore)
+    packed['batch'] = batch                  # still resident: pass 2 re-uses it when it covers file A
     return tables
 
 
@@ -79,13 +80,20 @@ def recalibrate_fastq(fastq, infer_rg=False):
     the recalibrated FASTQ is printed to stdout.  K1 -> K3 -> K2, tables and LUT stay on
     the device between the kernels."""
     packed, tables = _pack_and_tally(fastq, infer_rg, 6, 42)
-    single = fastx.pack_single(packed['text'], infer_rg)
-    if single['n'] == 0:
+    text = packed['text']
+    if text.n == 0:
         return
     if tables is None:
         raise IndexError('index 0 is out of bounds for axis 0 with size 0')   # no read was tallied
     lut, shape, _, _ = dev.solve(tables)
-    batch = dev.ReadBatch.from_host(single['seq'], single['qual'], single['meta'])
+    if packed['n'] == text.n:
+        # pass 2 walks the same reads with the same first-appearance read groups (:141-148):
+        # the planes of pass 1 are still on the device
+        batch, single = packed['batch'], packed
+    else:
+        # file B was shorter (zip truncation): pass 2 still covers all of file A
+        single = fastx.pack_single(text, infer_rg)
+        batch = dev.ReadBatch.from_host(single['seq'], single['qual'], single['meta'])
     out = dev.apply(batch, lut, shape)
     # recalibrate.py:153-156: '@' + name, sequence, '+', qualities -- rendered by the C++ writer in
     # slabs, written through print() like the reference
