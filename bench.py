@@ -55,6 +55,12 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=2_000_000, help='reads in the CPU baseline sample (0 = skip)')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: library banners (RCCL prints its version to stdout under
+    # NCCL_DEBUG=VERSION) are sent to stderr until the result is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -63,7 +69,8 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = 'RANK' in os.environ                 # launched by torch.distributed.run (any N, also 1)
+    if use_dist:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     from kbbq import _device as dev
@@ -85,7 +92,7 @@ def main():
         dev.apply(batch, lut, shape, out=out, check=False)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -106,7 +113,7 @@ def main():
     k2_ms, k2_n = ctx.kernel_ms(1)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -147,8 +154,11 @@ def main():
         }
         if world == 1 and args.cpu_sample > 0:
             res['cpu_baseline'] = cpu_baseline(args.cpu_sample)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(res), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

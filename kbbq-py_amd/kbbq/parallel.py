@@ -22,7 +22,7 @@ def allreduce_tables(buf):
     """In-place SUM over all ranks of the concatenated count tables
     [pos_errs | pos_total | dinuc_errs | dinuc_total] (int64)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 
