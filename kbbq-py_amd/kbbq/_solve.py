@@ -45,13 +45,76 @@ def combiln(numerrs, numtotal):
         return scipy.special.gammaln(n + 1) - (scipy.special.gammaln(k + 1) + scipy.special.gammaln(n - k + 1))
 
 
+def _round64(t):
+    """Round a positive Python int to 64 significant bits, ties to even -> (mantissa, shift)."""
+    n = t.bit_length()
+    if n <= 64:
+        return t, 0
+    sh = n - 64
+    m, rem = t >> sh, t & ((1 << sh) - 1)
+    half = 1 << (sh - 1)
+    if rem > half or (rem == half and (m & 1)):
+        m += 1
+        if m == 1 << 64:
+            m >>= 1; sh += 1
+    return m, sh
+
+
+def sequential_constant_sum(p, n):
+    """Exactly the value an x87 longdouble accumulator holds after adding the float64 `p` to it
+    `n` times, one add at a time (np.add.at on the longdouble expected_errs, recalibrate.py:111),
+    in O(64) big-integer steps instead of n.  Needed when every counted base of a read group has
+    the same quality: the mean error is then p itself up to the accumulated rounding, and p_to_q
+    truncates right at that boundary (the reference's "float badness", tests/test_recalibrate.py:63)."""
+    if n <= 0 or p == 0:
+        return np.longdouble(0)
+    mp, ep = np.frexp(np.float64(p))
+    mp = int(mp * (1 << 53)); ep = int(ep) - 53               # p = mp * 2**ep exactly
+    S, E = mp, ep                                             # accumulator after the first add: p itself
+    n -= 1
+
+    def add(S, E):                                            # one exact add, rounded to 64 bits
+        e0 = min(E, ep)
+        m, sh = _round64((S << (E - e0)) + (mp << (ep - e0)))
+        return m, e0 + sh
+
+    while n > 0:
+        S1, E1 = add(S, E)
+        if n < 8 or S1.bit_length() < 64 or E1 != E:
+            S, E = S1, E1                                     # few adds left, still growing, or binade changed
+            n -= 1
+            continue
+        # full-width mantissa in binade E: p = a*ulp + r with fixed a, r, so after at most one
+        # irregular add (an exact tie landing on an odd mantissa) the increment is constant.  Look
+        # two more adds ahead and jump while the mantissa stays below 2**64.
+        S2, E2 = add(S1, E1)
+        S3, E3 = add(S2, E2)
+        if E2 != E or E3 != E or (S3 - S2) != (S2 - S1):
+            S, E = S1, E1
+            n -= 1
+            continue
+        inc = S2 - S1
+        S, n = S1, n - 1
+        k = min(n, ((1 << 64) - 1 - S) // inc) if inc > 0 else n
+        # leave the last add before the binade boundary to the exact path
+        k = max(0, k - 1)
+        S += inc * k
+        n -= k
+    return np.ldexp(np.longdouble(S), E)
+
+
 def vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore=42):
     """The reference's 9-tuple from the four 3-d count arrays: q_* and rg_* are marginals of
     pos_* (every counted base has exactly one cycle); meanq = p_to_q(sum_q q_total * 10^(-q/10)
     / rg_total) in longdouble (recalibrate.py:111,120)."""
     q_errs, q_total = pos_errs.sum(axis=2), pos_total.sum(axis=2)
     rg_errs, rg_total = q_errs.sum(axis=1), q_total.sum(axis=1)
-    expected = (q_total.astype(np.longdouble) * utils.q_to_p(np.arange(maxscore + 1))).sum(axis=1)
+    p = utils.q_to_p(np.arange(maxscore + 1))
+    expected = (q_total.astype(np.longdouble) * p).sum(axis=1)
+    for r in range(q_total.shape[0]):
+        nz = np.flatnonzero(q_total[r])
+        if nz.size == 1:      # one quality value only: reproduce the reference's add-by-add rounding
+            expected[r] = sequential_constant_sum(np.float64(p[nz[0]]), int(q_total[r, nz[0]]))
     with np.errstate(divide='ignore', invalid='ignore'):
         meanq = utils.p_to_q(expected / rg_total, maxscore)
     return meanq, rg_errs, rg_total, q_errs, q_total, pos_errs, pos_total, dinuc_errs, dinuc_total

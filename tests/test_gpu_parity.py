@@ -109,6 +109,62 @@ def test_accumulate_and_apply_match_oracle(dev, oracle, shape, minscore):
     assert np.array_equal(chk, out)
 
 
+def _random_planes(rng, n, L, pitch, qvals, qprob, pn=0.02, perr=0.05, R=1, lens=None):
+    """Hand-made reads (not the synthetic generator): binned qualities, N runs, any alphabet mix."""
+    seq = np.full((n, pitch), ord('N'), dtype=np.uint8); cseq = seq.copy()
+    qual = np.zeros((n, pitch), dtype=np.uint8)
+    lens = np.full(n, L) if lens is None else lens
+    meta = np.zeros(n, dtype=np.uint32)
+    acgt = np.frombuffer(b'ACGT', dtype=np.uint8)
+    for i in range(n):
+        l = int(lens[i])
+        b = acgt[rng.integers(0, 4, l)]
+        b[rng.random(l) < pn] = ord('N')
+        if rng.random() < 0.05:                      # a run of N
+            a = rng.integers(0, l); b[a:a + rng.integers(1, 20)] = ord('N')
+        c = b.copy()
+        e = rng.random(l) < perr
+        c[e] = acgt[rng.integers(0, 4, int(e.sum()))]
+        seq[i, :l] = b; cseq[i, :l] = c
+        qual[i, :l] = 33 + rng.choice(qvals, size=l, p=qprob)
+        meta[i] = l | (int(rng.integers(0, R)) << 16) | ((i & 1) << 31)
+    return seq, cseq, qual, meta
+
+
+@pytest.mark.parametrize('case', ['binned', 'all_low', 'one_base', 'many_rgs', 'homopolymer'])
+def test_handmade_reads_match_oracle(dev, oracle, case):
+    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    if case == 'binned':          # modern Illumina: a handful of quality bins, one below minscore
+        seq, cseq, qual, meta = _random_planes(rng, 3000, 151, 160, [2, 11, 25, 37], [.05, .1, .25, .6]); R, S = 1, 151
+    elif case == 'all_low':       # most reads entirely below minscore (never counted), a few not
+        seq, cseq, qual, meta = _random_planes(rng, 800, 100, 112, [2, 3, 5, 30], [.4, .3, .29, .01]); R, S = 1, 100
+    elif case == 'one_base':      # reads of length 1 and 2 (non-decreasing), 16-byte rows
+        lens = np.sort(rng.integers(1, 3, 500))
+        seq, cseq, qual, meta = _random_planes(rng, 500, 2, 16, [7, 40], [.5, .5], lens=lens); R, S = 1, 2
+    elif case == 'many_rgs':      # 32 read groups in random order
+        seq, cseq, qual, meta = _random_planes(rng, 4000, 75, 80, np.arange(2, 42), np.full(40, 1 / 40), R=32); R, S = 32, 75
+    else:                         # homopolymers with constant quality: every count in very few bins
+        seq, cseq, qual, meta = _random_planes(rng, 2000, 150, 160, [40], [1.0], pn=0.0, perr=0.0)
+        seq[:, :150] = ord('A'); cseq[:, :150] = ord('A'); cseq[::3, 10] = ord('T'); R, S = 1, 150
+    got = _tables_via_device(dev, seq, cseq, qual, meta, R, S)
+    want = oracle.accumulate(seq, cseq, qual, meta, R, S)
+    for g, w, k in zip(got, want[5:], VEC[5:]):
+        assert np.array_equal(g, w), (case, k)
+    if want[2].min() > 0:          # every read group has counted bases: the model is defined (SURVEY H9)
+        t = dev.Tables(R, 2 * S)
+        import torch
+        t.buf.copy_(torch.from_numpy(np.concatenate([x.ravel() for x in want[5:]])))
+        lut, shape, vectors, dqs = dev.solve(t, want_dq=True)
+        wdq = oracle.get_delta_qs(*want)
+        for g, w, k in zip(dqs, wdq, DQ):
+            assert np.array_equal(g, w), (case, k)
+        batch = dev.ReadBatch.from_host(seq, qual, meta)
+        out = dev.apply(batch, lut, shape)[:seq.shape[0]].cpu().numpy()
+        ref = oracle.apply(seq, qual, meta, want[0], *wdq)
+        inside = np.arange(seq.shape[1])[None, :] < (meta & 0xFFFF)[:, None]
+        assert np.array_equal(out[inside].astype(np.int32) - 33, ref[inside]), case
+
+
 def test_accumulate_adds_into_tables_and_is_linear(dev, oracle):
     seq, cseq, qual, meta = oracle.synth(0, 4000, 4000, 21, nrg=2)
     whole = _tables_via_device(dev, seq, cseq, qual, meta, 2, 150)

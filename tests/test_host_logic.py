@@ -210,6 +210,27 @@ def test_prior_and_q_p_tables_match_reference():
                           np.array([6, 5, 3, 10, 20, 30]))
 
 
+def test_sequential_constant_sum_is_exact():
+    """_solve.sequential_constant_sum == a longdouble accumulator fed one add at a time."""
+    from kbbq import _solve
+    if np.finfo(np.longdouble).nmant != 63:
+        pytest.skip('np.longdouble is not x87 extended here')
+    ps = [10.0 ** (-(q / 10.0)) for q in (0, 6, 7, 10, 20, 25, 30, 37, 40, 42)] + [0.5, 0.75, 1.0 / 3, 2.0 ** -20 * 3]
+    for p in ps:
+        acc = np.longdouble(0); step = np.longdouble(np.float64(p))
+        checks = {1, 2, 3, 5, 17, 100, 1023, 1024, 4097, 30000, 65537, 300000}
+        for i in range(1, 300001):
+            acc = acc + step
+            if i in checks:
+                assert _solve.sequential_constant_sum(p, i) == acc, (p, i)
+    # the mean of n copies of 10^-4 truncates to 39 or 40 depending on the accumulated rounding
+    from kbbq import compare_reads
+    for n in (2, 1000, 300000, 7_500_000_000):
+        s = _solve.sequential_constant_sum(np.float64(1e-4), n)
+        assert abs(float(s / n) / 1e-4 - 1) < 1e-9
+        assert int(compare_reads.p_to_q(np.array([s / n]))[0]) in (39, 40)
+
+
 def test_meanq_from_marginals_matches_reference():
     from kbbq import recalibrate
     for name in ('c1_10k_1rg', 'c3cut_2k_8rg', 'c5cut_2k_mixed', 'q42_500_3rg', 'short_64_1rg'):
