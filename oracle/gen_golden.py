@@ -116,6 +116,51 @@ def numeric_tables(utils):
     return out, dict(grid_errs=errs, grid_total=tot, grid_dq=np.asarray(dq).astype(np.int64))
 
 
+BENCH_CASES = {'bench_a': dict(seed=11, npairs=150), 'bench_b': dict(seed=12, npairs=60, readlen=(20, 80))}
+
+
+def run_bench_case(name, c, tmp):
+    """Benchmark path (SURVEY 8(f) #1): the reference's own functions on a synthetic truth set."""
+    import contextlib
+    import io
+    import oracle_benchmark as OB
+    import pysam                                        # the shim's stand-in
+    from kbbq import benchmark as rb
+    d = os.path.join(tmp, name); os.makedirs(d)
+    paths = OB.synth_truthset(d, **c)
+    sha = {k: O.sha256(open(v, 'rb').read()) for k, v in paths.items()}
+    ref = rb.get_ref_dict(paths['fa'])
+    var = rb.get_var_sites(paths['vcf'])
+    with open(paths['bed']) as bedfh:
+        fullskips = rb.get_full_skips(ref, var, bedfh)
+    edict = rb.get_error_dict(pysam.AlignmentFile(paths['sam']), ref, fullskips)
+    keys = list(edict)
+    arrs = dict(errors=np.concatenate([edict[k][0] for k in keys]).astype(np.uint8),
+                skips=np.concatenate([edict[k][1] for k in keys]).astype(np.uint8),
+                lens=np.array([len(edict[k][0]) for k in keys], dtype=np.int64))
+    for tag, kw in (('bam', dict()), ('bam_oq', dict(use_oq=True))):
+        with open(paths['bed']) as bedfh:
+            a, t = rb.benchmark_bam(pysam.AlignmentFile(paths['sam']), ref, var, bedfh=bedfh, **kw)
+        arrs[tag + '_q'], arrs[tag + '_n'] = np.asarray(a).astype(np.int64), np.asarray(t).astype(np.int64)
+    with open(paths['bed']) as bedfh:
+        a, t = rb.benchmark_fastq(paths['fq'], pysam.AlignmentFile(paths['sam']), ref, var, bedfh)
+    arrs['fastq_q'], arrs['fastq_n'] = np.asarray(a).astype(np.int64), np.asarray(t).astype(np.int64)
+    # without a BED as well
+    a, t = rb.benchmark_bam(pysam.AlignmentFile(paths['sam']), ref, var)
+    arrs['nobed_q'], arrs['nobed_n'] = np.asarray(a).astype(np.int64), np.asarray(t).astype(np.int64)
+    texts = {}
+    for tag, kw in (('bam', dict()), ('fastq', dict(fastqfile=paths['fq']))):
+        buf = io.StringIO()
+        with open(paths['bed']) as bedfh, contextlib.redirect_stdout(buf):
+            rb.benchmark(paths['sam'], paths['fa'], paths['vcf'], label='lbl', bedfh=bedfh, **kw)
+        texts[tag] = buf.getvalue()
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), **arrs)
+    with open(os.path.join(GOLD, name + '.json'), 'w') as fh:
+        json.dump(dict(case=c, input_sha256=sha, read_keys=keys, printed=texts), fh, indent=1)
+    print('%-18s reads=%d bases=%d errors=%d skips=%d' % (name, len(keys), arrs['lens'].sum(),
+                                                          arrs['errors'].sum(), arrs['skips'].sum()), flush=True)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     _shim.install()
@@ -130,6 +175,10 @@ def main():
             if only and name not in only:
                 continue
             run_case(name, c, recal, applybqsr, tmp)
+        for name, c in BENCH_CASES.items():
+            if only and name not in only:
+                continue
+            run_bench_case(name, c, tmp)
     if not only:
         info, arrs = numeric_tables(utils)
         info['versions'] = dict(numpy=np.__version__, scipy=scipy.__version__,
