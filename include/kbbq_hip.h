@@ -184,6 +184,27 @@ int    kbbq_solve_dev(kbbq_ctx* ctx, const int64_t* d_tables, int R, int S2, int
                       const int32_t* d_meanq, const double* d_aux, const double* h_consts129,
                       int32_t* d_post_q, void* d_lut_blob, int32_t* d_dq);
 
+/* ---- K4 / K5: benchmark-path error flagging -----------------
+ * kbbq_find_errors_dev replaces compare_reads.find_read_errors (compare_reads.py:84-139)
+ * for a batch of aligned reads: per read a CIGAR walk against its reference window
+ * [ref_start, ref_start + ref_len) of the concatenated genome / skip-mask byte arrays
+ * (skip mask = benchmark.get_full_skips, benchmark.py:22-39); cigar ops are
+ * (length << 4 | op) with BAM op codes.  Outputs one byte per base (0 / 1) in the err and
+ * skip planes; flip[r] != 0 reverses both for reverse-strand reads (benchmark.py:70-72).
+ * Python's negative-index wraps of the reference (skips[-1], subset[-1]) are reproduced;
+ * its IndexError / ValueError cases arrive through kbbq_ctx_status as KBBQ_E_INDEX /
+ * KBBQ_E_RANGE.
+ * kbbq_count_q_dev replaces the two np.bincount calls of benchmark.calculate_q
+ * (benchmark.py:76-91) over the unskipped bases: counts[0..255] = observations per
+ * quality (byte - qoffset), counts[256..511] = errors; ADDS into d_counts512.          */
+int kbbq_find_errors_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint32_t* d_len, int64_t nreads, int pitch,
+                         const int64_t* d_ref_start, const int32_t* d_ref_len,
+                         const uint32_t* d_cig_off, const uint32_t* d_cig_n, const uint32_t* d_cigar,
+                         const uint8_t* d_genome, const uint8_t* d_skipmask, const uint8_t* d_flip,
+                         uint8_t* d_err, uint8_t* d_skip);
+int kbbq_count_q_dev(kbbq_ctx* ctx, const uint8_t* d_qual, const uint8_t* d_err, const uint8_t* d_skip,
+                     const uint32_t* d_len, int64_t nreads, int pitch, int qoffset, int64_t* d_counts512);
+
 /* ---- host FASTQ ingest / egress (no GPU) ----------------------------------
  * Replaces, for this path, pysam.FastxFile iteration (recalibrate.py:56-57,141-142),
  * the name parsing of compare_reads.py:304-318 / recalibrate.py:59-64 and the print()

@@ -592,6 +592,48 @@ int kbbq_solve_dev(kbbq_ctx* c, const int64_t* d_tables, int R, int S2, int mins
     return KBBQ_OK;
 }
 
+// ---- K4 / K5: benchmark path --------------------------------------------
+int kbbq_find_errors_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint32_t* d_len, int64_t nreads, int pitch,
+                         const int64_t* d_ref_start, const int32_t* d_ref_len,
+                         const uint32_t* d_cig_off, const uint32_t* d_cig_n, const uint32_t* d_cigar,
+                         const uint8_t* d_genome, const uint8_t* d_skipmask, const uint8_t* d_flip,
+                         uint8_t* d_err, uint8_t* d_skip)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (nreads < 0 || pitch <= 0 || (pitch & 15)) return fail(KBBQ_E_ARG, "kbbq_find_errors_dev: bad nreads/pitch");
+    if (nreads == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    K4Params p;
+    p.seq = d_seq; p.len = d_len; p.nreads = nreads; p.pitch = pitch;
+    p.ref_start = (const long long*)d_ref_start; p.ref_len = d_ref_len;
+    p.cig_off = d_cig_off; p.cig_n = d_cig_n; p.cigar = d_cigar;
+    p.genome = d_genome; p.skipmask = d_skipmask; p.flip = d_flip; p.err = d_err; p.skip = d_skip;
+    p.status = c->d_status;
+    int gx = (int)std::min<int64_t>((nreads + 255) / 256, (int64_t)c->cus * 8);
+    hipLaunchKernelGGL(k4_find_errors, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+int kbbq_count_q_dev(kbbq_ctx* c, const uint8_t* d_qual, const uint8_t* d_err, const uint8_t* d_skip,
+                     const uint32_t* d_len, int64_t nreads, int pitch, int qoffset, int64_t* d_counts512)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    int rc = check_planes("kbbq_count_q_dev", nreads, pitch, d_qual, d_err, d_skip);
+    if (rc) return rc;
+    if (nreads == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    K5Params p;
+    p.qual = d_qual; p.err = d_err; p.skip = d_skip; p.len = d_len; p.nreads = nreads; p.pitch = pitch;
+    p.cpr = pitch / 16; p.cpr_magic = magic_for(p.cpr); p.qoffset = qoffset;
+    p.counts = reinterpret_cast<u64*>(d_counts512); p.status = c->d_status;
+    const int64_t nchunks = nreads * p.cpr;
+    int gx = (int)std::min<int64_t>((nchunks + 255) / 256, (int64_t)c->cus * 8);
+    hipLaunchKernelGGL(k5_count_q, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
 // ---- host-buffer entry points: stage, run, fetch -------------------------
 struct DevBuf {
     void* p = nullptr;

@@ -517,3 +517,110 @@ __global__ __launch_bounds__(256) void k3_fill_full_lut(LutFillParams p)
     }
     if (bad) { atomicOr(p.flags, bad); atomicMin(&p.status[ST_LUT], 0ull); }
 }
+
+// ---------------------------------------------------------------- K4 / K5: benchmark path
+// (SURVEY.md 8(f) #1).  K4 restates compare_reads.find_read_errors (compare_reads.py:84-139):
+// a CIGAR walk that compares the read with the reference and marks sites to skip; K5 is the
+// two np.bincount calls of benchmark.calculate_q (benchmark.py:76-91) over the unskipped bases.
+struct K4Params {
+    const uint8_t* seq; const u32* len; long long nreads; int pitch;
+    const long long* ref_start;      // offset of reference_start in `genome` / `skipmask`
+    const int* ref_len;              // reference_end - reference_start (the read's reference window)
+    const u32* cig_off; const u32* cig_n; const u32* cigar;   // per read: first op, op count; ops = len << 4 | op
+    const uint8_t* genome; const uint8_t* skipmask; const uint8_t* flip;
+    uint8_t* err; uint8_t* skip; u64* status;
+};
+
+// One thread per read: the walk is sequential by definition (a deletion ORs into the base
+// written by the previous operation; Python's negative indices wrap: skips[-1], subset[-1]).
+__global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
+{
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < p.nreads;
+         r += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)p.len[r];
+        const int rl = p.ref_len[r];
+        const uint8_t* s = p.seq + (size_t)r * p.pitch;
+        uint8_t* e = p.err + (size_t)r * p.pitch;
+        uint8_t* k = p.skip + (size_t)r * p.pitch;
+        const uint8_t* g = p.genome + p.ref_start[r];
+        const uint8_t* v = p.skipmask + p.ref_start[r];
+        for (int i = 0; i < p.pitch; ++i) { e[i] = 0; k[i] = 0; }
+        int readidx = 0, refidx = 0;
+        const u32* ops = p.cigar + p.cig_off[r];
+        for (u32 c = 0; c < p.cig_n[r]; ++c) {
+            const int op = (int)(ops[c] & 15u), l = (int)(ops[c] >> 4);
+            if (op == 0 || op == 7 || op == 8) {                       // M = X  (:109-114)
+                if (refidx + l > rl || readidx + l > n) { flag(p.status, ST_RANGE, r); break; }   // shape mismatch: ValueError
+                for (int i = 0; i < l; ++i) {
+                    e[readidx + i] = g[refidx + i] != s[readidx + i];
+                    k[readidx + i] = v[refidx + i] != 0;
+                }
+                readidx += l; refidx += l;
+            } else if (op == 1) {                                      // I      (:115-120)
+                if (rl == 0 || refidx >= rl) { flag(p.status, ST_INDEX, r); break; }   // subset_variable[refidx]
+                const int left = refidx - 1 < 0 ? rl - 1 : refidx - 1;               // Python wraps index -1
+                const uint8_t both = (v[left] != 0) && (v[refidx] != 0);
+                for (int i = readidx; i < readidx + l && i < n; ++i) k[i] = both;
+                readidx += l;
+            } else if (op == 2 || op == 3) {                           // D N    (:121-125)
+                if (n == 0) { flag(p.status, ST_INDEX, r); break; }
+                const int at = readidx - 1 < 0 ? n + (readidx - 1) : readidx - 1;    // skips[-1]: the last base
+                if (at < 0 || at >= n) { flag(p.status, ST_INDEX, r); break; }
+                uint8_t any = 0;
+                for (int i = refidx; i < refidx + l && i < rl; ++i) any |= v[i] != 0;
+                k[at] = k[at] | any;
+                refidx += l;
+            } else if (op == 4) {                                      // S      (:126-129)
+                for (int i = readidx; i < readidx + l && i < n; ++i) k[i] = 1;
+                readidx += l;
+            } else if (op == 5 || op == 6) {                           // H P    (:130-134)
+            } else { flag(p.status, ST_RANGE, r); break; }             // unrecognised operation: ValueError
+        }
+        if (p.flip[r]) {                                               // benchmark.py:70-72
+            for (int i = 0, j = n - 1; i < j; ++i, --j) {
+                const uint8_t a = e[i]; e[i] = e[j]; e[j] = a;
+                const uint8_t b = k[i]; k[i] = k[j]; k[j] = b;
+            }
+        }
+    }
+}
+
+struct K5Params {
+    const uint8_t* qual; const uint8_t* err; const uint8_t* skip; const u32* len;
+    long long nreads; int pitch; int cpr; u32 cpr_magic; int qoffset;
+    u64* counts;                     // [0..255] totals, [256..511] errors
+    u64* status;
+};
+
+// lane <-> 16-byte chunk; LDS histograms (256 totals + 256 errors, u32) per workgroup
+__global__ __launch_bounds__(256) void k5_count_q(K5Params p)
+{
+    __shared__ u32 h[512];
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) h[i] = 0u;
+    __syncthreads();
+    const long long nchunks = p.nreads * p.cpr;
+    // a workgroup adds at most 2^31 counts into its u32 bins before flushing
+    for (long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks;
+         ch += (long long)gridDim.x * blockDim.x) {
+        const long long r = ch / p.cpr;
+        const int j = (int)(ch - r * p.cpr);
+        const int nb = (int)p.len[r] - 16 * j;
+        if (nb <= 0) continue;
+        const size_t off = (size_t)r * p.pitch + (size_t)16 * j;
+        const uint4 qv = *reinterpret_cast<const uint4*>(p.qual + off);
+        const uint4 ev = *reinterpret_cast<const uint4*>(p.err + off);
+        const uint4 sv = *reinterpret_cast<const uint4*>(p.skip + off);
+        const u32 q[4] = {qv.x, qv.y, qv.z, qv.w}, e[4] = {ev.x, ev.y, ev.z, ev.w}, s[4] = {sv.x, sv.y, sv.z, sv.w};
+        for (int i = 0; i < 16 && i < nb; ++i) {
+            const int sh = 8 * (i & 3);
+            if ((s[i >> 2] >> sh) & 0xFFu) continue;
+            const int qq = (int)((q[i >> 2] >> sh) & 0xFFu) - p.qoffset;
+            if (qq < 0) { flag(p.status, ST_RANGE, r); continue; }      // np.bincount rejects negative values: ValueError
+            atomicAdd(&h[qq], 1u);
+            if ((e[i >> 2] >> sh) & 0xFFu) atomicAdd(&h[256 + qq], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += blockDim.x)
+        if (h[i]) atomicAdd(&p.counts[i], (u64)h[i]);
+}

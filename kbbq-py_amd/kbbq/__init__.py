@@ -7,7 +7,7 @@ kbbq.gatk.applybqsr, kbbq.main); the per-base work runs in hand-written HIP
 kernels (libkbbq_hip.so, C ABI in include/kbbq_hip.h).  The benchmark / plot /
 GATK-report subsystems of the reference are out of scope.
 """
-__all__ = ['compare_reads', 'recalibrate', 'covariate', 'read', 'fastx']
+__all__ = ['compare_reads', 'recalibrate', 'covariate', 'read', 'fastx', 'benchmark', 'aln']
 __version__ = '0.0.0'
 
 from . import compare_reads

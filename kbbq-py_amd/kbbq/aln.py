@@ -1,0 +1,166 @@
+"""
+Text-format readers for the benchmark path (SAM, FASTA, VCF, BED) -- what the reference
+gets from pysam.AlignmentFile / FastaFile / VariantFile / tabix_iterator on that path
+(reference kbbq/benchmark.py:9-30,57-74,145-164).  pysam/htslib is not available here, so
+binary BAM / BCF / bgzip-indexed inputs are not read: convert with `samtools view -h`.
+Objects are duck-typed after pysam so code written against the reference keeps working.
+"""
+import gzip
+
+import numpy as np
+
+CIGAR_OPS = 'MIDNSHP=X'
+
+
+class AlignedRead:
+    """The pysam.AlignedSegment attributes the benchmark path uses."""
+
+    def __init__(self, line):
+        f = line.rstrip('\r\n').split('\t')
+        if len(f) < 11:
+            raise ValueError('not a SAM alignment line: %r' % line[:60])
+        self.query_name = f[0]
+        self.flag = int(f[1])
+        self.reference_name = f[2]
+        self.reference_start = int(f[3]) - 1
+        self.mapping_quality = int(f[4])
+        self.cigarstring = f[5]
+        self.cigartuples = parse_cigar(f[5])
+        self.query_sequence = f[9]
+        self.query_qualities = [ord(c) - 33 for c in f[10]] if f[10] != '*' else None
+        self.tags = {}
+        for t in f[11:]:
+            k, ty, v = t.split(':', 2)
+            self.tags[k] = int(v) if ty == 'i' else v
+        self._line = line.rstrip('\r\n')
+
+    @classmethod
+    def fromstring(cls, line, header=None):
+        return cls(line)
+
+    @property
+    def query_length(self):
+        return len(self.query_sequence)
+
+    @property
+    def reference_end(self):
+        return self.reference_start + sum(l for op, l in self.cigartuples if op in (0, 2, 3, 7, 8))
+
+    is_paired = property(lambda self: bool(self.flag & 1))
+    is_reverse = property(lambda self: bool(self.flag & 16))
+    is_read1 = property(lambda self: bool(self.flag & 64))
+    is_read2 = property(lambda self: bool(self.flag & 128))
+
+    def get_tag(self, k):
+        return self.tags[k]
+
+    def has_tag(self, k):
+        return k in self.tags
+
+    def set_tag(self, k, v):
+        self.tags[k] = v
+
+    def __str__(self):
+        return self._line
+
+
+def parse_cigar(text):
+    if text == '*':
+        return []
+    out, num = [], ''
+    for ch in text:
+        if ch.isdigit():
+            num += ch
+        else:
+            out.append((CIGAR_OPS.index(ch), int(num))); num = ''
+    return out
+
+
+def _open(path):
+    return gzip.open(path, 'rt') if str(path).endswith('.gz') else open(path, 'r')
+
+
+class AlignmentFile:
+    """Iterable of AlignedRead from a SAM text file (mode is accepted and ignored)."""
+
+    def __init__(self, path, mode='r'):
+        with open(path, 'rb') as fh:
+            if fh.read(4) in (b'BAM\x01', b'\x1f\x8b\x08\x04'):
+                raise NotImplementedError('binary BAM needs htslib; convert with `samtools view -h`')
+        self.header = []
+        self._reads = []
+        with _open(path) as fh:
+            for line in fh:
+                if line.startswith('@'):
+                    self.header.append(line.rstrip('\n'))
+                elif line.strip():
+                    self._reads.append(AlignedRead(line))
+
+    def __iter__(self):
+        return iter(self._reads)
+
+    def __len__(self):
+        return len(self._reads)
+
+
+class FastaFile:
+    def __init__(self, path):
+        seqs, name = {}, None
+        with _open(path) as fh:
+            for line in fh:
+                line = line.rstrip('\r\n')
+                if line.startswith('>'):
+                    name = line[1:].split()[0]; seqs[name] = []
+                elif name is not None:
+                    seqs[name].append(line)
+        self._seqs = {k: ''.join(v) for k, v in seqs.items()}
+        self.references = list(self._seqs)
+
+    def fetch(self, reference=None):
+        return self._seqs[reference]
+
+
+class VariantRecord:
+    def __init__(self, chrom, start, stop):
+        self.chrom, self.start, self.stop = chrom, start, stop
+
+
+def read_vcf(path):
+    """Records with pysam's 0-based half-open (start, stop) = (POS - 1, POS - 1 + len(REF))."""
+    with _open(path) as fh:
+        for line in fh:
+            if line.startswith('#') or not line.strip():
+                continue
+            f = line.split('\t')
+            start = int(f[1]) - 1
+            yield VariantRecord(f[0], start, start + len(f[3]))
+
+
+class BedRecord:
+    def __init__(self, contig, start, end):
+        self.contig, self.start, self.end = contig, start, end
+
+
+def read_bed(fh):
+    """BED intervals from an OPEN text handle (the reference passes argparse's file object)."""
+    for line in fh:
+        if line.strip() and not line.startswith(('#', 'track', 'browser')):
+            f = line.split()
+            yield BedRecord(f[0], int(f[1]), int(f[2]))
+
+
+def chars(text):
+    """'ACGT' -> array(['A','C','G','T'], dtype='<U1') without a Python list."""
+    return np.frombuffer(text.encode('ascii'), dtype=np.uint8).astype(np.uint32).view('U1')
+
+
+def codes(arr):
+    """Array of 1-character strings (or bytes / str) -> uint8 character codes."""
+    if isinstance(arr, (bytes, bytearray)):
+        return np.frombuffer(bytes(arr), dtype=np.uint8)
+    if isinstance(arr, str):
+        return np.frombuffer(arr.encode('ascii'), dtype=np.uint8)
+    arr = np.asarray(arr)
+    if arr.dtype.kind == 'U':
+        return np.ascontiguousarray(arr).view(np.uint32).astype(np.uint8)
+    return arr.astype(np.uint8)

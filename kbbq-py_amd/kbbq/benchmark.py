@@ -1,0 +1,252 @@
+"""
+kbbq.benchmark -- truth-set calibration benchmark (reference kbbq/benchmark.py:9-164) with the
+per-base work on the MI355X: the CIGAR walk that flags errors and skipped sites
+(compare_reads.find_read_errors, K4) and the per-quality counting (calculate_q, K5).
+Reference genome, variant sites and confident regions are read from TEXT formats
+(kbbq/aln.py); the small per-genome set-up (skip mask) is host NumPy as in the reference.
+"""
+import numpy as np
+
+from . import aln
+from . import compare_reads
+from . import fastx
+
+
+def get_ref_dict(reffilename):
+    """{contig: array of 1-character strings} for every contig of the FASTA."""
+    fasta = aln.FastaFile(reffilename)
+    return {chrom: aln.chars(fasta.fetch(reference=chrom)) for chrom in fasta.references}
+
+
+def get_var_sites(vcf):
+    """{contig: [0-based positions covered by any record]}."""
+    d = dict()
+    for record in aln.read_vcf(vcf):
+        d.setdefault(record.chrom, list()).extend(range(record.start, record.stop))
+    return d
+
+
+def get_bed_dict(refdict, bedfh):
+    beddict = {chrom: np.zeros(len(refdict[chrom]), dtype=bool) for chrom in refdict.keys()}
+    for rec in aln.read_bed(bedfh):
+        beddict[rec.contig][rec.start:rec.end] = True
+    return beddict
+
+
+def get_full_skips(refdict, var_sites, bedfh=None):
+    """Boolean skip mask per contig: variant sites, plus everything outside the BED if given."""
+    skips = {chrom: np.zeros(len(refdict[chrom]), dtype=bool) for chrom in refdict.keys()}
+    for chrom in skips.keys():
+        skips[chrom][np.array(var_sites[chrom], dtype=np.int_)] = True
+    if bedfh is not None:
+        beddict = get_bed_dict(refdict, bedfh)
+        for chrom in skips.keys():
+            skips[chrom][~beddict[chrom]] = True
+    return skips
+
+
+def get_bam_readname(read):
+    return read.query_name + ("/2" if read.is_read2 else "/1")
+
+
+def get_fastq_readname(read):
+    return read.name.split(sep='_')[0]
+
+
+# ---------------------------------------------------------------------------
+# device batch
+# ---------------------------------------------------------------------------
+class _Genome:
+    """Concatenated contigs + skip mask on the device (uploaded once per benchmark call)."""
+
+    def __init__(self, refdict, fullskips):
+        from . import _device as dev
+        torch = dev._torch()
+        self.offset, parts, masks, pos = {}, [], [], 0
+        for chrom, arr in refdict.items():
+            self.offset[chrom] = pos
+            parts.append(aln.codes(arr)); masks.append(np.asarray(fullskips[chrom], dtype=np.uint8))
+            pos += len(arr)
+        self.length = pos
+        cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, dtype=np.uint8)
+        self.genome = torch.from_numpy(np.ascontiguousarray(cat(parts))).cuda()
+        self.mask = torch.from_numpy(np.ascontiguousarray(cat(masks))).cuda()
+        self.sizes = {c: len(a) for c, a in refdict.items()}
+
+
+def _flag_batch(reads, genome, flip_reverse):
+    """K4 over a list of aligned reads -> (err, skip) device planes [n, pitch], lens (host)."""
+    from . import _device as dev
+    from . import _native as N
+    torch = dev._torch()
+    n = len(reads)
+    lens = np.array([len(r.query_sequence) for r in reads], dtype=np.uint32)
+    pitch = fastx.pitch_for(int(lens.max()) if n else 1)
+    seq = np.zeros((max(n, 1), pitch), dtype=np.uint8)
+    ref_start = np.zeros(max(n, 1), dtype=np.int64); ref_len = np.zeros(max(n, 1), dtype=np.int32)
+    cig_off = np.zeros(max(n, 1), dtype=np.uint32); cig_n = np.zeros(max(n, 1), dtype=np.uint32)
+    flip = np.zeros(max(n, 1), dtype=np.uint8)
+    cigar = []
+    for i, r in enumerate(reads):
+        seq[i, :lens[i]] = aln.codes(r.query_sequence)
+        size = genome.sizes[r.reference_name]                      # KeyError: unknown contig, as in the reference
+        start = min(max(r.reference_start, 0), size)               # Python slice clamping of the reference window
+        end = min(max(r.reference_end, start), size)
+        ref_start[i] = genome.offset[r.reference_name] + start
+        ref_len[i] = end - start
+        cig_off[i] = len(cigar); cig_n[i] = len(r.cigartuples)
+        for op, l in r.cigartuples:
+            code = op if isinstance(op, (int, np.integer)) and 0 <= op <= 8 else 15   # 15: unrecognised -> ValueError
+            cigar.append((int(l) << 4) | int(code))
+        flip[i] = 1 if (flip_reverse and r.is_reverse) else 0
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_seq, d_len = up(seq), up(lens.view(np.int32) if n else np.zeros(1, np.int32))
+    d_cigar = up(np.array(cigar if cigar else [0], dtype=np.uint32).view(np.int32))
+    err = torch.zeros((max(n, 1), pitch), dtype=torch.uint8, device='cuda')
+    skip = torch.zeros((max(n, 1), pitch), dtype=torch.uint8, device='cuda')
+    ctx = dev.context()
+    # keep every device tensor referenced until the kernel has run (N.ptr only takes the address)
+    d_rs, d_rl, d_flip = up(ref_start), up(ref_len), up(flip)
+    d_co, d_cn = up(cig_off.view(np.int32)), up(cig_n.view(np.int32))
+    N.check(N.load().kbbq_find_errors_dev(ctx.handle, N.ptr(d_seq), N.ptr(d_len), n, pitch,
+                                          N.ptr(d_rs), N.ptr(d_rl), N.ptr(d_co), N.ptr(d_cn),
+                                          N.ptr(d_cigar), N.ptr(genome.genome), N.ptr(genome.mask),
+                                          N.ptr(d_flip), N.ptr(err), N.ptr(skip)))
+    ctx.status()
+    return err, skip, lens, pitch
+
+
+def _count_q(qual, err, skip, lens, pitch, qoffset):
+    """K5 -> (numerrs[256], numtotal[256]) as int64 host arrays."""
+    from . import _device as dev
+    from . import _native as N
+    torch = dev._torch()
+    n = len(lens)
+    counts = torch.zeros(512, dtype=torch.int64, device='cuda')
+    d_len = torch.from_numpy(np.ascontiguousarray(lens.astype(np.uint32)).view(np.int32)).cuda() if n else torch.zeros(1, dtype=torch.int32, device='cuda')
+    ctx = dev.context()
+    N.check(N.load().kbbq_count_q_dev(ctx.handle, N.ptr(qual), N.ptr(err), N.ptr(skip), N.ptr(d_len),
+                                      n, pitch, qoffset, N.ptr(counts)))
+    ctx.status()
+    h = counts.cpu().numpy()
+    return h[256:].copy(), h[:256].copy()
+
+
+def _actual_q(numerrs, numtotal):
+    """benchmark.py:83-91 from the two count vectors (trimmed to the largest observed quality)."""
+    top = np.flatnonzero(numtotal)
+    size = int(top[-1]) + 1 if top.size else 0
+    numtotal, numerrs = numtotal[:size], numerrs[:size]
+    nonzero = numtotal != 0
+    q = compare_reads.p_to_q(np.true_divide(numerrs[nonzero], numtotal[nonzero]))
+    actual_q = np.zeros(len(numtotal), dtype=np.int_)
+    actual_q[nonzero] = q
+    return actual_q, numtotal.astype(np.int_)
+
+
+def get_error_dict(bamfile, refdict, fullskips):
+    """{canonical read name: (errors, skips)} -- flags of reverse-strand reads flipped, because a
+    FASTQ made from the BAM holds them reverse-complemented."""
+    reads = list(bamfile)
+    genome = _Genome(refdict, fullskips)
+    err, skip, lens, _ = _flag_batch(reads, genome, flip_reverse=True)
+    e, s = err.cpu().numpy().astype(bool), skip.cpu().numpy().astype(bool)
+    return {get_bam_readname(r): (e[i, :lens[i]].copy(), s[i, :lens[i]].copy()) for i, r in enumerate(reads)}
+
+
+def calculate_q(errors, quals):
+    """(actual_q, numtotal) indexed by predicted quality, from flat arrays (reference
+    benchmark.py:76-91).  The two bincounts run on the device (K5)."""
+    from . import _device as dev
+    torch = dev._torch()
+    errors = np.asarray(errors, dtype=bool).reshape(-1)
+    quals = np.asarray(quals).reshape(-1)
+    if quals.size and (quals.min() < 0 or quals.max() > 255):
+        raise ValueError('qualities must lie in 0..255')
+    n = quals.size
+    pitch = fastx.pitch_for(max(n, 1))
+    if pitch > 65536:                      # long flat input: fold into rows of 4096
+        pitch = 4096
+    rows = max(1, -(-n // pitch))
+    q = np.zeros(rows * pitch, dtype=np.uint8); q[:n] = quals
+    e = np.zeros(rows * pitch, dtype=np.uint8); e[:n] = errors
+    lens = np.full(rows, pitch, dtype=np.uint32); lens[-1] = n - (rows - 1) * pitch
+    up = lambda a: torch.from_numpy(a.reshape(rows, pitch)).cuda()
+    d_q, d_e = up(q), up(e)
+    d_s = torch.zeros((rows, pitch), dtype=torch.uint8, device='cuda')
+    numerrs, numtotal = _count_q(d_q, d_e, d_s, lens, pitch, 0)
+    return _actual_q(numerrs, numtotal)
+
+
+def get_bamread_quals(read, use_oq=False):
+    if use_oq:
+        return np.array([ord(c) - 33 for c in read.get_tag('OQ')], dtype=np.int_)
+    return np.array(read.query_qualities, dtype=np.int_)
+
+
+def _qual_plane(reads, lens, pitch, use_oq):
+    q = np.zeros((max(len(reads), 1), pitch), dtype=np.uint8)
+    for i, r in enumerate(reads):
+        v = get_bamread_quals(r, use_oq)
+        if len(v) != lens[i]:
+            raise IndexError('boolean index did not match indexed array: read %d has %d qualities for %d bases'
+                             % (i, len(v), lens[i]))
+        if v.size and (v.min() < 0 or v.max() > 255):
+            raise ValueError('qualities must lie in 0..255')
+        q[i, :lens[i]] = v
+    return q
+
+
+def benchmark_bam(bamfile, ref, var_sites, use_oq=False, bedfh=None):
+    from . import _device as dev
+    torch = dev._torch()
+    fullskips = get_full_skips(ref, var_sites, bedfh)
+    reads = list(bamfile)
+    err, skip, lens, pitch = _flag_batch(reads, _Genome(ref, fullskips), flip_reverse=False)
+    qual = torch.from_numpy(_qual_plane(reads, lens, pitch, use_oq)).cuda()
+    return _actual_q(*_count_q(qual, err, skip, lens, pitch, 0))
+
+
+def benchmark_fastq(fqfile, bamfile, ref, var_sites, bedfh=None):
+    from . import _device as dev
+    torch = dev._torch()
+    fullskips = get_full_skips(ref, var_sites, bedfh)
+    reads = list(bamfile)
+    err, skip, lens, pitch = _flag_batch(reads, _Genome(ref, fullskips), flip_reverse=True)
+    row = {}
+    for i, r in enumerate(reads):
+        row[get_bam_readname(r)] = i                                 # later reads replace earlier ones (dict)
+    fq = fastx.NativeFastq(fqfile)
+    idx = np.array([row[fq.name(i).split('_')[0]] for i in range(fq.n)], dtype=np.int64)   # KeyError if absent
+    n, S, _, kind, bad = fq.scan(None, False)
+    _, _, fqual, fmeta = fq.fill(None, False, fq.n, max(pitch, fastx.pitch_for(S)))
+    flens = (fmeta & 0xFFFF).astype(np.uint32)
+    if np.any(flens != lens[idx]):
+        raise IndexError('boolean index did not match indexed array: FASTQ and BAM read lengths differ')
+    d_idx = torch.from_numpy(idx).cuda()
+    fp = fqual.shape[1]
+    e = torch.zeros((max(fq.n, 1), fp), dtype=torch.uint8, device='cuda'); s = torch.zeros_like(e)
+    if fq.n:
+        e[:fq.n, :pitch] = err.index_select(0, d_idx); s[:fq.n, :pitch] = skip.index_select(0, d_idx)
+    return _actual_q(*_count_q(torch.from_numpy(fqual).cuda(), e, s, flens, fp, 33))
+
+
+def print_benchmark(actual_q, label, nbases):
+    """Tab-separated rows: predicted quality, actual quality, label, number of bases."""
+    nonzero = (nbases != 0)
+    for pq, aq, nb in zip(np.arange(len(actual_q))[nonzero], actual_q[nonzero], nbases[nonzero]):
+        print(pq, aq, label, nb, sep="\t")
+
+
+def benchmark(bamfile, fafile, vcffile, fastqfile=None, label=None, use_oq=False, bedfh=None):
+    """Run the benchmark and print it.  With a FASTQ, its reads are matched to the alignments by name."""
+    bam = aln.AlignmentFile(bamfile, 'r')
+    ref = get_ref_dict(fafile)
+    var_sites = get_var_sites(vcffile)
+    if fastqfile is not None:
+        actual_q, nbases = benchmark_fastq(fastqfile, bam, ref, var_sites, bedfh)
+        label = (fastqfile if label is None else label)
+    else:
+        actual_q, nbases = benchmark_bam(bam, ref, var_sites, use_oq, bedfh)
+        label = (bamfile if label is None else label)
+    print_benchmark(actual_q, label, nbases)

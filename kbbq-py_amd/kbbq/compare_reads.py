@@ -22,6 +22,22 @@ from . import _native as N
 _MAXSCORE = 42
 
 
+def find_read_errors(read, ref, variable):
+    """(errors, skips) of one aligned read from its CIGAR (reference compare_reads.py:84-139):
+    M/=/X compare with the reference and take the site mask, insertions are skipped when both
+    flanking sites are, deletions / N mark the previous base when they cover a masked site, soft
+    clips are skipped; indels are not counted as errors.  Runs on the device (K4)."""
+    from . import benchmark as _bm
+    chrom = read.reference_name
+    g = _bm._Genome({chrom: ref[chrom]}, {chrom: variable[chrom]})
+    for op, _ in read.cigartuples:
+        if not (isinstance(op, (int, np.integer)) and 0 <= op <= 8):
+            raise ValueError("Unrecognized Cigar Operation " + str(op) + " In Read\n" + str(read))
+    err, skip, lens, _ = _bm._flag_batch([read], g, flip_reverse=False)
+    L = int(lens[0])
+    return err[0, :L].cpu().numpy().astype(bool), skip[0, :L].cpu().numpy().astype(bool)
+
+
 class RescaledNormal:
     """Cached log-prior of the Bayesian delta-Q model: a normal density over the
     quality-score difference d, sigma = 0.5, rescaled to 0.9 at d = 0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """
 kbbq command line -- the `recalibrate` sub-command of the reference CLI
-(reference kbbq/main.py:26-89).  `benchmark` and `plot` are out of scope here.
+and the `benchmark` sub-command (reference kbbq/main.py:26-89).  `plot` is out of scope here.
 """
 import argparse
 
@@ -12,6 +12,12 @@ from . import recalibrate as _recal
 def recalibrate(args):
     _recal.recalibrate(bam=args.bam, fastq=args.fastq, infer_rg=args.infer_rg,
                        use_oq=args.use_oq, set_oq=args.set_oq, gatkreport=args.gatkreport)
+
+
+def benchmark(args):
+    from . import benchmark as _bm
+    _bm.benchmark(bamfile=args.bam, fafile=args.reference, vcffile=args.vcf, fastqfile=args.fastq,
+                  label=args.label, use_oq=args.use_oq, bedfh=args.bedfile)
 
 
 def main():
@@ -35,6 +41,19 @@ def main():
     rp.add_argument('--infer-rg', action='store_true',
                     help='Infer the read group from the FASTQ read name (name_RG:Z:id).')
     rp.set_defaults(command=recalibrate)
+
+    bp = sub.add_parser('benchmark', description='Benchmark a SAM or FASTQ file using a truth set')
+    req = bp.add_argument_group(title='required arguments')
+    req.add_argument('-b', '--bam', required=True,
+                     help='Truth set alignments (SAM text). Differences from the reference at nonvariable sites are errors.')
+    req.add_argument('-r', '--reference', required=True, help='FASTA file containing the reference genome')
+    req.add_argument('-v', '--vcf', required=True, help='VCF file containing variable sites')
+    bp.add_argument('-f', '--fastq', default=None, help='fastq file to benchmark')
+    bp.add_argument('-l', '--label', default=None, help='label to use for label column')
+    bp.add_argument('-u', '--use-oq', action='store_true', help='Use the OQ tag for quality scores')
+    bp.add_argument('-d', '--bedfile', type=argparse.FileType('r'),
+                    help='BED file of confident regions. Sites outside the given regions will be skipped.')
+    bp.set_defaults(command=benchmark)
 
     args = parser.parse_args()
     args.command(args)
