@@ -191,6 +191,8 @@ int    kbbq_solve_dev(kbbq_ctx* ctx, const int64_t* d_tables, int R, int S2, int
  * (skip mask = benchmark.get_full_skips, benchmark.py:22-39); cigar ops are
  * (length << 4 | op) with BAM op codes.  Outputs one byte per base (0 / 1) in the err and
  * skip planes; flip[r] != 0 reverses both for reverse-strand reads (benchmark.py:70-72).
+ * All buffers 16-byte aligned; seq, genome and skipmask need 32 readable bytes of slack past
+ * their last byte (unaligned 16-byte windows are fetched as two aligned loads).
  * Python's negative-index wraps of the reference (skips[-1], subset[-1]) are reproduced;
  * its IndexError / ValueError cases arrive through kbbq_ctx_status as KBBQ_E_INDEX /
  * KBBQ_E_RANGE.

@@ -609,7 +609,10 @@ int kbbq_find_errors_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint32_t* d_le
     p.cig_off = d_cig_off; p.cig_n = d_cig_n; p.cigar = d_cigar;
     p.genome = d_genome; p.skipmask = d_skipmask; p.flip = d_flip; p.err = d_err; p.skip = d_skip;
     p.status = c->d_status;
-    int gx = (int)std::min<int64_t>((nreads + 255) / 256, (int64_t)c->cus * 8);
+    if (((uintptr_t)d_seq | (uintptr_t)d_genome | (uintptr_t)d_skipmask | (uintptr_t)d_err | (uintptr_t)d_skip) & 15)
+        return fail(KBBQ_E_ARG, "kbbq_find_errors_dev: buffers must be 16-byte aligned");
+    const int64_t nchunks4 = nreads * (pitch / 16);
+    int gx = (int)std::min<int64_t>((nchunks4 + 255) / 256, (int64_t)c->cus * 16);
     hipLaunchKernelGGL(k4_find_errors, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;

@@ -531,57 +531,142 @@ struct K4Params {
     uint8_t* err; uint8_t* skip; u64* status;
 };
 
-// One thread per read: the walk is sequential by definition (a deletion ORs into the base
-// written by the previous operation; Python's negative indices wrap: skips[-1], subset[-1]).
+// 16 bytes starting at any byte offset of a 16-byte-aligned array (two aligned loads + a byte
+// funnel shift).  The caller guarantees 32 readable bytes past the last byte it asks for.
+__device__ __forceinline__ void load16_any(const uint8_t* base, long long off, u32 out[4])
+{
+    const uint4* p = reinterpret_cast<const uint4*>(base + (off & ~15ll));
+    const uint4 lo = p[0], hi = p[1];
+    const int ws = (int)(off & 15) >> 2;                 // whole words to drop
+    const u32 bs = ((u32)off & 3u) * 8u;                 // then bits
+    u32 w0 = lo.x, w1 = lo.y, w2 = lo.z, w3 = lo.w, w4 = hi.x, w5 = hi.y, w6 = hi.z, w7 = hi.w;
+    u32 a0 = ws == 0 ? w0 : ws == 1 ? w1 : ws == 2 ? w2 : w3;
+    u32 a1 = ws == 0 ? w1 : ws == 1 ? w2 : ws == 2 ? w3 : w4;
+    u32 a2 = ws == 0 ? w2 : ws == 1 ? w3 : ws == 2 ? w4 : w5;
+    u32 a3 = ws == 0 ? w3 : ws == 1 ? w4 : ws == 2 ? w5 : w6;
+    u32 a4 = ws == 0 ? w4 : ws == 1 ? w5 : ws == 2 ? w6 : w7;
+    out[0] = __builtin_amdgcn_alignbit(a1, a0, bs);
+    out[1] = __builtin_amdgcn_alignbit(a2, a1, bs);
+    out[2] = __builtin_amdgcn_alignbit(a3, a2, bs);
+    out[3] = __builtin_amdgcn_alignbit(a4, a3, bs);
+}
+
+// 0x01 in every byte of x that is non-zero
+__device__ __forceinline__ u32 nonzero_bytes(u32 x)
+{
+    return ((x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u;
+}
+
+__device__ __forceinline__ void set_byte(u32 v[4], int i, u32 val)      // i in 0..15, slow paths only
+{
+    const u32 m = 0xFFu << (8 * (i & 3)), x = (val & 0xFFu) << (8 * (i & 3));
+    v[0] = (i >> 2) == 0 ? (v[0] & ~m) | x : v[0];
+    v[1] = (i >> 2) == 1 ? (v[1] & ~m) | x : v[1];
+    v[2] = (i >> 2) == 2 ? (v[2] & ~m) | x : v[2];
+    v[3] = (i >> 2) == 3 ? (v[3] & ~m) | x : v[3];
+}
+
+__device__ __forceinline__ u32 get_byte(const u32 v[4], int i)
+{
+    const u32 w = (i >> 2) == 0 ? v[0] : (i >> 2) == 1 ? v[1] : (i >> 2) == 2 ? v[2] : v[3];
+    return (w >> (8 * (i & 3))) & 0xFFu;
+}
+
+// lane <-> one 16-byte OUTPUT chunk of one read.  The lane walks the read's (short) CIGAR in
+// order and applies every operation's effect to its own 16 positions in that order, which is
+// exactly the reference's sequential semantics (an M assigns, a later D/N ORs into the base
+// before it, Python's index -1 wraps: skips[-1], subset[-1]).  A chunk that lies wholly inside
+// one M/=/X operation -- the common case -- is 16 bytes of read against 16 bytes of reference
+// and of the site mask (unaligned windows: two aligned loads + funnel shift), compared
+// byte-parallel.  For reverse-strand reads the OUTPUT is reversed (benchmark.py:70-72): the
+// lane's input positions are then [n-16j-16, n-16j) and its 16 result bytes are byte-reversed.
+// seq / genome / skipmask need 32 readable bytes of slack past their last byte.
 __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
 {
-    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < p.nreads;
-         r += (long long)gridDim.x * blockDim.x) {
+    const int cpr = p.pitch >> 4;
+    const long long nchunks = p.nreads * cpr;
+    for (long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks;
+         ch += (long long)gridDim.x * blockDim.x) {
+        const long long r = ch / cpr;
+        const int j = (int)(ch - r * cpr);
         const int n = (int)p.len[r];
         const int rl = p.ref_len[r];
-        const uint8_t* s = p.seq + (size_t)r * p.pitch;
-        uint8_t* e = p.err + (size_t)r * p.pitch;
-        uint8_t* k = p.skip + (size_t)r * p.pitch;
-        const uint8_t* g = p.genome + p.ref_start[r];
-        const uint8_t* v = p.skipmask + p.ref_start[r];
-        for (int i = 0; i < p.pitch; ++i) { e[i] = 0; k[i] = 0; }
-        int readidx = 0, refidx = 0;
-        const u32* ops = p.cigar + p.cig_off[r];
-        for (u32 c = 0; c < p.cig_n[r]; ++c) {
-            const int op = (int)(ops[c] & 15u), l = (int)(ops[c] >> 4);
-            if (op == 0 || op == 7 || op == 8) {                       // M = X  (:109-114)
-                if (refidx + l > rl || readidx + l > n) { flag(p.status, ST_RANGE, r); break; }   // shape mismatch: ValueError
-                for (int i = 0; i < l; ++i) {
-                    e[readidx + i] = g[refidx + i] != s[readidx + i];
-                    k[readidx + i] = v[refidx + i] != 0;
+        const bool f = p.flip[r] != 0;
+        u32 ev[4] = {0u, 0u, 0u, 0u}, kv[4] = {0u, 0u, 0u, 0u};
+        const int out_lo = 16 * j, out_hi = out_lo + 16 < n ? out_lo + 16 : n;
+        if (out_lo < n) {
+            const int cnt = out_hi - out_lo;
+            const int in_lo = f ? n - out_hi : out_lo;            // input (unflipped) positions [in_lo, in_lo + cnt)
+            const int in_hi = in_lo + cnt;
+            const uint8_t* s = p.seq + (size_t)r * p.pitch;
+            const long long g0 = p.ref_start[r];
+            int readidx = 0, refidx = 0;
+            const u32* ops = p.cigar + p.cig_off[r];
+            const u32 nc = p.cig_n[r];
+            for (u32 c = 0; c < nc; ++c) {
+                const int op = (int)(ops[c] & 15u), l = (int)(ops[c] >> 4);
+                if (op == 0 || op == 7 || op == 8) {                       // M = X  (:109-114)
+                    if (refidx + l > rl || readidx + l > n) { flag(p.status, ST_RANGE, r); break; }   // shape mismatch: ValueError
+                    const int a = readidx > in_lo ? readidx : in_lo, b = readidx + l < in_hi ? readidx + l : in_hi;
+                    if (a < b) {
+                        const long long roff = g0 + refidx + (a - readidx);
+                        if (b - a == 16) {                                 // the whole chunk inside this operation
+                            u32 sw[4], gw[4], mw[4];
+                            load16_any(s, a, sw);
+                            load16_any(p.genome, roff, gw);
+                            load16_any(p.skipmask, roff, mw);
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) { ev[w] = nonzero_bytes(sw[w] ^ gw[w]); kv[w] = nonzero_bytes(mw[w]); }
+                        } else {
+                            for (int q = a; q < b; ++q) {
+                                set_byte(ev, q - in_lo, p.genome[roff + (q - a)] != s[q] ? 1u : 0u);
+                                set_byte(kv, q - in_lo, p.skipmask[roff + (q - a)] != 0 ? 1u : 0u);
+                            }
+                        }
+                    }
+                    readidx += l; refidx += l;
+                } else if (op == 1) {                                      // I      (:115-120)
+                    if (rl == 0 || refidx >= rl) { flag(p.status, ST_INDEX, r); break; }   // subset_variable[refidx]
+                    const int left = refidx - 1 < 0 ? rl - 1 : refidx - 1;               // Python wraps index -1
+                    const u32 both = (p.skipmask[g0 + left] != 0 && p.skipmask[g0 + refidx] != 0) ? 1u : 0u;
+                    const int a = readidx > in_lo ? readidx : in_lo, b = readidx + l < in_hi ? readidx + l : in_hi;
+                    for (int q = a; q < b; ++q) set_byte(kv, q - in_lo, both);
+                    readidx += l;
+                } else if (op == 2 || op == 3) {                           // D N    (:121-125)
+                    if (n == 0) { flag(p.status, ST_INDEX, r); break; }
+                    const int at = readidx - 1 < 0 ? n + (readidx - 1) : readidx - 1;    // skips[-1]: the last base
+                    if (at < 0 || at >= n) { flag(p.status, ST_INDEX, r); break; }
+                    if (at >= in_lo && at < in_hi) {
+                        u32 any = 0u;
+                        for (int i = refidx; i < refidx + l && i < rl; ++i) any |= p.skipmask[g0 + i];
+                        set_byte(kv, at - in_lo, get_byte(kv, at - in_lo) | (any ? 1u : 0u));
+                    }
+                    refidx += l;
+                } else if (op == 4) {                                      // S      (:126-129)
+                    const int a = readidx > in_lo ? readidx : in_lo, b = readidx + l < in_hi ? readidx + l : in_hi;
+                    for (int q = a; q < b; ++q) set_byte(kv, q - in_lo, 1u);
+                    readidx += l;
+                } else if (op == 5 || op == 6) {                           // H P    (:130-134)
+                } else { flag(p.status, ST_RANGE, r); break; }             // unrecognised operation: ValueError
+            }
+            if (f) {                                                       // output byte i = input byte cnt-1-i
+                if (cnt == 16) {
+                    const u32 e0 = ev[0], e1 = ev[1], e2 = ev[2], e3 = ev[3], k0 = kv[0], k1 = kv[1], k2 = kv[2], k3 = kv[3];
+                    ev[0] = __builtin_amdgcn_perm(0u, e3, 0x00010203u); ev[1] = __builtin_amdgcn_perm(0u, e2, 0x00010203u);
+                    ev[2] = __builtin_amdgcn_perm(0u, e1, 0x00010203u); ev[3] = __builtin_amdgcn_perm(0u, e0, 0x00010203u);
+                    kv[0] = __builtin_amdgcn_perm(0u, k3, 0x00010203u); kv[1] = __builtin_amdgcn_perm(0u, k2, 0x00010203u);
+                    kv[2] = __builtin_amdgcn_perm(0u, k1, 0x00010203u); kv[3] = __builtin_amdgcn_perm(0u, k0, 0x00010203u);
+                } else {
+                    u32 e2v[4] = {0u, 0u, 0u, 0u}, k2v[4] = {0u, 0u, 0u, 0u};
+                    for (int i = 0; i < cnt; ++i) { set_byte(e2v, i, get_byte(ev, cnt - 1 - i)); set_byte(k2v, i, get_byte(kv, cnt - 1 - i)); }
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { ev[w] = e2v[w]; kv[w] = k2v[w]; }
                 }
-                readidx += l; refidx += l;
-            } else if (op == 1) {                                      // I      (:115-120)
-                if (rl == 0 || refidx >= rl) { flag(p.status, ST_INDEX, r); break; }   // subset_variable[refidx]
-                const int left = refidx - 1 < 0 ? rl - 1 : refidx - 1;               // Python wraps index -1
-                const uint8_t both = (v[left] != 0) && (v[refidx] != 0);
-                for (int i = readidx; i < readidx + l && i < n; ++i) k[i] = both;
-                readidx += l;
-            } else if (op == 2 || op == 3) {                           // D N    (:121-125)
-                if (n == 0) { flag(p.status, ST_INDEX, r); break; }
-                const int at = readidx - 1 < 0 ? n + (readidx - 1) : readidx - 1;    // skips[-1]: the last base
-                if (at < 0 || at >= n) { flag(p.status, ST_INDEX, r); break; }
-                uint8_t any = 0;
-                for (int i = refidx; i < refidx + l && i < rl; ++i) any |= v[i] != 0;
-                k[at] = k[at] | any;
-                refidx += l;
-            } else if (op == 4) {                                      // S      (:126-129)
-                for (int i = readidx; i < readidx + l && i < n; ++i) k[i] = 1;
-                readidx += l;
-            } else if (op == 5 || op == 6) {                           // H P    (:130-134)
-            } else { flag(p.status, ST_RANGE, r); break; }             // unrecognised operation: ValueError
-        }
-        if (p.flip[r]) {                                               // benchmark.py:70-72
-            for (int i = 0, j = n - 1; i < j; ++i, --j) {
-                const uint8_t a = e[i]; e[i] = e[j]; e[j] = a;
-                const uint8_t b = k[i]; k[i] = k[j]; k[j] = b;
             }
         }
+        const size_t off = (size_t)r * p.pitch + (size_t)16 * j;
+        *reinterpret_cast<uint4*>(p.err + off) = make_uint4(ev[0], ev[1], ev[2], ev[3]);
+        *reinterpret_cast<uint4*>(p.skip + off) = make_uint4(kv[0], kv[1], kv[2], kv[3]);
     }
 }
 

@@ -68,7 +68,8 @@ class _Genome:
             parts.append(aln.codes(arr)); masks.append(np.asarray(fullskips[chrom], dtype=np.uint8))
             pos += len(arr)
         self.length = pos
-        cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, dtype=np.uint8)
+        slack = np.zeros(32, dtype=np.uint8)            # K4 fetches unaligned 16-byte windows as two aligned loads
+        cat = lambda xs: np.concatenate(list(xs) + [slack])
         self.genome = torch.from_numpy(np.ascontiguousarray(cat(parts))).cuda()
         self.mask = torch.from_numpy(np.ascontiguousarray(cat(masks))).cuda()
         self.sizes = {c: len(a) for c, a in refdict.items()}
@@ -82,7 +83,7 @@ def _flag_batch(reads, genome, flip_reverse):
     n = len(reads)
     lens = np.array([len(r.query_sequence) for r in reads], dtype=np.uint32)
     pitch = fastx.pitch_for(int(lens.max()) if n else 1)
-    seq = np.zeros((max(n, 1), pitch), dtype=np.uint8)
+    seq = np.zeros((max(n, 1) + 1, pitch), dtype=np.uint8)         # one spare row: slack for K4's window loads
     ref_start = np.zeros(max(n, 1), dtype=np.int64); ref_len = np.zeros(max(n, 1), dtype=np.int32)
     cig_off = np.zeros(max(n, 1), dtype=np.uint32); cig_n = np.zeros(max(n, 1), dtype=np.uint32)
     flip = np.zeros(max(n, 1), dtype=np.uint8)
