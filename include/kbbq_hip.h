@@ -170,6 +170,10 @@ int kbbq_apply(kbbq_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uin
  *
  * kbbq_delta_q_dev: dq[i] = argmax_i - prior_q[i] for ncells independent cells
  * (prior_q must lie in 0..42).
+ * kbbq_posterior_q_dev: the same cell solve for a float64 prior (the reference calls
+ * gatk_delta_q with EstimatedQReported when it builds a report, gatk/bqsr.py:294): the
+ * distance |q' - prior| is the float64 difference truncated toward zero, -1 < prior < 43;
+ * returns the posterior quality argmax_i itself.
  * kbbq_solve_dev: the whole hierarchy from the device count tables: marginals,
  * read-group and quality levels (d_post_q[R*43] scratch), then cycle and
  * dinucleotide levels, writing the K2 LUT blob (kbbq_lut_bytes bytes) and, when
@@ -178,6 +182,9 @@ int kbbq_apply(kbbq_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uin
 int    kbbq_delta_q_dev(kbbq_ctx* ctx, const int64_t* d_prior_q, const int64_t* d_errs,
                         const int64_t* d_total, const double* d_comb, int64_t ncells,
                         const double* h_consts129, int64_t* d_dq);
+int    kbbq_posterior_q_dev(kbbq_ctx* ctx, const double* d_prior_q, const int64_t* d_errs,
+                            const int64_t* d_total, const double* d_comb, int64_t ncells,
+                            const double* h_consts129, int64_t* d_post_q);
 size_t kbbq_solve_aux_count(int R, int S2);
 size_t kbbq_solve_dq_count(int R, int S2);
 int    kbbq_solve_dev(kbbq_ctx* ctx, const int64_t* d_tables, int R, int S2, int minscore,

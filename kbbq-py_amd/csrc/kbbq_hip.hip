@@ -557,6 +557,24 @@ int kbbq_delta_q_dev(kbbq_ctx* c, const int64_t* d_prior_q, const int64_t* d_err
     return KBBQ_OK;
 }
 
+int kbbq_posterior_q_dev(kbbq_ctx* c, const double* d_prior_q, const int64_t* d_errs, const int64_t* d_total,
+                         const double* d_comb, int64_t ncells, const double* h_consts129, int64_t* d_post)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (ncells < 0) return fail(KBBQ_E_ARG, "kbbq_posterior_q_dev: ncells < 0");
+    if (ncells == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    K3PostParams p;
+    p.prior_q = d_prior_q; p.errs = (const long long*)d_errs; p.total = (const long long*)d_total;
+    p.comb = d_comb; p.n = ncells; p.post = (long long*)d_post;
+    int rc = load_consts(p.c, h_consts129);
+    if (rc) return rc;
+    int gx = (int)std::min<int64_t>((ncells + 255) / 256, (int64_t)c->cus * 8);
+    hipLaunchKernelGGL(k3_posterior_q, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
 size_t kbbq_solve_aux_count(int R, int S2) { return (size_t)R + (size_t)R * KQ + (size_t)R * KQ * S2 + (size_t)R * KQ * KND; }
 size_t kbbq_solve_dq_count(int R, int S2) { return (size_t)R + (size_t)R * KQ + (size_t)R * KQ * S2 + (size_t)R * KQ * 17; }
 

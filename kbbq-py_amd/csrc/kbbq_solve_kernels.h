@@ -39,6 +39,20 @@ __global__ __launch_bounds__(256) void k3_delta_q(K3CellParams p)
     }
 }
 
+struct K3PostParams {
+    const double* prior_q; const long long* errs; const long long* total; const double* comb;
+    long long n; long long* post; SolveConsts c;
+};
+
+// the same cell solve for a float64 prior; returns the posterior quality itself (the caller
+// subtracts the prior in float64 as the reference's `posterior_q - prior_q` does)
+__global__ __launch_bounds__(256) void k3_posterior_q(K3PostParams p)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n;
+         i += (long long)gridDim.x * blockDim.x)
+        p.post[i] = (long long)solve_cell<double>(p.c, p.prior_q[i], p.errs[i], p.total[i], p.comb[i]);
+}
+
 __global__ __launch_bounds__(64) void k3_levels_ab(K3FusedParams p)
 {
     __shared__ long long qe[KSOLVE_NQ], qt[KSOLVE_NQ];

@@ -22,7 +22,12 @@ struct SolveConsts {
     double log1mp[KSOLVE_NQ];   // scipy.special.xlog1py(1.0, -p[q'])
 };
 
-X87_HD int solve_cell(const SolveConsts& c, int prior_q, long long errs, long long total, double comb)
+// PRIOR selects how |q' - prior_q| is formed: the reference subtracts in the prior's own dtype and
+// truncates toward zero (np.subtract.outer(...).astype(int), compare_reads.py:246): exact for an
+// integer prior, and for a float64 prior (bqsr.vectors_to_report's EstimatedQReported) two
+// neighbouring candidates can share distance 0.
+template <typename PRIOR>
+X87_HD int solve_cell(const SolveConsts& c, PRIOR prior_q, long long errs, long long total, double comb)
 {
     const long long kk = errs + 1, nn = total + 2;
     // rv_discrete.logpmf masks: outside the support everything is -inf (or nan for n < 0):
@@ -33,7 +38,7 @@ X87_HD int solve_cell(const SolveConsts& c, int prior_q, long long errs, long lo
     x87val best = x87_from_special(2);
     int arg = 0;
     for (int cand = 0; cand < KSOLVE_NQ; ++cand) {
-        int diff = cand - prior_q; if (diff < 0) diff = -diff;
+        int diff = (int)((PRIOR)cand - prior_q); if (diff < 0) diff = -diff;
         const double pr = diff < KSOLVE_NQ ? c.prior[diff] : c.prior[KSOLVE_NQ - 1];
         const double t1 = k * c.logp[cand];
         const double t2 = nk * c.log1mp[cand];

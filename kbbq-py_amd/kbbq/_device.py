@@ -47,6 +47,21 @@ class Tables:
         n = N.load().kbbq_tables_count(self.R, self.S2)
         self.buf = torch.zeros(n, dtype=torch.int64, device='cuda' if device is None else device)
 
+    @classmethod
+    def from_host(cls, pos_errs, pos_total, dinuc_errs, dinuc_total, device=None):
+        """Upload stored count arrays (a model read back from a GATK report)."""
+        torch = _torch()
+        pos_errs = np.asarray(pos_errs)
+        R, nq, S2 = pos_errs.shape
+        if nq != NQ or np.shape(pos_total) != (R, NQ, S2) or np.shape(dinuc_errs) != (R, NQ, 16) \
+                or np.shape(dinuc_total) != (R, NQ, 16):
+            raise ValueError('count arrays must be [R,43,2S], [R,43,2S], [R,43,16], [R,43,16]')
+        t = cls(R, S2, device=device)
+        flat = np.concatenate([np.ascontiguousarray(a, dtype=np.int64).ravel()
+                               for a in (pos_errs, pos_total, dinuc_errs, dinuc_total)])
+        t.buf.copy_(torch.from_numpy(flat))
+        return t
+
     def views(self):
         R, S2 = self.R, self.S2
         npos, ndn = R * NQ * S2, R * NQ * 16
@@ -180,25 +195,32 @@ def _model_consts():
 
 
 def delta_q(prior_q, numerrs, numtotal):
-    """K3, generic form: compare_reads.gatk_delta_q on the device (host: gammaln terms)."""
+    """K3, generic form: compare_reads.gatk_delta_q on the device (host: gammaln terms).
+    An integer prior returns integers; a float prior (the report builder's EstimatedQReported,
+    reference gatk/bqsr.py:294) returns `posterior - prior` in float64, as the reference does."""
     from . import _solve
     torch = _torch()
-    pq = np.ascontiguousarray(np.asarray(prior_q), dtype=np.int64)
+    prior = np.asarray(prior_q)
+    is_float = prior.dtype.kind == 'f'
+    pq = np.ascontiguousarray(prior, dtype=np.float64 if is_float else np.int64)
     e = np.ascontiguousarray(np.asarray(numerrs), dtype=np.int64)
     t = np.ascontiguousarray(np.asarray(numtotal), dtype=np.int64)
     assert pq.shape == e.shape == t.shape
-    if pq.size and (pq.min() < 0 or pq.max() > MAXSCORE):
-        raise IndexError('index %d is out of bounds for axis 0 with size %d'
-                         % (int(np.abs(pq).max()), MAXSCORE + 1))   # prior_dist[|q' - prior_q|]
+    # prior_dist[|q' - prior_q|] has 43 entries: the distance to q' = 0 or 42 must stay below 43
+    if pq.size and (not np.all(np.isfinite(pq)) or np.trunc(pq.max()) > MAXSCORE or np.trunc(pq.min() - MAXSCORE) < -MAXSCORE):
+        worst = int(max(abs(np.trunc(0 - pq.max())), abs(np.trunc(MAXSCORE - pq.min())))) if np.all(np.isfinite(pq)) else -1
+        raise IndexError('index %d is out of bounds for axis 0 with size %d' % (worst, MAXSCORE + 1))
     if pq.size == 0:
-        return np.zeros(pq.shape, dtype=np.int_)
+        return np.zeros(pq.shape, dtype=np.float64 if is_float else np.int_)
     comb = np.ascontiguousarray(_solve.combiln(e, t), dtype=np.float64)
     ctx = context()
     d = [torch.from_numpy(x.ravel()).cuda() for x in (pq, e, t, comb)]
     out = torch.empty(pq.size, dtype=torch.int64, device='cuda')
-    N.check(N.load().kbbq_delta_q_dev(ctx.handle, N.ptr(d[0]), N.ptr(d[1]), N.ptr(d[2]), N.ptr(d[3]),
-                                      pq.size, N.ptr(_model_consts()), N.ptr(out)))
-    return out.cpu().numpy().reshape(pq.shape).astype(np.int_)
+    fn = N.load().kbbq_posterior_q_dev if is_float else N.load().kbbq_delta_q_dev
+    N.check(fn(ctx.handle, N.ptr(d[0]), N.ptr(d[1]), N.ptr(d[2]), N.ptr(d[3]),
+               pq.size, N.ptr(_model_consts()), N.ptr(out)))
+    res = out.cpu().numpy().reshape(pq.shape)
+    return res - pq if is_float else res.astype(np.int_)
 
 
 def solve(tables, want_dq=False, minscore=MINSCORE):

@@ -335,4 +335,6 @@ def pack_single(text, infer_rg_flag):
         raise _SCAN_ERRORS[kind](idx)
     pitch = pitch_for(S)
     seq, _, qual, meta = text.fill(None, infer_rg_flag, n, pitch)
-    return dict(seq=seq, qual=qual, meta=meta, n=n, pitch=pitch, S=S, R=R)
+    rgs = text.rg_names()
+    return dict(seq=seq, qual=qual, meta=meta, n=n, pitch=pitch, S=S, R=R,
+                rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)})

@@ -12,6 +12,8 @@ owned by the caller, output through print(), and the exceptions the reference
 raises on bad input (AssertionError, IndexError, TypeError, NotImplementedError,
 ValueError -- SURVEY.md 8(b)).
 """
+import os
+
 import numpy as np
 
 from . import compare_reads as utils
@@ -75,24 +77,62 @@ def fastq_to_covariate_arrays(fastq, infer_rg=False, minscore=6, maxscore=42):
     return _vectors_from_tables(*tables.to_host(), maxscore)
 
 
-def recalibrate_fastq(fastq, infer_rg=False):
+def _rg_order(rg_to_int):
+    """Read-group names in id order, as text (the report's ReadGroup column)."""
+    return [str(k) for k, _ in sorted(rg_to_int.items(), key=lambda kv: kv[1])]
+
+
+def save_model(tables, rg_to_int, path):
+    """Count tables (K1 output) -> GATK recalibration report file (gatk/bqsr.py
+    vectors_to_report; the option main.py:55-58 declares)."""
+    from .gatk import bqsr
+    vectors = _vectors_from_tables(*tables.to_host(), 42)
+    bqsr.vectors_to_report(*vectors, _rg_order(rg_to_int)).write(path)
+
+
+def load_model(path, rg_to_int):
+    """GATK recalibration report file -> device count tables for the given read groups
+    (gatk/applybqsr.py table_to_vectors).  meanq is NOT taken from the 4-decimal
+    EstimatedQReported column: K3 recomputes it from the counts exactly as pass 1 would have,
+    so a saved-and-reloaded model recalibrates identically to a fresh one."""
+    from . import recaltable
+    report = recaltable.RecalibrationReport.fromfile(path)
+    vectors = applybqsr.table_to_vectors(report, _rg_order(rg_to_int))
+    return dev.Tables.from_host(*vectors[5:9])
+
+
+def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
     """Recalibrate FASTQ file fastq[0] using its error-corrected version fastq[1];
     the recalibrated FASTQ is printed to stdout.  K1 -> K3 -> K2, tables and LUT stay on
-    the device between the kernels."""
-    packed, tables = _pack_and_tally(fastq, infer_rg, 6, 42)
-    text = packed['text']
-    if text.n == 0:
-        return
-    if tables is None:
-        raise IndexError('index 0 is out of bounds for axis 0 with size 0')   # no read was tallied
+    the device between the kernels.  gatkreport (the reference declares the option and raises
+    NotImplementedError, recalibrate.py:167-168): an existing report replaces pass 1 (fastq[1]
+    is not read); otherwise the model of pass 1 is saved there."""
+    if gatkreport is not None and os.path.exists(gatkreport):
+        text = fastx.NativeFastq(fastq[0])
+        if text.n == 0:
+            return
+        single = fastx.pack_single(text, infer_rg)
+        packed = dict(text=text, n=-1)
+        tables = load_model(gatkreport, single['rg_to_int'])
+    else:
+        packed, tables = _pack_and_tally(fastq, infer_rg, 6, 42)
+        text = packed['text']
+        if text.n == 0:
+            return
+        if tables is None:
+            raise IndexError('index 0 is out of bounds for axis 0 with size 0')   # no read was tallied
+        if gatkreport is not None:
+            save_model(tables, packed['rg_to_int'], gatkreport)
     lut, shape, _, _ = dev.solve(tables)
     if packed['n'] == text.n:
         # pass 2 walks the same reads with the same first-appearance read groups (:141-148):
         # the planes of pass 1 are still on the device
         batch, single = packed['batch'], packed
     else:
-        # file B was shorter (zip truncation): pass 2 still covers all of file A
-        single = fastx.pack_single(text, infer_rg)
+        # file B was shorter (zip truncation), or the model came from a report: pass 2 covers
+        # all of file A with its own first-appearance read groups
+        if packed['n'] >= 0:
+            single = fastx.pack_single(text, infer_rg)
         batch = dev.ReadBatch.from_host(single['seq'], single['qual'], single['meta'])
     out = dev.apply(batch, lut, shape)
     # recalibrate.py:153-156: '@' + name, sequence, '+', qualities -- rendered by the C++ writer in
@@ -111,11 +151,9 @@ def recalibrate_bam(bam, use_oq=False, set_oq=False):
 
 
 def recalibrate(bam, fastq, infer_rg=False, use_oq=False, set_oq=False, gatkreport=None):
-    if gatkreport is not None:
-        raise NotImplementedError('GATKreport reading / creation is not yet supported.')
-    elif bam is not None:
+    if bam is not None:
         recalibrate_bam(bam, use_oq, set_oq)
     elif fastq is not None:
-        recalibrate_fastq(fastq, infer_rg=infer_rg)
+        recalibrate_fastq(fastq, infer_rg=infer_rg, gatkreport=gatkreport)
     else:
         raise ValueError('A BAM or FASTQ file should be provided for recalibration.')

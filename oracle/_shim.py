@@ -5,7 +5,8 @@ nothing else.  It contains no reference code.
 
 Why it is needed: the reference imports pysam, khmer and
 seaborn, none of which are installed, and uses NumPy aliases that NumPy 2.x
-removed (np.int, np.bool, np.float, np.object, np.unicode, np.NINF).  The
+removed (np.int, np.bool, np.float, np.object, np.unicode, np.NINF) and one pandas method
+that pandas 2.x removed (DataFrame.append, used by gatk/bqsr.py:355; aliased to pd.concat).  The
 reference only touches pysam on this path through FastxFile iteration
 (recalibrate.py:56,141) and FastxRecord attributes (.name, .sequence, .quality,
 .get_quality_array()), so a few lines of stand-in reader are enough.  The
@@ -150,6 +151,10 @@ def install(reference_root='/root/reference'):
                           ('unicode', np.str_), ('NINF', -np.inf)):
         if not hasattr(np, alias):
             setattr(np, alias, target)
+
+    import pandas as pd
+    if not hasattr(pd.DataFrame, 'append'):
+        pd.DataFrame.append = lambda self, other: pd.concat([self, other])
 
     class FastxRecord:
         def __init__(self, name=None, sequence=None, quality=None, comment=None):

@@ -84,6 +84,43 @@ def run_case(name, c, recal, applybqsr, tmp):
         json.dump(info, fh, indent=1)
     print('%-18s bases=%d pass1 %.2fs solve %.2fs e2e %.2fs  out=%s' % (
         name, bases, t1 - t0, t2 - t1, t3 - t2, info['output_sha256'][:12]), flush=True)
+    run_report_case(name, c, vectors, names)
+
+
+def run_report_case(name, c, vectors, names):
+    """Model file: the reference's vectors_to_report on the vectors it just
+    produced, printed through its RecalibrationReport, re-read through its fromfile."""
+    import types
+    from kbbq import compare_reads as utils
+    from kbbq import recaltable
+    from kbbq.gatk import bqsr
+    if c['infer_rg']:
+        rg_order = []
+        for nm in names:
+            rg = utils.fastq_infer_rg(types.SimpleNamespace(name=nm))
+            if rg not in rg_order:
+                rg_order.append(rg)
+    else:
+        rg_order = ['0']
+    rep = bqsr.vectors_to_report(*[np.asarray(v) for v in vectors], rg_order)
+    text = str(rep)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'r.txt')
+        rep.write(path)
+        assert open(path).read() == text
+        again = recaltable.RecalibrationReport.fromfile(path)
+        reread = str(again) == text
+    lines = text.split('\n')
+    info = dict(rg_order=rg_order, sha256=O.sha256(text), length=len(text), nlines=len(lines),
+                head='\n'.join(lines[:40]), sampled={str(i): lines[i] for i in range(0, len(lines), 499)},
+                table_heads=[ln for ln in lines if ln.startswith('#:GATKTable:')],
+                reference_reread_is_identical=bool(reread))
+    with open(os.path.join(GOLD, 'report_' + name + '.json'), 'w') as fh:
+        json.dump(info, fh, indent=1)
+    if len(text) < 200000:
+        with open(os.path.join(GOLD, 'report_' + name + '.txt'), 'w') as fh:
+            fh.write(text)
+    print('%-18s report %d lines sha=%s reread_identical=%s' % (name, len(lines), info['sha256'][:12], reread), flush=True)
 
 
 def numeric_tables(utils):

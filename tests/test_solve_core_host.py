@@ -48,14 +48,15 @@ def solver(tmp_path_factory):
                            os.path.join(ROOT, 'tests', 'native', 'solve_check.cpp')])
 
     def run(prior_q, errs, total):
-        prior_q = np.ascontiguousarray(prior_q, dtype=np.int64).ravel()
+        is_float = np.asarray(prior_q).dtype.kind == 'f'
+        prior_q = np.ascontiguousarray(prior_q, dtype=np.float64 if is_float else np.int64).ravel()
         errs = np.ascontiguousarray(errs, dtype=np.int64).ravel()
         total = np.ascontiguousarray(total, dtype=np.int64).ravel()
         comb = _solve.combiln(errs, total)
         rec = np.empty(len(errs), dtype=[('p', '<i8'), ('e', '<i8'), ('t', '<i8'), ('c', '<f8')])
-        rec['p'], rec['e'], rec['t'], rec['c'] = prior_q, errs, total, comb
+        rec['p'], rec['e'], rec['t'], rec['c'] = prior_q.view(np.int64), errs, total, comb
         blob = struct.pack('<q', len(errs)) + _solve.model_consts().tobytes() + rec.tobytes()
-        out = subprocess.run([exe], input=blob, capture_output=True, timeout=600)
+        out = subprocess.run([exe] + (['f'] if is_float else []), input=blob, capture_output=True, timeout=600)
         assert out.returncode == 0
         return np.frombuffer(out.stdout, dtype=np.int64) - prior_q
     return run
@@ -82,3 +83,18 @@ def test_solve_core_matches_reference_grid(solver, oracle):
         dd = np.broadcast_to(prior2[..., None], g['dinuc_total'].shape)
         assert np.array_equal(solver(dd, g['dinuc_errs'], g['dinuc_total']).reshape(dd.shape),
                               g['dinucdq'][..., :16])
+
+
+@pytest.mark.skipif(np.finfo(np.longdouble).nmant != 63, reason='np.longdouble is not x87 extended here')
+def test_solve_core_float_prior(solver, oracle):
+    """The report builder calls gatk_delta_q with a float64 prior (reference gatk/bqsr.py:294):
+    distance = float64 difference truncated toward zero."""
+    rng = np.random.default_rng(11)
+    err, t = _cells(rng, 4000)
+    pq = rng.uniform(-0.999, 42.999, len(err))
+    pq[:200] = np.round(pq[:200])                       # integral floats
+    pq[200:400] = np.round(pq[200:400]) + rng.choice([-1e-12, 1e-12, 2e-15, -2e-15], 200)
+    pq = np.clip(pq, -0.999, 42.999)
+    got = solver(pq, err, t)
+    want = oracle.gatk_delta_q(pq, err, t)
+    assert got.dtype == np.float64 and np.array_equal(got, want)
