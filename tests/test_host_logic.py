@@ -346,8 +346,12 @@ def test_dispatcher_errors():
         recalibrate.recalibrate_bam(None)
     with pytest.raises(NotImplementedError):
         recalibrate.recalibrate(fastq=None, bam='foo')
-    with pytest.raises(NotImplementedError):
+    # the reference raises NotImplementedError for any gatkreport (recalibrate.py:167-168); here the
+    # option is implemented, so without an input it is the ValueError below
+    with pytest.raises(ValueError):
         recalibrate.recalibrate(fastq=None, bam=None, gatkreport='foo')
+    with pytest.raises(NotImplementedError):
+        recalibrate.recalibrate(fastq=None, bam='foo', gatkreport='foo')
     with pytest.raises(ValueError):
         recalibrate.recalibrate(fastq=None, bam=None, gatkreport=None)
     a = fastx.FastxRecord('r', 'ACGTAC', 'IIIIII'); b = fastx.FastxRecord('r', 'ACGTAC', 'IIIIII')
