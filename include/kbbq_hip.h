@@ -211,6 +211,23 @@ int kbbq_find_errors_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint32_t* d_
                          const uint32_t* d_cig_off, const uint32_t* d_cig_n, const uint32_t* d_cigar,
                          const uint8_t* d_genome, const uint8_t* d_skipmask, const uint8_t* d_flip,
                          uint8_t* d_err, uint8_t* d_skip);
+/* kbbq_canonical_reads_dev: first half of gatk.bqsr.bam_to_bqsr_covariates (gatk/bqsr.py:52-123;
+ * strand-aware covariates :23-50, skips :86-88).  Rewrites aligned reads into sequencing
+ * orientation so that kbbq_accumulate_dev tallies them: per read the aligned part
+ * [clip & 0xFFFF, clip >> 16) only, reverse-strand reads (flags bit 0) reverse-complemented
+ * (letters outside ACGT -> N), padded to the common length S with uncounted bases; a base is
+ * given quality byte 0 (never counted) when its K4 skip flag is set, its original quality is
+ * below minscore, it lies in the trimmed range [trim & 0xFFFF, trim >> 16) (adaptor, host) or
+ * it is N; out_cseq differs from out_seq exactly where the K4 error flag is set; out_meta =
+ * S | read group (flags >> 16) << 16 | read 2 (flags bit 1) << 31.  The reference's TypeError
+ * (a looked-up dinucleotide with a letter outside ACGT on a forward read, decided on the
+ * ORIGINAL qualities with dinuc_minscore) arrives as KBBQ_E_TYPE.  Input planes need one
+ * spare row of slack; all planes 16-byte aligned.                                      */
+int kbbq_canonical_reads_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_oq, const uint8_t* d_err,
+                             const uint8_t* d_skip, const uint32_t* d_len, const uint32_t* d_clip,
+                             const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads, int pitch, int S,
+                             int minscore, int dinuc_minscore, uint8_t* d_out_seq, uint8_t* d_out_cseq,
+                             uint8_t* d_out_qual, uint32_t* d_out_meta);
 int kbbq_count_q_dev(kbbq_ctx* ctx, const uint8_t* d_qual, const uint8_t* d_err, const uint8_t* d_skip,
                      const uint32_t* d_len, int64_t nreads, int pitch, int qoffset, int64_t* d_counts512);
 

@@ -636,6 +636,35 @@ int kbbq_find_errors_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint32_t* d_le
     return KBBQ_OK;
 }
 
+int kbbq_canonical_reads_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_oq, const uint8_t* d_err,
+                             const uint8_t* d_skip, const uint32_t* d_len, const uint32_t* d_clip,
+                             const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads, int pitch, int S,
+                             int minscore, int dinuc_minscore, uint8_t* d_out_seq, uint8_t* d_out_cseq,
+                             uint8_t* d_out_qual, uint32_t* d_out_meta)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (nreads < 0 || pitch <= 0 || (pitch & 15) || S <= 0 || S > pitch || S > 65535)
+        return fail(KBBQ_E_ARG, "kbbq_canonical_reads_dev: bad nreads/pitch/S");
+    if (minscore < 0 || minscore > 94 || dinuc_minscore < 0 || dinuc_minscore > 94)
+        return fail(KBBQ_E_ARG, "kbbq_canonical_reads_dev: minscore out of range");
+    if (nreads == 0) return KBBQ_OK;
+    if (((uintptr_t)d_seq | (uintptr_t)d_oq | (uintptr_t)d_err | (uintptr_t)d_skip | (uintptr_t)d_out_seq
+         | (uintptr_t)d_out_cseq | (uintptr_t)d_out_qual) & 15)
+        return fail(KBBQ_E_ARG, "kbbq_canonical_reads_dev: planes must be 16-byte aligned");
+    HIPCHK(hipSetDevice(c->device));
+    K6Params p;
+    p.seq = d_seq; p.oq = d_oq; p.err = d_err; p.skip = d_skip; p.len = d_len; p.clip = d_clip; p.trim = d_trim;
+    p.flags = d_flags; p.nreads = nreads; p.pitch = pitch; p.S = S;
+    p.qlo = 33u + (u32)minscore; p.dlo = 33u + (u32)dinuc_minscore;
+    p.out_seq = d_out_seq; p.out_cseq = d_out_cseq; p.out_qual = d_out_qual; p.out_meta = d_out_meta;
+    p.status = c->d_status;
+    const int64_t nchunks = nreads * (pitch / 16);
+    int gx = (int)std::min<int64_t>((nchunks + 255) / 256, (int64_t)c->cus * 16);
+    hipLaunchKernelGGL(k6_canonical_reads, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
 int kbbq_count_q_dev(kbbq_ctx* c, const uint8_t* d_qual, const uint8_t* d_err, const uint8_t* d_skip,
                      const uint32_t* d_len, int64_t nreads, int pitch, int qoffset, int64_t* d_counts512)
 {

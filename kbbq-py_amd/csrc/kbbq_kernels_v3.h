@@ -670,6 +670,128 @@ __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
     }
 }
 
+// ---------------------------------------------------------------- K6 (BAM-sourced tally)
+// gatk/bqsr.py:52-123 tallies aligned reads with strand-aware covariates: the cycle and the
+// dinucleotide context are those of the base in SEQUENCING orientation over the aligned part
+// (bqsr.py:23-50), and a base is skipped when K4 flagged its site, when its original quality is
+// below minscore, when it lies past the adaptor boundary (bqsr.py:158-206, host: a per-read
+// range) or when it is 'N' (bqsr.py:86-88).  K6 rewrites every read into that orientation --
+// aligned part only, reverse-strand reads reverse-complemented (unknown letters -> 'N', as
+// Dinucleotide.complement.get(x, 'N')), padded with uncounted bases to the common length S,
+// skipped bases given quality byte 0, errors expressed as cseq != seq -- and the result goes
+// through the SAME tally kernel as the FASTQ path (K1): canonical position = cycle, sidecar
+// `second` bit = is_read2 (column 2S-1-c), context from the canonical neighbours.
+// lane <-> one 16-byte OUTPUT chunk; input windows are unaligned (load16_any).
+struct K6Params {
+    const uint8_t* seq; const uint8_t* oq; const uint8_t* err; const uint8_t* skip;   // [nreads(+1 slack row), pitch]
+    const u32* len;                  // query length (must be S: checked on the host)
+    const u32* clip;                 // query_alignment_start | query_alignment_end << 16
+    const u32* trim;                 // skipped range lo | hi << 16 (lo == hi: none)
+    const u32* flags;                // bit 0 reverse, bit 1 read 2, bits 16.. read group
+    long long nreads; int pitch; int S; u32 qlo; u32 dlo;
+    uint8_t* out_seq; uint8_t* out_cseq; uint8_t* out_qual; u32* out_meta;
+    u64* status;
+};
+
+__device__ __forceinline__ u32 complement4(u32 w)
+{
+    const u32 h = (w >> 1) & 0x07070707u;
+    const u32 expect = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, h);
+    const u32 comp = __builtin_amdgcn_perm(0x4E4E4E4Eu, 0x43414754u, h);       // A->T C->G T->A G->C, else N
+    const u32 bad = nonzero_bytes(expect ^ w) * 0xFFu;                          // not exactly A C G T N
+    return (comp & ~bad) | (0x4E4E4E4Eu & bad);
+}
+
+__device__ __forceinline__ bool is_acgt(u32 ch) { return ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'; }
+
+__global__ __launch_bounds__(256) void k6_canonical_reads(K6Params p)
+{
+    const int cpr = p.pitch >> 4;
+    const long long nchunks = p.nreads * cpr;
+    for (long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks;
+         ch += (long long)gridDim.x * blockDim.x) {
+        const long long r = ch / cpr;
+        const int j = (int)(ch - r * cpr);
+        const u32 fl = p.flags[r];
+        const bool rev = (fl & 1u) != 0;
+        const int qs = (int)(p.clip[r] & 0xFFFFu), qe = (int)(p.clip[r] >> 16);
+        const int tlo = (int)(p.trim[r] & 0xFFFFu), thi = (int)(p.trim[r] >> 16);
+        const int L = qe - qs;
+        const int c0 = 16 * j;
+        u32 os[4] = {0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu};
+        u32 oc[4] = {0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu};
+        u32 oqv[4] = {0u, 0u, 0u, 0u};
+        const size_t row = (size_t)r * p.pitch;
+        if (j == 0) p.out_meta[r] = (u32)p.S | ((fl >> 16) << 16) | ((fl & 2u) ? 0x80000000u : 0u);
+        if (c0 + 16 <= L) {
+            // whole chunk inside the aligned part: input positions [i0, i0 + 16), reversed when rev
+            const int i0 = rev ? qe - c0 - 16 : qs + c0;
+            u32 s[4], q[4], e[4], k[4];
+            load16_any(p.seq, (long long)row + i0, s);
+            load16_any(p.oq, (long long)row + i0, q);
+            load16_any(p.err, (long long)row + i0, e);
+            load16_any(p.skip, (long long)row + i0, k);
+            bool odd = false;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const u32 below = (~((q[w] | 0x80808080u) - p.qlo * 0x01010101u) >> 7) & 0x01010101u;   // q < minscore
+                const u32 trimmed = (byte_mask(thi - i0, w) & ~byte_mask(tlo - i0, w)) & 0x01010101u;
+                const u32 isn = nonzero_bytes(s[w] ^ 0x4E4E4E4Eu) ^ 0x01010101u;
+                const u32 sk = (nonzero_bytes(k[w]) | below | trimmed | isn) * 0xFFu;
+                u32 code, code5, expect;
+                decode4x(s[w], code, code5, expect);
+                odd |= (expect != s[w]);
+                os[w] = rev ? complement4(s[w]) : s[w];
+                oc[w] = os[w] ^ (nonzero_bytes(e[w]) << 7);                    // an error: cseq differs from seq
+                oqv[w] = q[w] & ~sk;
+            }
+            if (odd && !rev) {
+                // the reference's TypeError (compare_reads.py:281-293 via bqsr.py:43-45) is decided on the
+                // ORIGINAL qualities, before any skipping: a looked-up pair with a letter outside ACGT
+                u32 prev = (c0 >= 1) ? p.seq[row + i0 - 1] : 'N';
+                for (int b = 0; b < 16; ++b) {
+                    const u32 cur = (s[b >> 2] >> (8 * (b & 3))) & 0xFFu, qq = (q[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+                    if (c0 + b >= 1 && qq >= p.dlo && cur != 'N' && prev != 'N' && !(is_acgt(cur) && is_acgt(prev)))
+                        flag(p.status, ST_TYPE, r);
+                    prev = cur;
+                }
+            }
+            if (rev) {
+                const u32 a0 = os[0], a1 = os[1], a2 = os[2], a3 = os[3];
+                os[0] = __builtin_amdgcn_perm(0u, a3, 0x00010203u); os[1] = __builtin_amdgcn_perm(0u, a2, 0x00010203u);
+                os[2] = __builtin_amdgcn_perm(0u, a1, 0x00010203u); os[3] = __builtin_amdgcn_perm(0u, a0, 0x00010203u);
+                const u32 b0 = oc[0], b1 = oc[1], b2 = oc[2], b3 = oc[3];
+                oc[0] = __builtin_amdgcn_perm(0u, b3, 0x00010203u); oc[1] = __builtin_amdgcn_perm(0u, b2, 0x00010203u);
+                oc[2] = __builtin_amdgcn_perm(0u, b1, 0x00010203u); oc[3] = __builtin_amdgcn_perm(0u, b0, 0x00010203u);
+                const u32 d0 = oqv[0], d1 = oqv[1], d2 = oqv[2], d3 = oqv[3];
+                oqv[0] = __builtin_amdgcn_perm(0u, d3, 0x00010203u); oqv[1] = __builtin_amdgcn_perm(0u, d2, 0x00010203u);
+                oqv[2] = __builtin_amdgcn_perm(0u, d1, 0x00010203u); oqv[3] = __builtin_amdgcn_perm(0u, d0, 0x00010203u);
+            }
+        } else if (c0 < L) {
+            // the last, partial chunk of the aligned part: byte by byte
+            for (int b = 0; b < L - c0; ++b) {
+                const int c = c0 + b;
+                const int i = rev ? qe - 1 - c : qs + c;
+                const u32 ch0 = p.seq[row + i], qq = p.oq[row + i];
+                const bool sk = p.skip[row + i] != 0 || qq < p.qlo || (i >= tlo && i < thi) || ch0 == 'N';
+                u32 outc = ch0;
+                if (rev) outc = ch0 == 'A' ? 'T' : ch0 == 'T' ? 'A' : ch0 == 'C' ? 'G' : ch0 == 'G' ? 'C' : 'N';
+                else if (c >= 1) {
+                    const u32 prev = p.seq[row + i - 1];
+                    if (qq >= p.dlo && ch0 != 'N' && prev != 'N' && !(is_acgt(ch0) && is_acgt(prev))) flag(p.status, ST_TYPE, r);
+                }
+                set_byte(os, b, outc);
+                set_byte(oc, b, p.err[row + i] ? (outc ^ 0x80u) : outc);
+                set_byte(oqv, b, sk ? 0u : qq);
+            }
+        }
+        const size_t off = row + (size_t)16 * j;
+        *reinterpret_cast<uint4*>(p.out_seq + off) = make_uint4(os[0], os[1], os[2], os[3]);
+        *reinterpret_cast<uint4*>(p.out_cseq + off) = make_uint4(oc[0], oc[1], oc[2], oc[3]);
+        *reinterpret_cast<uint4*>(p.out_qual + off) = make_uint4(oqv[0], oqv[1], oqv[2], oqv[3]);
+    }
+}
+
 struct K5Params {
     const uint8_t* qual; const uint8_t* err; const uint8_t* skip; const u32* len;
     long long nreads; int pitch; int cpr; u32 cpr_magic; int qoffset;

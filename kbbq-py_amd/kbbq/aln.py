@@ -1,7 +1,7 @@
 """
-Text-format readers for the benchmark path (SAM, FASTA, VCF, BED) -- what the reference
-gets from pysam.AlignmentFile / FastaFile / VariantFile / tabix_iterator on that path
-(reference kbbq/benchmark.py:9-30,57-74,145-164).  pysam/htslib is not available here, so
+Text-format readers for the benchmark path and the BAM-sourced tally (SAM, FASTA, VCF, BED) --
+what the reference gets from pysam.AlignmentFile / FastaFile / VariantFile / tabix_iterator
+(reference kbbq/benchmark.py:9-30,57-74,145-164; kbbq/gatk/bqsr.py:23-206).  pysam/htslib is not available here, so
 binary BAM / BCF / bgzip-indexed inputs are not read: convert with `samtools view -h`.
 Objects are duck-typed after pysam so code written against the reference keeps working.
 """
@@ -26,6 +26,9 @@ class AlignedRead:
         self.mapping_quality = int(f[4])
         self.cigarstring = f[5]
         self.cigartuples = parse_cigar(f[5])
+        self.next_reference_name = f[6]
+        self.next_reference_start = int(f[7]) - 1
+        self.template_length = int(f[8])
         self.query_sequence = f[9]
         self.query_qualities = [ord(c) - 33 for c in f[10]] if f[10] != '*' else None
         self.tags = {}
@@ -47,9 +50,53 @@ class AlignedRead:
         return self.reference_start + sum(l for op, l in self.cigartuples if op in (0, 2, 3, 7, 8))
 
     is_paired = property(lambda self: bool(self.flag & 1))
+    is_unmapped = property(lambda self: bool(self.flag & 4))
+    mate_is_unmapped = property(lambda self: bool(self.flag & 8))
     is_reverse = property(lambda self: bool(self.flag & 16))
+    mate_is_reverse = property(lambda self: bool(self.flag & 32))
     is_read1 = property(lambda self: bool(self.flag & 64))
     is_read2 = property(lambda self: bool(self.flag & 128))
+
+    @property
+    def tlen(self):                       # pysam's older name of template_length
+        return self.template_length
+
+    @tlen.setter
+    def tlen(self, v):
+        self.template_length = v
+
+    def _soft_clip(self, ops):
+        n = 0
+        for op, l in ops:
+            if op == 4:
+                n += l
+            elif op != 5:                 # hard clips may sit outside the soft clips
+                break
+        return n
+
+    @property
+    def query_alignment_start(self):
+        return self._soft_clip(self.cigartuples)
+
+    @property
+    def query_alignment_end(self):
+        return self.query_length - self._soft_clip(reversed(self.cigartuples))
+
+    @property
+    def query_alignment_length(self):
+        return self.query_alignment_end - self.query_alignment_start
+
+    def get_aligned_pairs(self):
+        """[(query index | None, reference index | None)] in CIGAR order, soft clips included."""
+        out, q, r = [], 0, self.reference_start
+        for op, l in self.cigartuples:
+            if op in (0, 7, 8):
+                out.extend(zip(range(q, q + l), range(r, r + l))); q += l; r += l
+            elif op in (1, 4):
+                out.extend((i, None) for i in range(q, q + l)); q += l
+            elif op in (2, 3):
+                out.extend((None, i) for i in range(r, r + l)); r += l
+        return out
 
     def get_tag(self, k):
         return self.tags[k]
@@ -80,6 +127,24 @@ def _open(path):
     return gzip.open(path, 'rt') if str(path).endswith('.gz') else open(path, 'r')
 
 
+class SamHeader(list):
+    """Header lines; as_dict() groups them by record type like pysam's AlignmentHeader."""
+
+    def as_dict(self):
+        out = {}
+        for line in self:
+            fields = line.split('\t')
+            if fields[0] == '@CO':
+                out.setdefault('CO', []).append('\t'.join(fields[1:]))
+                continue
+            rec = {x[:2]: x[3:] for x in fields[1:]}
+            if fields[0] == '@HD':
+                out['HD'] = rec
+            else:
+                out.setdefault(fields[0][1:], []).append(rec)
+        return out
+
+
 class AlignmentFile:
     """Iterable of AlignedRead from a SAM text file (mode is accepted and ignored)."""
 
@@ -87,7 +152,7 @@ class AlignmentFile:
         with open(path, 'rb') as fh:
             if fh.read(4) in (b'BAM\x01', b'\x1f\x8b\x08\x04'):
                 raise NotImplementedError('binary BAM needs htslib; convert with `samtools view -h`')
-        self.header = []
+        self.header = SamHeader()
         self._reads = []
         with _open(path) as fh:
             for line in fh:
@@ -98,6 +163,11 @@ class AlignmentFile:
 
     def __iter__(self):
         return iter(self._reads)
+
+    def __next__(self):
+        if not hasattr(self, '_it'):
+            self._it = iter(self._reads)
+        return next(self._it)
 
     def __len__(self):
         return len(self._reads)

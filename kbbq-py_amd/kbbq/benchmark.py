@@ -75,8 +75,9 @@ class _Genome:
         self.sizes = {c: len(a) for c, a in refdict.items()}
 
 
-def _flag_batch(reads, genome, flip_reverse):
-    """K4 over a list of aligned reads -> (err, skip) device planes [n, pitch], lens (host)."""
+def _flag_batch(reads, genome, flip_reverse, keep=None):
+    """K4 over a list of aligned reads -> (err, skip) device planes [n (+1 slack row), pitch], lens
+    (host).  `keep`, a dict, receives the device seq plane for callers that go on to K6."""
     from . import _device as dev
     from . import _native as N
     torch = dev._torch()
@@ -103,8 +104,10 @@ def _flag_batch(reads, genome, flip_reverse):
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     d_seq, d_len = up(seq), up(lens.view(np.int32) if n else np.zeros(1, np.int32))
     d_cigar = up(np.array(cigar if cigar else [0], dtype=np.uint32).view(np.int32))
-    err = torch.zeros((max(n, 1), pitch), dtype=torch.uint8, device='cuda')
-    skip = torch.zeros((max(n, 1), pitch), dtype=torch.uint8, device='cuda')
+    err = torch.zeros((max(n, 1) + 1, pitch), dtype=torch.uint8, device='cuda')
+    skip = torch.zeros((max(n, 1) + 1, pitch), dtype=torch.uint8, device='cuda')
+    if keep is not None:
+        keep['seq'] = d_seq
     ctx = dev.context()
     # keep every device tensor referenced until the kernel has run (N.ptr only takes the address)
     d_rs, d_rl, d_flip = up(ref_start), up(ref_len), up(flip)

@@ -121,6 +121,17 @@ def gatk_delta_q(prior_q, numerrs, numtotal, maxscore=_MAXSCORE):
     return delta_q(prior_q, numerrs, numtotal)
 
 
+def bamread_get_oq(read):
+    """Original qualities from the OQ tag, phred+33 text -> int array (reference
+    compare_reads.py:332-336)."""
+    return np.frombuffer(read.get_tag('OQ').encode('utf-32-le'), dtype=np.uint32).astype(np.int_) - 33
+
+
+def get_rg_to_pu(bamfileobj):
+    """{read group ID: platform unit} in header order (reference compare_reads.py:338-340)."""
+    return {rg['ID']: rg['PU'] for rg in bamfileobj.header.as_dict()['RG']}
+
+
 def generic_cycle_covariate(sequencelen, secondinpair=False):
     """0..L-1, or -1..-L for second-in-pair reads (reference compare_reads.py:275-279)."""
     cycle = np.arange(sequencelen)

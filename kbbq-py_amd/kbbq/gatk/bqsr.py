@@ -1,15 +1,190 @@
 """
-kbbq.gatk.bqsr -- the report-building half of the reference's kbbq/gatk/bqsr.py
-(quantize :213-224, vectors_to_report :226-366): count tables (K1 output) -> GATK
-recalibration report.  The EmpiricalQuality columns are the reference's gatk_delta_q calls
-(:294, :307, :336, :352); they run on the device (K3, compare_reads.gatk_delta_q), including
-the float64-prior call of the read-group table.  Everything else is column assembly.
+kbbq.gatk.bqsr -- the reference's kbbq/gatk/bqsr.py on the device.
+
+Report building (quantize :213-224, vectors_to_report :226-366): count tables (K1 output) ->
+GATK recalibration report.  The EmpiricalQuality columns are the reference's gatk_delta_q
+calls (:294, :307, :336, :352); they run on the device (K3), including the float64-prior call
+of the read-group table.  Everything else is column assembly.
+
+BAM-sourced tally (bam_to_bqsr_covariates :52-123 with the strand-aware covariates :23-50 and
+the adaptor trimming :131-206): K4 flags errors / known sites by CIGAR walk, K6 rewrites every
+read into sequencing orientation with the skipped bases uncounted, and K1 -- the very kernel of
+the FASTQ path -- tallies.  Host work per read: the CIGAR-derived scalars (clip ends, adaptor
+index); the per-read covariate functions exist for API parity and run on the host.
 """
 import numpy as np
 import pandas as pd
 
 from .. import compare_reads as utils
 from .. import recaltable
+
+
+# ---------------------------------------------------------------- per-read covariates (host, API parity)
+def bamread_bqsr_cycle(read):
+    """Cycle of every base of the aligned part, 0 on soft clips (reference bqsr.py:23-31)."""
+    full = np.zeros(read.query_length, dtype=np.int_)
+    cyc = utils.generic_cycle_covariate(read.query_alignment_length, read.is_read2)
+    full[read.query_alignment_start:read.query_alignment_end] = cyc[::-1] if read.is_reverse else cyc
+    return full
+
+
+def bamread_bqsr_dinuc(read, use_oq=True, minscore=6):
+    """Dinucleotide context in sequencing orientation over the aligned part (reference
+    bqsr.py:33-50)."""
+    a, b = read.query_alignment_start, read.query_alignment_end
+    quals = (utils.bamread_get_oq(read) if use_oq else np.array(read.query_qualities, dtype=np.int_))[a:b]
+    letters = np.array(list(read.query_sequence[a:b]), dtype='U1')
+    if read.is_reverse:
+        comp = utils.Dinucleotide.complement
+        letters = np.array([comp.get(x, 'N') for x in letters[::-1]], dtype='U1')
+        quals = quals[::-1]
+    ctx = utils.generic_dinuc_covariate(letters, quals, minscore) if b > a else np.zeros(0, dtype=np.int_)
+    full = np.zeros(read.query_length, dtype=np.int_)
+    full[a:b] = ctx[::-1] if read.is_reverse else ctx
+    return full
+
+
+# ---------------------------------------------------------------- adaptor trimming (host)
+def bamread_adaptor_boundary(read):
+    """Reference position where the adaptor starts, or None (reference bqsr.py:131-155, after
+    GATK ReadUtils.getAdaptorBoundary)."""
+    if (read.tlen == 0 or not read.is_paired or read.is_unmapped or read.mate_is_unmapped
+            or read.is_reverse == read.mate_is_reverse):
+        return None
+    if read.is_reverse:
+        if (read.reference_end - 1) > read.next_reference_start:
+            return read.next_reference_start - 1
+        return None
+    if read.reference_start <= read.next_reference_start + read.tlen:
+        return read.reference_start + abs(read.tlen)
+    return None
+
+
+_UNSET = object()
+
+
+def _trim_range(read, boundary=_UNSET):
+    """(lo, hi): query positions [lo, hi) lie past the adaptor boundary (reference
+    bqsr.py:158-206), found by one pass over the CIGAR instead of get_aligned_pairs()."""
+    if boundary is _UNSET:
+        boundary = bamread_adaptor_boundary(read)
+    n = len(read.query_qualities)
+    if boundary is None:
+        return 0, 0
+    ops = read.cigartuples
+    if read.is_reverse:
+        if boundary < read.reference_start:
+            return 0, 0
+        # walking backwards: the last reference position <= boundary, then the nearest base at or before it
+        q, r, reached = sum(l for op, l in ops if op in (0, 1, 4, 7, 8)), read.reference_end, False
+        for op, l in reversed(ops):
+            if op in (0, 7, 8):
+                if reached:
+                    return 0, q
+                if r - l <= boundary:
+                    return 0, q - ((r - 1) - min(boundary, r - 1))
+                q -= l; r -= l
+            elif op in (1, 4):
+                if reached:
+                    return 0, q
+                q -= l
+            elif op in (2, 3):
+                if r - l <= boundary:
+                    reached = True
+                r -= l
+        return 0, 0
+    if boundary > read.reference_end - 1:
+        return 0, 0
+    q, r, reached = 0, read.reference_start, False
+    for op, l in ops:
+        if op in (0, 7, 8):
+            if reached:
+                return q, n
+            if r + l > boundary:
+                return q + max(boundary - r, 0), n
+            q += l; r += l
+        elif op in (1, 4):
+            if reached:
+                return q, n
+            q += l
+        elif op in (2, 3):
+            if r + l > boundary:
+                reached = True
+            r += l
+    return n, n
+
+
+def trim_bamread(read, boundary=_UNSET):
+    """Boolean array: bases to skip because they lie past the adaptor boundary (reference
+    bqsr.py:158-206).  `boundary` defaults to bamread_adaptor_boundary(read), looked up at call
+    time like the reference does."""
+    lo, hi = _trim_range(read, bamread_adaptor_boundary(read) if boundary is _UNSET else boundary)
+    out = np.zeros(len(read.query_qualities), dtype=bool)
+    out[lo:hi] = True
+    return out
+
+
+# ---------------------------------------------------------------- the tally (device)
+def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxscore=42):
+    """The nine model vectors from aligned reads, a FASTA reference and known variant sites
+    (reference bqsr.py:52-123): K4 -> K6 -> K1.  Every read must have the first read's length
+    (the reference indexes with masks of that length: IndexError otherwise); quality = OQ tag."""
+    from .. import _device as dev
+    from .. import _native as N
+    from .. import _solve, aln, benchmark
+    if maxscore != 42:
+        raise ValueError('the Q axis of the device tables is fixed at 43 (maxscore = 42)')
+    torch = dev._torch()
+    rg_to_pu = utils.get_rg_to_pu(bamfileobj)
+    rg_to_int = {rg: i for i, rg in enumerate(rg_to_pu)}
+    R = len(rg_to_int)
+    fasta = aln.FastaFile(fastafilename)
+    ref = {chrom: aln.chars(fasta.fetch(reference=chrom)) for chrom in fasta.references}
+    fullskips = {}
+    for chrom in ref:
+        fullskips[chrom] = np.zeros(len(ref[chrom]), dtype=bool)
+        fullskips[chrom][np.array(var_pos[chrom], dtype=np.int_)] = True      # KeyError: a contig without sites
+    reads = list(bamfileobj)
+    if not reads:
+        raise StopIteration                                                    # next(bamfileobj) at :71
+    S = len(reads[0].query_qualities)
+    n = len(reads)
+    genome = benchmark._Genome(ref, fullskips)
+    kept = {}
+    err, skip, lens, pitch = benchmark._flag_batch(reads, genome, flip_reverse=False, keep=kept)
+    oq = np.zeros((n + 1, pitch), dtype=np.uint8)
+    clip = np.zeros(n, dtype=np.uint32); trim = np.zeros(n, dtype=np.uint32); flags = np.zeros(n, dtype=np.uint32)
+    bad_length = None
+    for i, r in enumerate(reads):
+        rg = rg_to_int[r.get_tag('RG')]
+        q = aln.codes(r.get_tag('OQ'))
+        if (len(q) != S or lens[i] != S) and bad_length is None:
+            bad_length = i
+        m = min(len(q), pitch)
+        oq[i, :m] = q[:m]
+        clip[i] = r.query_alignment_start | (r.query_alignment_end << 16)
+        lo, hi = _trim_range(r)
+        trim[i] = lo | (hi << 16)
+        flags[i] = (1 if r.is_reverse else 0) | (2 if r.is_read2 else 0) | (rg << 16)
+    upto = n if bad_length is None else bad_length       # reads before the offending one are still examined
+    tables = dev.Tables(max(R, 1), 2 * S)
+    if upto:
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        d_seq, d_oq = kept['seq'], up(oq)
+        d_len, d_clip, d_trim, d_flags = (up(x[:max(upto, 1)].view(np.int32)) for x in (lens.astype(np.uint32), clip, trim, flags))
+        batch = dev.ReadBatch(upto, pitch, with_corrected=True)
+        ctx = dev.context()
+        N.check(N.load().kbbq_canonical_reads_dev(
+            ctx.handle, N.ptr(d_seq), N.ptr(d_oq), N.ptr(err), N.ptr(skip), N.ptr(d_len), N.ptr(d_clip),
+            N.ptr(d_trim), N.ptr(d_flags), upto, pitch, S, minscore, 6,
+            N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual), N.ptr(batch.meta)))
+        ctx.status()
+        dev.accumulate(batch, tables, minscore, dinuc_minscore=6)
+    if bad_length is not None:
+        raise IndexError('boolean index did not match indexed array along axis 0; size of axis is %d but size of '
+                         'corresponding boolean axis is %d' % (S, int(lens[bad_length])))
+    return _solve.vectors_from_tables(*tables.to_host(), maxscore)
+
 
 # the fixed argument table GATK expects to find (reference bqsr.py:263-281)
 _ARGUMENTS = (
@@ -122,3 +297,11 @@ def vectors_to_report(meanq, global_errs, global_total, q_errs, q_total,
     frames = (arguments, quant_frame, rg_frame, q_frame, cov_frame)
     return recaltable.RecalibrationReport(
         [recaltable.GATKTable(t, d, f) for t, d, f in zip(titles, descriptions, frames)])
+
+
+def bam_to_report(bamfileobj, fastafilename, var_pos):
+    """Aligned reads -> recalibration report; read groups are named by their PU (reference
+    bqsr.py:368-371)."""
+    rgs = list(utils.get_rg_to_pu(bamfileobj).values())
+    vectors = bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos)
+    return vectors_to_report(*vectors, rgs)

@@ -49,12 +49,56 @@ class AlignedSegment:
             k, ty, v = t.split(':', 2)
             self.tags[k] = int(v) if ty == 'i' else v
         self.query_length = len(self.query_sequence)
-        self.reference_end = self.reference_start + sum(l for op, l in self.cigartuples if op in (0, 2, 3, 7, 8))
         self.is_paired = bool(self.flag & 1)
+        self.is_unmapped = bool(self.flag & 4)
+        self.mate_is_unmapped = bool(self.flag & 8)
         self.is_reverse = bool(self.flag & 16)
+        self.mate_is_reverse = bool(self.flag & 32)
         self.is_read1 = bool(self.flag & 64)
         self.is_read2 = bool(self.flag & 128)
+        self.next_reference_start = int(f[7]) - 1
+        self.tlen = self.template_length = int(f[8])
         self._line = line
+
+    # pysam derives these from the CIGAR on every access (the reference's tests reassign .cigartuples)
+    @property
+    def reference_end(self):
+        return self.reference_start + sum(l for op, l in self.cigartuples if op in (0, 2, 3, 7, 8))
+
+    @property
+    def query_alignment_start(self):
+        n = 0
+        for op, l in self.cigartuples:
+            if op == 4:
+                n += l
+            elif op != 5:
+                break
+        return n
+
+    @property
+    def query_alignment_end(self):
+        n = 0
+        for op, l in reversed(self.cigartuples):
+            if op == 4:
+                n += l
+            elif op != 5:
+                break
+        return self.query_length - n
+
+    @property
+    def query_alignment_length(self):
+        return self.query_alignment_end - self.query_alignment_start
+
+    def get_aligned_pairs(self):
+        out, q, r = [], 0, self.reference_start
+        for op, l in self.cigartuples:
+            if op in (0, 7, 8):
+                out.extend((q + i, r + i) for i in range(l)); q += l; r += l
+            elif op in (1, 4):
+                out.extend((q + i, None) for i in range(l)); q += l
+            elif op in (2, 3):
+                out.extend((None, r + i) for i in range(l)); r += l
+        return out
 
     @classmethod
     def fromstring(cls, line, header=None):
@@ -85,9 +129,24 @@ class AlignmentFile:
                 elif line.strip():
                     self._reads.append(AlignedSegment(line))
         self.header = self
+        self._it = iter(self._reads)
 
     def __iter__(self):
         return iter(self._reads)
+
+    def __next__(self):
+        return next(self._it)
+
+    def as_dict(self):
+        d = {}
+        for line in self.header_lines:
+            f = line.split('\t')
+            d.setdefault(f[0][1:], []).append({x[:2]: x[3:] for x in f[1:]})
+        return d
+
+    def get_index_statistics(self):
+        import collections
+        return [collections.namedtuple('IndexStats', 'contig mapped unmapped total')('*', len(self._reads), 0, len(self._reads))]
 
 
 class FastaFile:

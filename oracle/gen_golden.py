@@ -198,6 +198,42 @@ def run_bench_case(name, c, tmp):
                                                           arrs['errors'].sum(), arrs['skips'].sum()), flush=True)
 
 
+BQSR_CASES = {'bqsr_a': dict(seed=21, npairs=150, S=60), 'bqsr_b': dict(seed=22, npairs=80, S=37, nrg=2)}
+
+
+def run_bqsr_case(name, c, tmp):
+    """BAM-sourced tally: the reference's bam_to_bqsr_covariates and its
+    per-read covariate / trimming functions on synthetic alignments (SAM text through the
+    stand-in reader)."""
+    import oracle_bqsr as OQ
+    import pysam
+    from kbbq import compare_reads as utils
+    from kbbq.gatk import bqsr
+    d = os.path.join(tmp, name); os.makedirs(d)
+    paths = OQ.synth_bqsr_set(d, **c)
+    sha = {k: O.sha256(open(v, 'rb').read()) for k, v in paths.items()}
+    var_pos = utils.get_var_sites(paths['vcf'])
+    vectors = bqsr.bam_to_bqsr_covariates(pysam.AlignmentFile(paths['sam']), paths['fa'], var_pos)
+    keys = ['meanq', 'rg_errs', 'rg_total', 'q_errs', 'q_total', 'pos_errs', 'pos_total',
+            'dinuc_errs', 'dinuc_total']
+    arrs = {k: np.asarray(v).astype(np.int64) for k, v in zip(keys, vectors)}
+    reads = list(pysam.AlignmentFile(paths['sam']))
+    arrs['cycle'] = np.concatenate([bqsr.bamread_bqsr_cycle(r) for r in reads]).astype(np.int64)
+    arrs['dinuc'] = np.concatenate([bqsr.bamread_bqsr_dinuc(r) for r in reads]).astype(np.int64)
+    arrs['trim'] = np.concatenate([bqsr.trim_bamread(r) for r in reads]).astype(np.uint8)
+    arrs['boundary'] = np.array([-(2 ** 40) if bqsr.bamread_adaptor_boundary(r) is None
+                                 else bqsr.bamread_adaptor_boundary(r) for r in reads], dtype=np.int64)
+    bam = pysam.AlignmentFile(paths['sam'])
+    rep = str(bqsr.bam_to_report(bam, paths['fa'], var_pos))
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), **arrs)
+    with open(os.path.join(GOLD, name + '.json'), 'w') as fh:
+        json.dump(dict(case=c, input_sha256=sha, rg_to_pu=utils.get_rg_to_pu(bam),
+                       report_sha256=O.sha256(rep), report_len=len(rep)), fh, indent=1)
+    print('%-18s reads=%d counted=%d errors=%d trimmed=%d meanq=%s' % (
+        name, len(reads), arrs['rg_total'].sum(), arrs['rg_errs'].sum(), arrs['trim'].sum(),
+        arrs['meanq'].tolist()), flush=True)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     _shim.install()
@@ -216,6 +252,10 @@ def main():
             if only and name not in only:
                 continue
             run_bench_case(name, c, tmp)
+        for name, c in BQSR_CASES.items():
+            if only and name not in only:
+                continue
+            run_bqsr_case(name, c, tmp)
     if not only:
         info, arrs = numeric_tables(utils)
         info['versions'] = dict(numpy=np.__version__, scipy=scipy.__version__,

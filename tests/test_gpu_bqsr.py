@@ -1,0 +1,157 @@
+"""
+GPU tests (-m gpu) of the BAM-sourced tally: K4 -> K6 -> K1 behind
+kbbq.gatk.bqsr.bam_to_bqsr_covariates, against goldens from the UNMODIFIED reference
+(tests/golden/bqsr_*), the reference's known answer (tests/test_gatk_bqsr.py:38-72) and the
+oracle (oracle/oracle_bqsr.py) on further synthetic alignments and error cases.
+"""
+import numpy as np
+import pytest
+
+from test_gpu_parity import dev                      # noqa: F401  (fixture)
+from test_oracle_bqsr import SIMPLE_FASTA, VEC, _inputs, _load
+
+pytestmark = pytest.mark.gpu
+
+
+def _var_pos(path):
+    from kbbq import benchmark
+    return benchmark.get_var_sites(path)
+
+
+def _oracle_vectors(paths, minscore=6):
+    import _shim
+    import oracle_bqsr as OQ
+    bam = _shim.AlignmentFile(paths['sam'])
+    fa = _shim.FastaFile(paths['fa'])
+    ref = {c: fa.fetch(c) for c in fa.references}
+    rgs = [rg['ID'] for rg in bam.as_dict()['RG']]
+    return OQ.bam_to_bqsr_covariates(list(bam), rgs, ref, _var_pos(paths['vcf']), minscore=minscore)
+
+
+@pytest.mark.parametrize('name', ['bqsr_a', 'bqsr_b'])
+def test_tally_matches_reference_goldens(dev, oracle, name, tmp_path):
+    from kbbq import aln
+    from kbbq.gatk import bqsr
+    info, gold, paths = _inputs(name, tmp_path, oracle)
+    got = bqsr.bam_to_bqsr_covariates(aln.AlignmentFile(paths['sam']), paths['fa'], _var_pos(paths['vcf']))
+    assert len(got) == 9
+    for k, g in zip(VEC, got):
+        assert g.dtype == np.int64 and np.array_equal(g, gold[k]), k
+    rep = str(bqsr.bam_to_report(aln.AlignmentFile(paths['sam']), paths['fa'], _var_pos(paths['vcf'])))
+    assert len(rep) == info['report_len'] and oracle.sha256(rep) == info['report_sha256']
+
+
+def test_known_answer_of_the_reference(dev, tmp_path):
+    """One hard-clipped base of quality 7 (tests/test_gatk_bqsr.py:38-72); meanq 6 is the
+    reference's own 'float badness'."""
+    from kbbq import aln
+    from kbbq.gatk import bqsr
+    fa = tmp_path / 'simple.fa'; fa.write_text(SIMPLE_FASTA)
+    sam = tmp_path / 't.sam'
+    sam.write_text('@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:ref\tLN:45\n@RG\tID:0\tPU:0\n'
+                   'clipped\t0\tref\t9\t255\t1M9H\t*\t0\t0\tA\t(\tOQ:Z:(\tRG:Z:0\n')
+    got = bqsr.bam_to_bqsr_covariates(aln.AlignmentFile(str(sam)), str(fa), {'ref': [9]})
+    z = lambda *s: np.zeros(s, dtype=np.int64)
+    qt = z(1, 43); qt[0, 7] = 1
+    pt = z(1, 43, 2); pt[0, 7, 0] = 1
+    want = [np.array([6]), np.array([0]), np.array([1]), z(1, 43), qt, z(1, 43, 2), pt, z(1, 43, 16), z(1, 43, 16)]
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+@pytest.mark.parametrize('shape', [dict(seed=31, npairs=400, S=150), dict(seed=32, npairs=300, S=151),
+                                   dict(seed=33, npairs=200, S=16, contigs=(('c', 2500),)),
+                                   dict(seed=34, npairs=300, S=100, nrg=5),
+                                   dict(seed=35, npairs=100, S=33, contigs=(('a', 1500), ('b', 1200), ('c', 1400)))])
+@pytest.mark.parametrize('minscore', [6, 2, 15])
+def test_tally_matches_oracle(dev, oracle, shape, minscore, tmp_path):
+    import oracle_bqsr as OQ
+    from kbbq import aln
+    from kbbq.gatk import bqsr
+    paths = OQ.synth_bqsr_set(str(tmp_path), **shape)
+    want = _oracle_vectors(paths, minscore)
+    got = bqsr.bam_to_bqsr_covariates(aln.AlignmentFile(paths['sam']), paths['fa'], _var_pos(paths['vcf']),
+                                      minscore=minscore)
+    for k, g, w in zip(VEC, got, want):
+        assert np.array_equal(g, w), k
+    assert want[2].sum() > 1000
+
+
+def _edit_sam(paths, fn):
+    lines = open(paths['sam']).read().split('\n')
+    out = []
+    idx = 0
+    for ln in lines:
+        if ln and not ln.startswith('@'):
+            ln = fn(idx, ln.split('\t'))
+            idx += 1
+            ln = '\t'.join(ln)
+        out.append(ln)
+    open(paths['sam'], 'w').write('\n'.join(out))
+
+
+def test_error_behaviour(dev, oracle, tmp_path):
+    import oracle_bqsr as OQ
+    from kbbq import aln
+    from kbbq.gatk import bqsr
+    run = lambda p: bqsr.bam_to_bqsr_covariates(aln.AlignmentFile(p['sam']), p['fa'], _var_pos(p['vcf']))
+
+    # a letter outside ACGTN: harmless on a reverse-strand read (complemented to N), TypeError on a forward read
+    d = tmp_path / 'a'; d.mkdir()
+    paths = OQ.synth_bqsr_set(str(d), seed=41, npairs=60, S=50)
+
+    def weird_reverse(i, f):
+        if int(f[1]) & 16 and i % 3 == 0:
+            f[9] = f[9][:20] + 'R' + f[9][21:]
+            f[-1] = f[-1][:7 + 18] + 'IIIII' + f[-1][7 + 23:]            # OQ:Z: prefix is 5 chars... keep length
+        return f
+    _edit_sam(paths, weird_reverse)
+    want = _oracle_vectors(paths)
+    for k, g, w in zip(VEC, run(paths), want):
+        assert np.array_equal(g, w), k
+
+    def weird_forward(i, f):
+        if not int(f[1]) & 16 and i == 10:
+            tag = f[-1]
+            f[9] = f[9][:25] + 'R' + f[9][26:]
+            f[-1] = tag[:5] + 'I' * (len(tag) - 5)                       # every base well above minscore
+            f[5] = '%dM' % len(f[9])
+        return f
+    _edit_sam(paths, weird_forward)
+    with pytest.raises(TypeError):
+        _oracle_vectors(paths)
+    with pytest.raises(TypeError):
+        run(paths)
+
+    # a read of another length than the first: the reference's boolean masks no longer fit
+    d = tmp_path / 'b'; d.mkdir()
+    paths = OQ.synth_bqsr_set(str(d), seed=42, npairs=20, S=40)
+
+    def shorter(i, f):
+        if i == 7:
+            f[9], f[10], f[-1], f[5] = f[9][:30], f[10][:30], f[-1][:5 + 30], '30M'
+        return f
+    _edit_sam(paths, shorter)
+    with pytest.raises(IndexError):
+        _oracle_vectors(paths)
+    with pytest.raises(IndexError):
+        run(paths)
+
+    # quality above 42 on a counted base: IndexError (np.add.at into a 43-wide axis)
+    d = tmp_path / 'c'; d.mkdir()
+    paths = OQ.synth_bqsr_set(str(d), seed=43, npairs=20, S=40)
+
+    def high_q(i, f):
+        if i == 3:
+            f[-1] = f[-1][:5] + 'L' * 40                                  # 'L' = 43
+            f[5] = '40M'
+        return f
+    _edit_sam(paths, high_q)
+    with pytest.raises(IndexError):
+        _oracle_vectors(paths)
+    with pytest.raises(IndexError):
+        run(paths)
+
+    # a contig without variant sites: KeyError, as var_pos[chrom] in the reference
+    with pytest.raises(KeyError):
+        bqsr.bam_to_bqsr_covariates(aln.AlignmentFile(paths['sam']), paths['fa'], {'chr1': [5]})
