@@ -198,8 +198,9 @@ int    kbbq_solve_dev(kbbq_ctx* ctx, const int64_t* d_tables, int R, int S2, int
  * (skip mask = benchmark.get_full_skips, benchmark.py:22-39); cigar ops are
  * (length << 4 | op) with BAM op codes.  Outputs one byte per base (0 / 1) in the err and
  * skip planes; flip[r] != 0 reverses both for reverse-strand reads (benchmark.py:70-72).
- * All buffers 16-byte aligned; seq, genome and skipmask need 32 readable bytes of slack past
- * their last byte (unaligned 16-byte windows are fetched as two aligned loads).
+ * The planes (seq, err, skip) are 16-byte aligned; reference windows are read with unaligned
+ * 16-byte loads that may run up to 15 bytes past a read's window: genome and skipmask need 16
+ * readable bytes after their last byte.
  * Python's negative-index wraps of the reference (skips[-1], subset[-1]) are reproduced;
  * its IndexError / ValueError cases arrive through kbbq_ctx_status as KBBQ_E_INDEX /
  * KBBQ_E_RANGE.
@@ -221,8 +222,9 @@ int kbbq_find_errors_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint32_t* d_
  * it is N; out_cseq differs from out_seq exactly where the K4 error flag is set; out_meta =
  * S | read group (flags >> 16) << 16 | read 2 (flags bit 1) << 31.  The reference's TypeError
  * (a looked-up dinucleotide with a letter outside ACGT on a forward read, decided on the
- * ORIGINAL qualities with dinuc_minscore) arrives as KBBQ_E_TYPE.  Input planes need one
- * spare row of slack; all planes 16-byte aligned.                                      */
+ * ORIGINAL qualities with dinuc_minscore) arrives as KBBQ_E_TYPE.  All planes 16-byte
+ * aligned; the four input planes need 16 readable bytes after their last row (windows of
+ * the last chunk of a read are fetched whole).                                          */
 int kbbq_canonical_reads_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_oq, const uint8_t* d_err,
                              const uint8_t* d_skip, const uint32_t* d_len, const uint32_t* d_clip,
                              const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads, int pitch, int S,

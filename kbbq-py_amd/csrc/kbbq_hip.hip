@@ -629,8 +629,8 @@ int kbbq_find_errors_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint32_t* d_le
     p.status = c->d_status;
     if (((uintptr_t)d_seq | (uintptr_t)d_genome | (uintptr_t)d_skipmask | (uintptr_t)d_err | (uintptr_t)d_skip) & 15)
         return fail(KBBQ_E_ARG, "kbbq_find_errors_dev: buffers must be 16-byte aligned");
-    const int64_t nchunks4 = nreads * (pitch / 16);
-    int gx = (int)std::min<int64_t>((nchunks4 + 255) / 256, (int64_t)c->cus * 16);
+    const int rpb4 = (pitch / 16) <= 256 ? 256 / (pitch / 16) : 1;              // reads per workgroup iteration
+    int gx = (int)std::min<int64_t>((nreads + rpb4 - 1) / rpb4, (int64_t)c->cus * 16);
     hipLaunchKernelGGL(k4_find_errors, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
@@ -658,8 +658,8 @@ int kbbq_canonical_reads_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d
     p.qlo = 33u + (u32)minscore; p.dlo = 33u + (u32)dinuc_minscore;
     p.out_seq = d_out_seq; p.out_cseq = d_out_cseq; p.out_qual = d_out_qual; p.out_meta = d_out_meta;
     p.status = c->d_status;
-    const int64_t nchunks = nreads * (pitch / 16);
-    int gx = (int)std::min<int64_t>((nchunks + 255) / 256, (int64_t)c->cus * 16);
+    const int rpb6 = (pitch / 16) <= 256 ? 256 / (pitch / 16) : 1;
+    int gx = (int)std::min<int64_t>((nreads + rpb6 - 1) / rpb6, (int64_t)c->cus * 16);
     hipLaunchKernelGGL(k6_canonical_reads, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;

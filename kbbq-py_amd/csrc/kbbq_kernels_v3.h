@@ -531,24 +531,14 @@ struct K4Params {
     uint8_t* err; uint8_t* skip; u64* status;
 };
 
-// 16 bytes starting at any byte offset of a 16-byte-aligned array (two aligned loads + a byte
-// funnel shift).  The caller guarantees 32 readable bytes past the last byte it asks for.
+// 16 bytes starting at ANY byte offset: one global_load_dwordx4 with an unaligned address (the
+// amdhsa targets run with unaligned access mode on; the compiler itself emits this for a
+// 1-byte-aligned 16-byte copy).  The caller guarantees the 16 bytes are readable.
 __device__ __forceinline__ void load16_any(const uint8_t* base, long long off, u32 out[4])
 {
-    const uint4* p = reinterpret_cast<const uint4*>(base + (off & ~15ll));
-    const uint4 lo = p[0], hi = p[1];
-    const int ws = (int)(off & 15) >> 2;                 // whole words to drop
-    const u32 bs = ((u32)off & 3u) * 8u;                 // then bits
-    u32 w0 = lo.x, w1 = lo.y, w2 = lo.z, w3 = lo.w, w4 = hi.x, w5 = hi.y, w6 = hi.z, w7 = hi.w;
-    u32 a0 = ws == 0 ? w0 : ws == 1 ? w1 : ws == 2 ? w2 : w3;
-    u32 a1 = ws == 0 ? w1 : ws == 1 ? w2 : ws == 2 ? w3 : w4;
-    u32 a2 = ws == 0 ? w2 : ws == 1 ? w3 : ws == 2 ? w4 : w5;
-    u32 a3 = ws == 0 ? w3 : ws == 1 ? w4 : ws == 2 ? w5 : w6;
-    u32 a4 = ws == 0 ? w4 : ws == 1 ? w5 : ws == 2 ? w6 : w7;
-    out[0] = __builtin_amdgcn_alignbit(a1, a0, bs);
-    out[1] = __builtin_amdgcn_alignbit(a2, a1, bs);
-    out[2] = __builtin_amdgcn_alignbit(a3, a2, bs);
-    out[3] = __builtin_amdgcn_alignbit(a4, a3, bs);
+    uint4 v;
+    __builtin_memcpy(&v, base + off, 16);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
 }
 
 // 0x01 in every byte of x that is non-zero
@@ -572,23 +562,47 @@ __device__ __forceinline__ u32 get_byte(const u32 v[4], int i)
     return (w >> (8 * (i & 3))) & 0xFFu;
 }
 
+// 0xFF in the bytes of word w (of a 16-byte vector) whose position p = 4w + k lies in [lo, hi)
+__device__ __forceinline__ u32 range_mask(int lo, int hi, int w) { return byte_mask(hi, w) & ~byte_mask(lo, w); }
+
+__device__ __forceinline__ void reverse16(u32 v[4])                      // byte i <- byte 15 - i
+{
+    const u32 a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+    v[0] = __builtin_amdgcn_perm(0u, a3, 0x00010203u); v[1] = __builtin_amdgcn_perm(0u, a2, 0x00010203u);
+    v[2] = __builtin_amdgcn_perm(0u, a1, 0x00010203u); v[3] = __builtin_amdgcn_perm(0u, a0, 0x00010203u);
+}
+
+__device__ __forceinline__ void shr_bytes16(u32 v[4], int nb)            // byte i <- byte i + nb (0 <= nb <= 15), zero fill
+{
+    const int ws = nb >> 2; const u32 bs = (u32)(nb & 3) * 8u;
+    const u32 a0 = ws == 0 ? v[0] : ws == 1 ? v[1] : ws == 2 ? v[2] : v[3];
+    const u32 a1 = ws == 0 ? v[1] : ws == 1 ? v[2] : ws == 2 ? v[3] : 0u;
+    const u32 a2 = ws == 0 ? v[2] : ws == 1 ? v[3] : 0u;
+    const u32 a3 = ws == 0 ? v[3] : 0u;
+    v[0] = __builtin_amdgcn_alignbit(a1, a0, bs); v[1] = __builtin_amdgcn_alignbit(a2, a1, bs);
+    v[2] = __builtin_amdgcn_alignbit(a3, a2, bs); v[3] = a3 >> bs;
+}
+
 // lane <-> one 16-byte OUTPUT chunk of one read.  The lane walks the read's (short) CIGAR in
 // order and applies every operation's effect to its own 16 positions in that order, which is
 // exactly the reference's sequential semantics (an M assigns, a later D/N ORs into the base
 // before it, Python's index -1 wraps: skips[-1], subset[-1]).  A chunk that lies wholly inside
 // one M/=/X operation -- the common case -- is 16 bytes of read against 16 bytes of reference
-// and of the site mask (unaligned windows: two aligned loads + funnel shift), compared
+// and of the site mask (unaligned 16-byte loads), compared
 // byte-parallel.  For reverse-strand reads the OUTPUT is reversed (benchmark.py:70-72): the
 // lane's input positions are then [n-16j-16, n-16j) and its 16 result bytes are byte-reversed.
-// seq / genome / skipmask need 32 readable bytes of slack past their last byte.
 __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
 {
+    // a workgroup takes 256 / cpr whole reads per iteration: (slot, chunk) of a thread are fixed
     const int cpr = p.pitch >> 4;
-    const long long nchunks = p.nreads * cpr;
-    for (long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks;
-         ch += (long long)gridDim.x * blockDim.x) {
-        const long long r = ch / cpr;
-        const int j = (int)(ch - r * cpr);
+    const int rpb = cpr <= 256 ? 256 / cpr : 0;
+    const int slot = cpr <= 256 ? (int)threadIdx.x / cpr : 0;
+    const int j0 = (int)threadIdx.x - slot * cpr;
+    const long long step = rpb ? rpb : 1;
+    for (long long rb = (long long)blockIdx.x * step; rb < p.nreads; rb += (long long)gridDim.x * step)
+    for (int j = j0; j < cpr; j += 256) {                          // one trip unless a row has more than 256 chunks
+        const long long r = rb + slot;
+        if (r >= p.nreads || (rpb && slot >= rpb)) break;
         const int n = (int)p.len[r];
         const int rl = p.ref_len[r];
         const bool f = p.flip[r] != 0;
@@ -603,21 +617,30 @@ __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
             int readidx = 0, refidx = 0;
             const u32* ops = p.cigar + p.cig_off[r];
             const u32 nc = p.cig_n[r];
+            u32 sw[4];
+            load16_any(s, in_lo, sw);                                      // the chunk's read bytes (may run into the next row)
             for (u32 c = 0; c < nc; ++c) {
                 const int op = (int)(ops[c] & 15u), l = (int)(ops[c] >> 4);
                 if (op == 0 || op == 7 || op == 8) {                       // M = X  (:109-114)
                     if (refidx + l > rl || readidx + l > n) { flag(p.status, ST_RANGE, r); break; }   // shape mismatch: ValueError
                     const int a = readidx > in_lo ? readidx : in_lo, b = readidx + l < in_hi ? readidx + l : in_hi;
                     if (a < b) {
-                        const long long roff = g0 + refidx + (a - readidx);
-                        if (b - a == 16) {                                 // the whole chunk inside this operation
-                            u32 sw[4], gw[4], mw[4];
-                            load16_any(s, a, sw);
-                            load16_any(p.genome, roff, gw);
-                            load16_any(p.skipmask, roff, mw);
+                        // reference window aligned with the CHUNK start (as if the operation began there):
+                        // bytes [a - in_lo, b - in_lo) of the comparison belong to this operation
+                        const int d = a - in_lo;
+                        const long long goff = g0 + refidx + (a - readidx) - d;
+                        if (goff >= 0) {
+                            u32 gw[4], mw[4];
+                            load16_any(p.genome, goff, gw);
+                            load16_any(p.skipmask, goff, mw);
 #pragma unroll
-                            for (int w = 0; w < 4; ++w) { ev[w] = nonzero_bytes(sw[w] ^ gw[w]); kv[w] = nonzero_bytes(mw[w]); }
-                        } else {
+                            for (int w = 0; w < 4; ++w) {
+                                const u32 rm = range_mask(d, b - in_lo, w);
+                                ev[w] = (ev[w] & ~rm) | (nonzero_bytes(sw[w] ^ gw[w]) & rm);
+                                kv[w] = (kv[w] & ~rm) | (nonzero_bytes(mw[w]) & rm);
+                            }
+                        } else {                                           // within 15 bytes of the genome's first byte
+                            const long long roff = g0 + refidx + (a - readidx);
                             for (int q = a; q < b; ++q) {
                                 set_byte(ev, q - in_lo, p.genome[roff + (q - a)] != s[q] ? 1u : 0u);
                                 set_byte(kv, q - in_lo, p.skipmask[roff + (q - a)] != 0 ? 1u : 0u);
@@ -630,7 +653,11 @@ __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
                     const int left = refidx - 1 < 0 ? rl - 1 : refidx - 1;               // Python wraps index -1
                     const u32 both = (p.skipmask[g0 + left] != 0 && p.skipmask[g0 + refidx] != 0) ? 1u : 0u;
                     const int a = readidx > in_lo ? readidx : in_lo, b = readidx + l < in_hi ? readidx + l : in_hi;
-                    for (int q = a; q < b; ++q) set_byte(kv, q - in_lo, both);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const u32 rm = range_mask(a - in_lo, b - in_lo, w);
+                        kv[w] = (kv[w] & ~rm) | ((both * 0x01010101u) & rm);
+                    }
                     readidx += l;
                 } else if (op == 2 || op == 3) {                           // D N    (:121-125)
                     if (n == 0) { flag(p.status, ST_INDEX, r); break; }
@@ -644,24 +671,18 @@ __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
                     refidx += l;
                 } else if (op == 4) {                                      // S      (:126-129)
                     const int a = readidx > in_lo ? readidx : in_lo, b = readidx + l < in_hi ? readidx + l : in_hi;
-                    for (int q = a; q < b; ++q) set_byte(kv, q - in_lo, 1u);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const u32 rm = range_mask(a - in_lo, b - in_lo, w);
+                        kv[w] = (kv[w] & ~rm) | (0x01010101u & rm);
+                    }
                     readidx += l;
                 } else if (op == 5 || op == 6) {                           // H P    (:130-134)
                 } else { flag(p.status, ST_RANGE, r); break; }             // unrecognised operation: ValueError
             }
             if (f) {                                                       // output byte i = input byte cnt-1-i
-                if (cnt == 16) {
-                    const u32 e0 = ev[0], e1 = ev[1], e2 = ev[2], e3 = ev[3], k0 = kv[0], k1 = kv[1], k2 = kv[2], k3 = kv[3];
-                    ev[0] = __builtin_amdgcn_perm(0u, e3, 0x00010203u); ev[1] = __builtin_amdgcn_perm(0u, e2, 0x00010203u);
-                    ev[2] = __builtin_amdgcn_perm(0u, e1, 0x00010203u); ev[3] = __builtin_amdgcn_perm(0u, e0, 0x00010203u);
-                    kv[0] = __builtin_amdgcn_perm(0u, k3, 0x00010203u); kv[1] = __builtin_amdgcn_perm(0u, k2, 0x00010203u);
-                    kv[2] = __builtin_amdgcn_perm(0u, k1, 0x00010203u); kv[3] = __builtin_amdgcn_perm(0u, k0, 0x00010203u);
-                } else {
-                    u32 e2v[4] = {0u, 0u, 0u, 0u}, k2v[4] = {0u, 0u, 0u, 0u};
-                    for (int i = 0; i < cnt; ++i) { set_byte(e2v, i, get_byte(ev, cnt - 1 - i)); set_byte(k2v, i, get_byte(kv, cnt - 1 - i)); }
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) { ev[w] = e2v[w]; kv[w] = k2v[w]; }
-                }
+                reverse16(ev); reverse16(kv);
+                shr_bytes16(ev, 16 - cnt); shr_bytes16(kv, 16 - cnt);
             }
         }
         const size_t off = (size_t)r * p.pitch + (size_t)16 * j;
@@ -683,7 +704,7 @@ __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
 // `second` bit = is_read2 (column 2S-1-c), context from the canonical neighbours.
 // lane <-> one 16-byte OUTPUT chunk; input windows are unaligned (load16_any).
 struct K6Params {
-    const uint8_t* seq; const uint8_t* oq; const uint8_t* err; const uint8_t* skip;   // [nreads(+1 slack row), pitch]
+    const uint8_t* seq; const uint8_t* oq; const uint8_t* err; const uint8_t* skip;   // [nreads, pitch]
     const u32* len;                  // query length (must be S: checked on the host)
     const u32* clip;                 // query_alignment_start | query_alignment_end << 16
     const u32* trim;                 // skipped range lo | hi << 16 (lo == hi: none)
@@ -707,11 +728,14 @@ __device__ __forceinline__ bool is_acgt(u32 ch) { return ch == 'A' || ch == 'C' 
 __global__ __launch_bounds__(256) void k6_canonical_reads(K6Params p)
 {
     const int cpr = p.pitch >> 4;
-    const long long nchunks = p.nreads * cpr;
-    for (long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks;
-         ch += (long long)gridDim.x * blockDim.x) {
-        const long long r = ch / cpr;
-        const int j = (int)(ch - r * cpr);
+    const int rpb = cpr <= 256 ? 256 / cpr : 0;
+    const int slot = cpr <= 256 ? (int)threadIdx.x / cpr : 0;
+    const int j0 = (int)threadIdx.x - slot * cpr;
+    const long long step = rpb ? rpb : 1;
+    for (long long rb = (long long)blockIdx.x * step; rb < p.nreads; rb += (long long)gridDim.x * step)
+    for (int j = j0; j < cpr; j += 256) {
+        const long long r = rb + slot;
+        if (r >= p.nreads || (rpb && slot >= rpb)) break;
         const u32 fl = p.flags[r];
         const bool rev = (fl & 1u) != 0;
         const int qs = (int)(p.clip[r] & 0xFFFFu), qe = (int)(p.clip[r] >> 16);
@@ -723,9 +747,11 @@ __global__ __launch_bounds__(256) void k6_canonical_reads(K6Params p)
         u32 oqv[4] = {0u, 0u, 0u, 0u};
         const size_t row = (size_t)r * p.pitch;
         if (j == 0) p.out_meta[r] = (u32)p.S | ((fl >> 16) << 16) | ((fl & 2u) ? 0x80000000u : 0u);
-        if (c0 + 16 <= L) {
-            // whole chunk inside the aligned part: input positions [i0, i0 + 16), reversed when rev
-            const int i0 = rev ? qe - c0 - 16 : qs + c0;
+        if (c0 < L) {
+            // input window [i0, i0 + 16): the chunk's bases in INPUT order occupy its first cnt bytes
+            // (a reverse-strand chunk is byte-reversed afterwards; a partial one then shifted down)
+            const int cnt = L - c0 < 16 ? L - c0 : 16;
+            const int i0 = rev ? (cnt == 16 ? qe - c0 - 16 : qs) : qs + c0;
             u32 s[4], q[4], e[4], k[4];
             load16_any(p.seq, (long long)row + i0, s);
             load16_any(p.oq, (long long)row + i0, q);
@@ -735,12 +761,12 @@ __global__ __launch_bounds__(256) void k6_canonical_reads(K6Params p)
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const u32 below = (~((q[w] | 0x80808080u) - p.qlo * 0x01010101u) >> 7) & 0x01010101u;   // q < minscore
-                const u32 trimmed = (byte_mask(thi - i0, w) & ~byte_mask(tlo - i0, w)) & 0x01010101u;
+                const u32 trimmed = range_mask(tlo - i0, thi - i0, w) & 0x01010101u;
                 const u32 isn = nonzero_bytes(s[w] ^ 0x4E4E4E4Eu) ^ 0x01010101u;
                 const u32 sk = (nonzero_bytes(k[w]) | below | trimmed | isn) * 0xFFu;
                 u32 code, code5, expect;
                 decode4x(s[w], code, code5, expect);
-                odd |= (expect != s[w]);
+                odd |= ((expect ^ s[w]) & byte_mask(cnt, w)) != 0u;
                 os[w] = rev ? complement4(s[w]) : s[w];
                 oc[w] = os[w] ^ (nonzero_bytes(e[w]) << 7);                    // an error: cseq differs from seq
                 oqv[w] = q[w] & ~sk;
@@ -749,7 +775,7 @@ __global__ __launch_bounds__(256) void k6_canonical_reads(K6Params p)
                 // the reference's TypeError (compare_reads.py:281-293 via bqsr.py:43-45) is decided on the
                 // ORIGINAL qualities, before any skipping: a looked-up pair with a letter outside ACGT
                 u32 prev = (c0 >= 1) ? p.seq[row + i0 - 1] : 'N';
-                for (int b = 0; b < 16; ++b) {
+                for (int b = 0; b < cnt; ++b) {
                     const u32 cur = (s[b >> 2] >> (8 * (b & 3))) & 0xFFu, qq = (q[b >> 2] >> (8 * (b & 3))) & 0xFFu;
                     if (c0 + b >= 1 && qq >= p.dlo && cur != 'N' && prev != 'N' && !(is_acgt(cur) && is_acgt(prev)))
                         flag(p.status, ST_TYPE, r);
@@ -757,32 +783,17 @@ __global__ __launch_bounds__(256) void k6_canonical_reads(K6Params p)
                 }
             }
             if (rev) {
-                const u32 a0 = os[0], a1 = os[1], a2 = os[2], a3 = os[3];
-                os[0] = __builtin_amdgcn_perm(0u, a3, 0x00010203u); os[1] = __builtin_amdgcn_perm(0u, a2, 0x00010203u);
-                os[2] = __builtin_amdgcn_perm(0u, a1, 0x00010203u); os[3] = __builtin_amdgcn_perm(0u, a0, 0x00010203u);
-                const u32 b0 = oc[0], b1 = oc[1], b2 = oc[2], b3 = oc[3];
-                oc[0] = __builtin_amdgcn_perm(0u, b3, 0x00010203u); oc[1] = __builtin_amdgcn_perm(0u, b2, 0x00010203u);
-                oc[2] = __builtin_amdgcn_perm(0u, b1, 0x00010203u); oc[3] = __builtin_amdgcn_perm(0u, b0, 0x00010203u);
-                const u32 d0 = oqv[0], d1 = oqv[1], d2 = oqv[2], d3 = oqv[3];
-                oqv[0] = __builtin_amdgcn_perm(0u, d3, 0x00010203u); oqv[1] = __builtin_amdgcn_perm(0u, d2, 0x00010203u);
-                oqv[2] = __builtin_amdgcn_perm(0u, d1, 0x00010203u); oqv[3] = __builtin_amdgcn_perm(0u, d0, 0x00010203u);
+                reverse16(os); reverse16(oc); reverse16(oqv);
+                if (cnt < 16) { shr_bytes16(os, 16 - cnt); shr_bytes16(oc, 16 - cnt); shr_bytes16(oqv, 16 - cnt); }
             }
-        } else if (c0 < L) {
-            // the last, partial chunk of the aligned part: byte by byte
-            for (int b = 0; b < L - c0; ++b) {
-                const int c = c0 + b;
-                const int i = rev ? qe - 1 - c : qs + c;
-                const u32 ch0 = p.seq[row + i], qq = p.oq[row + i];
-                const bool sk = p.skip[row + i] != 0 || qq < p.qlo || (i >= tlo && i < thi) || ch0 == 'N';
-                u32 outc = ch0;
-                if (rev) outc = ch0 == 'A' ? 'T' : ch0 == 'T' ? 'A' : ch0 == 'C' ? 'G' : ch0 == 'G' ? 'C' : 'N';
-                else if (c >= 1) {
-                    const u32 prev = p.seq[row + i - 1];
-                    if (qq >= p.dlo && ch0 != 'N' && prev != 'N' && !(is_acgt(ch0) && is_acgt(prev))) flag(p.status, ST_TYPE, r);
+            if (cnt < 16) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {                                  // past the aligned part: uncounted padding
+                    const u32 vm = byte_mask(cnt, w);
+                    os[w] = (os[w] & vm) | (0x4E4E4E4Eu & ~vm);
+                    oc[w] = (oc[w] & vm) | (0x4E4E4E4Eu & ~vm);
+                    oqv[w] &= vm;
                 }
-                set_byte(os, b, outc);
-                set_byte(oc, b, p.err[row + i] ? (outc ^ 0x80u) : outc);
-                set_byte(oqv, b, sk ? 0u : qq);
             }
         }
         const size_t off = row + (size_t)16 * j;

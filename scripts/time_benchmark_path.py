@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Kernel timing of the benchmark path (K4 find_errors, K5 count_q) on synthetic aligned reads
-built directly as arrays (no SAM text): n reads x L bases against a random genome."""
+"""Kernel timing of the benchmark path (K4 find_errors, K5 count_q) and of the BAM-sourced tally
+(K4 -> K6 canonical reads -> K1) on synthetic aligned reads built directly as arrays (no SAM
+text): n reads x L bases against a random genome."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'kbbq-py_amd'))
 ap = argparse.ArgumentParser(); ap.add_argument('--reads', type=int, default=4_000_000); ap.add_argument('--len', type=int, default=150)
 ap.add_argument('--genome', type=int, default=200_000_000)
+ap.add_argument('--sorted', action='store_true', help='reads in coordinate order (a sorted BAM) instead of random order')
 a = ap.parse_args()
 import numpy as np, torch
 from kbbq import _device as dev, _native as N
@@ -15,6 +17,8 @@ g = torch.randint(0, 4, (G,), dtype=torch.uint8, device='cuda')
 genome = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device='cuda')[g.long()]
 mask = (torch.rand(G, device='cuda') < 0.01).to(torch.uint8)
 start = torch.randint(0, G - 2 * L - 64, (n,), dtype=torch.int64, device='cuda')
+if a.sorted:
+    start = torch.sort(start).values
 idx = start[:, None] + torch.arange(pitch, device='cuda')[None, :]
 seq = genome[idx]                                    # reads = reference windows ...
 err_at = torch.rand((n, pitch), device='cuda') < 0.01
@@ -32,8 +36,8 @@ o = cig_off.long()
 cigar[o[~ins]] = (L << 4) | 0
 cigar[o[ins]] = (50 << 4) | 0; cigar[o[ins] + 1] = (2 << 4) | 1; cigar[o[ins] + 2] = ((L - 52) << 4) | 0
 flip = (torch.rand(n, device='cuda') < 0.5).to(torch.uint8)
-err = torch.empty((n, pitch), dtype=torch.uint8, device='cuda'); skip = torch.empty_like(err)
-qual = torch.randint(2, 42, (n, pitch), dtype=torch.uint8, device='cuda')
+err = torch.zeros((n + 1, pitch), dtype=torch.uint8, device='cuda'); skip = torch.zeros_like(err)
+qual = torch.randint(2, 42, (n + 1, pitch), dtype=torch.uint8, device='cuda')
 counts = torch.zeros(512, dtype=torch.int64, device='cuda')
 ctx = dev.context(); lib = N.load()
 def k4():
@@ -42,7 +46,30 @@ def k4():
                                      N.ptr(err), N.ptr(skip)))
 def k5():
     N.check(lib.kbbq_count_q_dev(ctx.handle, N.ptr(qual), N.ptr(err), N.ptr(skip), N.ptr(lens), n, pitch, 0, N.ptr(counts)))
-for f, name, bpb in ((k4, 'K4 find_errors', 5), (k5, 'K5 count_q', 3)):
+# BAM-sourced tally: K4 flags (not flipped) -> K6 -> K1
+oq = qual + 33
+noflip = torch.zeros_like(flip)
+clip = torch.full((n,), L << 16, dtype=torch.int32, device='cuda')
+soft = torch.rand(n, device='cuda') < 0.2                      # 20 % of the reads carry 5-base soft clips at both ends
+clip[soft] = 5 | ((L - 5) << 16)
+trim = torch.zeros(n, dtype=torch.int32, device='cuda')
+trimmed = torch.rand(n, device='cuda') < 0.05
+trim[trimmed] = (L - 20) | (L << 16)
+flags = (torch.randint(0, 4, (n,), device='cuda', dtype=torch.int32))      # strand and mate bits, read group 0
+batch = dev.ReadBatch(n, pitch, with_corrected=True)
+tables = dev.Tables(1, 2 * L)
+def k4n():
+    N.check(lib.kbbq_find_errors_dev(ctx.handle, N.ptr(seq), N.ptr(lens), n, pitch, N.ptr(start), N.ptr(ref_len),
+                                     N.ptr(cig_off), N.ptr(cig_n), N.ptr(cigar), N.ptr(genome), N.ptr(mask), N.ptr(noflip),
+                                     N.ptr(err), N.ptr(skip)))
+def k6():
+    N.check(lib.kbbq_canonical_reads_dev(ctx.handle, N.ptr(seq), N.ptr(oq), N.ptr(err), N.ptr(skip), N.ptr(lens),
+                                         N.ptr(clip), N.ptr(trim), N.ptr(flags), n, pitch, L, 6, 6,
+                                         N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual), N.ptr(batch.meta)))
+def k1():
+    dev.accumulate(batch, tables, 6, check=False, dinuc_minscore=6)
+for f, name, bpb in ((k4, 'K4 find_errors', 5), (k5, 'K5 count_q', 3), (k4n, 'K4 (no flip)', 5),
+                     (k6, 'K6 canonical_reads', 7), (k1, 'K1 on canonical reads', 3)):
     f(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3): f()
