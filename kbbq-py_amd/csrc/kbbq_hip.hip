@@ -460,7 +460,12 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
         q.full = reinterpret_cast<const int8_t*>(d_lut) + lut_full_offset(R, Qt, S2);
         q.full_bytes = (int)full_bytes;
         q.out = d_out; q.status = c->d_status;
-        int per_cu = std::max(1, std::min<int>((int)(c->lds_bytes / full_bytes), 2048 / K2V3_THREADS));
+#ifdef K2V3_PER_CU
+        int per_cu = K2V3_PER_CU;
+#else
+        // resident workgroups per CU: LDS copies of the LUT, and the register allocation's waves per SIMD
+        int per_cu = std::max(1, std::min<int>((int)(c->lds_bytes / full_bytes), (K2V3_WAVES * 4 * 64) / K2V3_THREADS));
+#endif
         const int64_t want = (nblocks + (K2V3_THREADS / 64) - 1) / (K2V3_THREADS / 64);
         int gx = (int)std::min<int64_t>(want, (int64_t)c->cus * per_cu);
         {

@@ -23,7 +23,15 @@
 
 #define K1V3_THREADS 1024        // one workgroup per CU: the replicated context table needs ~150 KB of LDS
 #define K1V3_DNREP 16            // copies of the context-total table (copy = lane & 15)
+#ifndef K2V3_THREADS
 #define K2V3_THREADS 512
+#endif
+#ifndef K2V3_NBUF
+#define K2V3_NBUF 2             // chunk buffers in the prefetch ring
+#endif
+#ifndef K2V3_WAVES
+#define K2V3_WAVES 4            // waves per SIMD the register allocation aims at
+#endif
 #define K1V3_FLUSH_ITERS 48          // 48 * 16 waves * 64 reads = 49,152 reads per workgroup between flushes (< 65,535)
 
 struct K1v3Params {
@@ -315,7 +323,7 @@ struct K2v3Params {
     uint8_t* out; u64* status;
 };
 
-__global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
+__global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2V3_WAVES, 8))) void k2v3_apply(K2v3Params p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     {
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
     const int lane_k0 = p.cpr == 1 ? lane : (int)__umulhi((u32)lane, p.cpr_magic);
     const int lane_j0 = lane - lane_k0 * p.cpr;
     const int dk1 = 64 / p.cpr, dj1 = 64 - dk1 * p.cpr;
-    const int dk2 = 128 / p.cpr, dj2 = 128 - dk2 * p.cpr;
+    const int dkn = (64 * K2V3_NBUF) / p.cpr, djn = 64 * K2V3_NBUF - dkn * p.cpr;
 
     for (long long blk = (long long)blockIdx.x * nwaves + wave; blk < nblocks;
          blk += (long long)gridDim.x * nwaves) {
@@ -392,6 +400,13 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
             carry_code = (u32)__builtin_amdgcn_readlane((int)last_code5, 63);
             carry_char = (u32)__builtin_amdgcn_readlane((int)last_char, 63);
             if (j == 0) { prev_code5 = 20u; prev_char = 0u; }
+#ifdef KBBQ_ABL_COPY
+            if (ch.act0) {      // timing-only build: the kernel's memory traffic with (almost) no work
+                *reinterpret_cast<uint4*>(bout + (__umul24((u32)k, (u32)p.pitch) + (u32)pos0)) =
+                    make_uint4(ch.q[0] ^ ch.s[0], ch.q[1] ^ ch.s[1], ch.q[2] ^ ch.s[2], ch.q[3] ^ ch.s[3]);
+                return;
+            }
+#endif
             if (ch.act0) {
                 u32 o[4] = {0u, 0u, 0u, 0u};
                 if (act) {
@@ -444,18 +459,24 @@ __global__ __launch_bounds__(K2V3_THREADS) void k2v3_apply(K2v3Params p)
         };
 
         if (total > 0) {
-            K2Chunk ca, cb;
-            ca.kk = lane_k0; ca.j = lane_j0;
-            cb.kk = lane_k0; cb.j = lane_j0; advance(cb, dk1, dj1);
-            fetch(ca);
-            for (int w0 = 0; w0 < total; w0 += 128) {
-                fetch(cb);
-                process(ca);
-                if (w0 + 64 < total) {
-                    advance(ca, dk2, dj2);
-                    fetch(ca);
-                    process(cb);
-                    advance(cb, dk2, dj2);
+            // ring of K2V3_NBUF chunk buffers: while one step is processed the next NBUF-1 are in flight
+            K2Chunk c[K2V3_NBUF];
+#pragma unroll
+            for (int b = 0; b < K2V3_NBUF; ++b) {
+                c[b].kk = lane_k0; c[b].j = lane_j0;
+#pragma unroll
+                for (int t = 0; t < b; ++t) advance(c[b], dk1, dj1);
+            }
+#pragma unroll
+            for (int b = 0; b < K2V3_NBUF - 1; ++b) fetch(c[b]);
+            for (int w0 = 0; w0 < total; w0 += 64 * K2V3_NBUF) {
+#pragma unroll
+                for (int b = 0; b < K2V3_NBUF; ++b) {
+                    if (b == 0 || w0 + 64 * b < total) {
+                        fetch(c[(b + K2V3_NBUF - 1) % K2V3_NBUF]);      // unconditional: inactive chunks load row 0
+                        process(c[b]);
+                        advance(c[b], dkn, djn);
+                    }
                 }
             }
         }
