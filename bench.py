@@ -68,10 +68,18 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    # KBBQ_BENCH_REHEARSE=gloo: every rank on the devices that exist (local % count), gloo instead of RCCL --
+    # a functional rehearsal of the N > 1 path on a one-GPU box; its numbers mean nothing
+    rehearse = os.environ.get('KBBQ_BENCH_REHEARSE', '') == 'gloo'
+    if rehearse:
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     use_dist = 'RANK' in os.environ                 # launched by torch.distributed.run (any N, also 1)
     if use_dist:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     from kbbq import _device as dev
     from kbbq import parallel, recalibrate
@@ -112,7 +120,7 @@ def main():
     k1_ms, k1_n = ctx.kernel_ms(0)
     k2_ms, k2_n = ctx.kernel_ms(1)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if rehearse else 'cuda')
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -139,7 +147,7 @@ def main():
             'metric': 'bases/sec recalibrated (2x150 bp)', 'value': total_bases / elapsed,
             'unit': 'bases/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic' + (' (gloo rehearsal, not a measurement)' if rehearse else ''),
             'config': {'workload': '%d synthetic 2x150 bp reads per GPU, %d read group(s), Q0-41, '
                                    'accumulate + solve + apply end-to-end, device-resident' % (n, R),
                        'reads_per_gpu': n, 'read_len': S, 'read_groups': R,
