@@ -185,6 +185,12 @@ int    kbbq_delta_q_dev(kbbq_ctx* ctx, const int64_t* d_prior_q, const int64_t* 
 int    kbbq_posterior_q_dev(kbbq_ctx* ctx, const double* d_prior_q, const int64_t* d_errs,
                             const int64_t* d_total, const double* d_comb, int64_t ncells,
                             const double* h_consts129, int64_t* d_post_q);
+/* host helpers of the solve (no GPU): kbbq_combiln_host fills comb[i] for cells (errs[i], total[i]) with
+ * the restated SciPy gammaln (csrc/solve_host.cpp; bit-identical to scipy.special.gammaln for positive
+ * arguments, NaN for cells outside the distribution's support, which the solve ignores), on `threads`
+ * threads; kbbq_gammaln_host exposes the gammaln itself for the tests.                              */
+int    kbbq_combiln_host(const int64_t* errs, const int64_t* total, int64_t ncells, double* comb, int threads);
+int    kbbq_gammaln_host(const double* x, int64_t n, double* out);
 size_t kbbq_solve_aux_count(int R, int S2);
 size_t kbbq_solve_dq_count(int R, int S2);
 int    kbbq_solve_dev(kbbq_ctx* ctx, const int64_t* d_tables, int R, int S2, int minscore,

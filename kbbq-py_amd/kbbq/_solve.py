@@ -36,13 +36,32 @@ def model_consts():
     return np.ascontiguousarray(np.concatenate([prior, logp, log1mp]))
 
 
-def combiln(numerrs, numtotal):
-    """The candidate-independent term of logpmf(errs + 1; total + 2, p), float64 per cell."""
+COMBILN_THREADS = 4
+
+
+def combiln_scipy(numerrs, numtotal):
+    """The candidate-independent term of logpmf(errs + 1; total + 2, p) with SciPy's own calls
+    (scipy/stats/_discrete_distns.py binom_gen._logpmf): the definition the native routine is
+    tested against, bit for bit."""
     x = np.asarray(numerrs) + 1
     n = np.asarray(numtotal) + 2
     k = np.floor(x)
     with np.errstate(all='ignore'):
         return scipy.special.gammaln(n + 1) - (scipy.special.gammaln(k + 1) + scipy.special.gammaln(n - k + 1))
+
+
+def combiln(numerrs, numtotal):
+    """The candidate-independent term of logpmf(errs + 1; total + 2, p), float64 per cell, by the
+    library's restatement of SciPy's gammaln (csrc/solve_host.cpp: one fused pass on a few parked
+    threads instead of three ufunc passes).  Cells outside the distribution's support (errs > total,
+    negative counts) come back NaN; the solve never reads them."""
+    from . import _native as N
+    e = np.ascontiguousarray(np.asarray(numerrs), dtype=np.int64)
+    t = np.ascontiguousarray(np.asarray(numtotal), dtype=np.int64)
+    assert e.shape == t.shape
+    out = np.empty(e.shape, dtype=np.float64)
+    N.check(N.load().kbbq_combiln_host(N.ptr(e), N.ptr(t), e.size, N.ptr(out), COMBILN_THREADS))
+    return out
 
 
 def _round64(t):

@@ -134,9 +134,15 @@ int main(int argc, char** argv)
         printf("%-44s %.3f ms  %.0f GB/s\n", name, ms, 3.0 * nkib * 1024 / ms / 1e6); fflush(stdout);
     };
     char nm[128];
-    for (int per_cu : {2, 4}) for (int blk : {10, 80}) {
+    for (int per_cu : {2, 4}) for (int blk : {1, 2, 4, 10, 80}) {
         snprintf(nm, sizeof nm, "blocked blk=%d KiB, %d x 512 thr per CU", blk, per_cu);
         run(nm, [&] { hipLaunchKernelGGL(blocked, dim3(cus * per_cu), dim3(512), 0, 0, a, b, c, nkib, blk); });
+    }
+    // the same kernel launched NON-persistently: one wave per block, grid covers everything
+    for (int thr : {256, 512}) for (int blk : {2, 10}) {
+        snprintf(nm, sizeof nm, "blocked blk=%d KiB, non-persistent grid, %d thr", blk, thr);
+        const long long wgs = (nkib / blk + thr / 64 - 1) / (thr / 64);
+        run(nm, [&] { hipLaunchKernelGGL(blocked, dim3((unsigned)wgs), dim3(thr), 0, 0, a, b, c, nkib, blk); });
     }
     for (int per_cu : {2, 4}) {
         snprintf(nm, sizeof nm, "flat (prefetch 1), %d x 512 thr per CU", per_cu);

@@ -25,6 +25,32 @@ def _cells(rng, n):
     return err, tot
 
 
+def test_native_gammaln_is_scipys_bit_for_bit():
+    """csrc/solve_host.cpp restates SciPy 1.15's xsf::cephes::lgam; every positive argument must give the
+    very float64 scipy.special.gammaln gives (same libm log, same operation order)."""
+    from kbbq import _native as N
+    lib = N.load()
+    rng = np.random.default_rng(5)
+    for x in (np.arange(1, 300001, dtype=np.float64), np.floor(10 ** rng.uniform(0, 10.5, 2_000_000)),
+              rng.uniform(1e-3, 2e4, 500_000), 10 ** rng.uniform(-3, 300, 200_000),
+              np.array([1, 2, 3, 12, 13, 14, 999, 1000, 1001, 1e8, 1e8 + 1, 2.0 ** 53, 1e300, 2.6e305, 1e308])):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty_like(x)
+        N.check(lib.kbbq_gammaln_host(N.ptr(x), x.size, N.ptr(out)))
+        with np.errstate(all='ignore'):
+            want = scipy.special.gammaln(x)
+        assert np.array_equal(out.view(np.int64), want.view(np.int64))
+    err, tot = _cells(rng, 200_000)
+    for threads in (1, 3, 8):
+        _solve.COMBILN_THREADS = threads
+        got = _solve.combiln(err, tot)
+        assert np.array_equal(got.view(np.int64), _solve.combiln_scipy(err, tot).view(np.int64))
+    _solve.COMBILN_THREADS = 4
+    # outside the support: NaN (never read by the solve), shapes are kept
+    bad = _solve.combiln(np.array([[5, -3]]), np.array([[2, 7]]))
+    assert bad.shape == (1, 2) and np.isnan(bad[0, 1])
+
+
 def test_logpmf_decomposition_is_bit_identical():
     rng = np.random.default_rng(1)
     err, tot = _cells(rng, 4000)
