@@ -596,9 +596,9 @@ int kbbq_solve_dev(kbbq_ctx* c, const int64_t* d_tables, int R, int S2, int mins
     p.meanq = d_meanq; p.aux = d_aux; p.post_q = d_post_q; p.lut = reinterpret_cast<int16_t*>(d_lut); p.dq = d_dq;
     int rc = load_consts(p.c, h_consts129);
     if (rc) return rc;
-    hipLaunchKernelGGL(k3_levels_ab, dim3((unsigned)R), dim3(64), 0, c->stream, p);
-    const int64_t cells = (int64_t)R * KQ * ((int64_t)S2 + KND);
-    int gx = (int)std::min<int64_t>((cells + 255) / 256, (int64_t)c->cus * 8);
+    hipLaunchKernelGGL(k3_levels_ab, dim3((unsigned)R), dim3(1024), 0, c->stream, p);
+    const int64_t cells = (int64_t)R * KQ * ((int64_t)S2 + KND);              // one wave per cell
+    int gx = (int)std::min<int64_t>((cells + 3) / 4, (int64_t)c->cus * 32);
     hipLaunchKernelGGL(k3_level_c, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     // derive the table-driven (int8) LUT and the flags the fast apply kernel relies on
     LutFillParams f;
@@ -608,9 +608,7 @@ int kbbq_solve_dev(kbbq_ctx* c, const int64_t* d_tables, int R, int S2, int mins
     f.flags = reinterpret_cast<int*>(reinterpret_cast<char*>(d_lut) + lut_flags_offset(R, KQ, S2));
     f.status = c->d_status;
     HIPCHK(hipMemsetAsync(f.flags, 0, 16, c->stream));
-    const int64_t fb = (int64_t)kbbq_full_lut_bytes(R, KQ, S2);
-    int gf = (int)std::min<int64_t>((fb + 255) / 256, (int64_t)c->cus * 8);
-    hipLaunchKernelGGL(k3_fill_full_lut, dim3((unsigned)std::max(gf, 1)), dim3(256), 0, c->stream, f);
+    hipLaunchKernelGGL(k3_fill_full_lut, dim3((unsigned)(R * (33 + KQ))), dim3(256), 0, c->stream, f);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
 }

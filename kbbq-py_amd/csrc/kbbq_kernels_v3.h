@@ -491,50 +491,64 @@ struct LutFillParams {
     int8_t* full; int8_t* compact8; int* flags; u64* status;
 };
 
+// one workgroup per row (read group, raw quality byte): the row of the full LUT, and for a model row also
+// its int8 copy of the canonical row and its range check (block-wide min / max)
 __global__ __launch_bounds__(256) void k3_fill_full_lut(LutFillParams p)
 {
+    __shared__ int red[4][4];
     const int rb = full_lut_row_bytes(p.S2);
     const int NR = 33 + p.Qt;
-    const long long total = (long long)p.R * NR * rb;
+    const int row = blockIdx.x;                       // r * NR + qb
+    const int r = row / NR, qb = row - r * NR;
+    const int W = full_lut_width(p.S2);
+    const bool model = qb >= 33 + p.minscore;
+    const int16_t* src = p.lut16 + ((size_t)r * p.Qt + (qb >= 33 ? qb - 33 : 0)) * p.rs16;
     int bad = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const long long row = i / rb;
-        const int x = (int)(i - row * rb);
-        const int r = (int)(row / NR);
-        const int qb = (int)(row - (long long)r * NR);
-        const int W = full_lut_width(p.S2);
+    int8_t* dst = p.full + (size_t)row * rb;
+    for (int x = threadIdx.x; x < rb; x += blockDim.x) {
         int v = 0;
-        if (qb < 33 + p.minscore) {
-            if (x < 2 * W) v = qb == 0 ? -33 : qb - 33;               // padding -> 0 ; uncounted -> unchanged
+        if (!model) {
+            if (x < 2 * W) v = qb == 0 ? -33 : qb - 33;                   // padding -> 0 ; uncounted -> unchanged
         } else {
-            const int16_t* src = p.lut16 + ((size_t)r * p.Qt + (qb - 33)) * p.rs16;
             if (x < p.S2) v = src[x];
             else if (x >= W && x < W + p.S2) v = src[p.S2 - 1 - (x - W)];   // mirrored copy for second-in-pair
             else if (x >= 2 * W && x < 2 * W + 25) v = src[p.S2 + (x - 2 * W)];
         }
         if (v < -128 || v > 127) bad |= 1;
-        p.full[i] = (int8_t)v;
+        dst[x] = (int8_t)v;
     }
-    // int8 copy of the canonical LUT (same row stride, one byte per entry)
-    const long long n16 = (long long)p.R * p.Qt * p.rs16;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int v = p.lut16[i];
-        if (v < -128 || v > 127) bad |= 1;
-        p.compact8[i] = (int8_t)v;
+    if (qb >= 33) {
+        // int8 copy of the canonical row (same row stride, one byte per entry)
+        int8_t* c8 = p.compact8 + ((size_t)r * p.Qt + (qb - 33)) * p.rs16;
+        for (int x = threadIdx.x; x < p.rs16; x += blockDim.x) {
+            const int v = src[x];
+            if (v < -128 || v > 127) bad |= 1;
+            c8[x] = (int8_t)v;
+        }
     }
-    // range safety per model row: min/max over cycles + min/max over contexts
-    const long long rows = (long long)p.R * p.Qt;
-    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < rows;
-         c += (long long)gridDim.x * blockDim.x) {
-        const int q = (int)(c % p.Qt);
-        if (q < p.minscore) continue;
-        const int16_t* src = p.lut16 + (size_t)c * p.rs16;
+    if (model) {
+        // range safety of the row: min/max over cycles + min/max over contexts must stay in 0..255 after +33
         int lo1 = 32767, hi1 = -32768, lo2 = 32767, hi2 = -32768;
-        for (int x = 0; x < p.S2; ++x) { const int v = src[x]; lo1 = v < lo1 ? v : lo1; hi1 = v > hi1 ? v : hi1; }
-        for (int x = 0; x < 25; ++x) { const int v = src[p.S2 + x]; lo2 = v < lo2 ? v : lo2; hi2 = v > hi2 ? v : hi2; }
-        if (lo1 + lo2 + 33 < 0 || hi1 + hi2 + 33 > 255) bad |= 2;
+        for (int x = threadIdx.x; x < p.S2; x += blockDim.x) { const int v = src[x]; lo1 = v < lo1 ? v : lo1; hi1 = v > hi1 ? v : hi1; }
+        for (int x = threadIdx.x; x < 25; x += blockDim.x) { const int v = src[p.S2 + x]; lo2 = v < lo2 ? v : lo2; hi2 = v > hi2 ? v : hi2; }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int o;
+            o = __shfl_xor(lo1, off); lo1 = o < lo1 ? o : lo1;
+            o = __shfl_xor(hi1, off); hi1 = o > hi1 ? o : hi1;
+            o = __shfl_xor(lo2, off); lo2 = o < lo2 ? o : lo2;
+            o = __shfl_xor(hi2, off); hi2 = o > hi2 ? o : hi2;
+        }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { red[w][0] = lo1; red[w][1] = hi1; red[w][2] = lo2; red[w][3] = hi2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < (int)(blockDim.x >> 6); ++k) {
+                lo1 = red[k][0] < lo1 ? red[k][0] : lo1; hi1 = red[k][1] > hi1 ? red[k][1] : hi1;
+                lo2 = red[k][2] < lo2 ? red[k][2] : lo2; hi2 = red[k][3] > hi2 ? red[k][3] : hi2;
+            }
+            if (lo1 + lo2 + 33 < 0 || hi1 + hi2 + 33 > 255) bad |= 2;
+        }
     }
     if (bad) { atomicOr(p.flags, bad); atomicMin(&p.status[ST_LUT], 0ull); }
 }

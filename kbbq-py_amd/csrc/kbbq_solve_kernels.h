@@ -53,39 +53,101 @@ __global__ __launch_bounds__(256) void k3_posterior_q(K3PostParams p)
         p.post[i] = (long long)solve_cell<double>(p.c, p.prior_q[i], p.errs[i], p.total[i], p.comb[i]);
 }
 
-__global__ __launch_bounds__(64) void k3_levels_ab(K3FusedParams p)
+// ---- wave-cooperative cell solve: lane = candidate quality -------------------------------------
+// All 64 lanes pass the SAME cell.  Lane q' < 43 forms the posterior of candidate q' exactly as
+// solve_cell does (same doubles, same order, same 80-bit add); the argmax is a butterfly over an
+// order-preserving key of the rounded 80-bit value, ties to the lower index (np.argmax: first
+// maximum), NaN neither greater nor smaller than anything (it can only arise at candidate 0, and
+// then wins every tie as the sequential scan does).  `sc` = the 129 model constants in LDS.
+__device__ __forceinline__ int k3_lane() { return (int)(threadIdx.x & 63u); }
+
+__device__ __forceinline__ int solve_cell_wave(const double* sc, int prior_q, long long errs, long long total, double comb)
+{
+    const long long kk = errs + 1, nn = total + 2;
+    if (nn < 0 || kk < 0 || kk > nn) return 0;                       // uniform: outside the support argmax is 0
+    const int lane = k3_lane();
+    const int cand = lane < KSOLVE_NQ ? lane : KSOLVE_NQ - 1;         // spare lanes repeat the last candidate
+    const double k = (double)kk;
+    const double nk = (double)nn - k;
+    int diff = cand - prior_q; if (diff < 0) diff = -diff;
+    const double pr = sc[diff < KSOLVE_NQ ? diff : KSOLVE_NQ - 1];
+    const double t1 = k * sc[KSOLVE_NQ + cand];
+    const double t2 = nk * sc[2 * KSOLVE_NQ + cand];
+    const double ll = (comb + t1) + t2;
+    const x87val v = x87_add(pr, ll);
+    // order-preserving key: (class rank, exponent, significand), mirrored for negative values
+    const int rank = v.cls == 2 ? 0 : v.cls == 3 ? 4 : v.cls == 1 ? 2 : (v.neg ? 1 : 3);
+    int hi = rank << 20;
+    unsigned long long lo = 0ull;
+    if (rank == 3) { hi += v.exp + 40000; lo = v.mant; }
+    if (rank == 1) { hi += 40000 - v.exp; lo = ~v.mant; }
+    int nan = v.cls == 4 ? 1 : 0;
+    int idx = lane < KSOLVE_NQ ? lane : 64 + lane;                    // a repeat never beats the original
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int ohi = __shfl_xor(hi, off), onan = __shfl_xor(nan, off), oidx = __shfl_xor(idx, off);
+        const unsigned long long olo = (unsigned long long)__shfl_xor((long long)lo, off);
+        const bool comparable = !(nan | onan);
+        const bool other_gt = comparable && (ohi != hi ? ohi > hi : olo > lo);
+        const bool mine_gt = comparable && (ohi != hi ? hi > ohi : lo > olo);
+        if (other_gt || (!mine_gt && oidx < idx)) { hi = ohi; lo = olo; nan = onan; idx = oidx; }
+    }
+    return idx;
+}
+
+__device__ __forceinline__ long long wave_sum_ll(long long v)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// one 1024-thread workgroup per read group: marginals of the cycle tables by row (coalesced, wave
+// sums), the read-group cell, then the 43 reported-quality cells, three per wave
+__global__ __launch_bounds__(1024) void k3_levels_ab(K3FusedParams p)
 {
     __shared__ long long qe[KSOLVE_NQ], qt[KSOLVE_NQ];
+    __shared__ double sc[3 * KSOLVE_NQ];
     __shared__ int post_rg;
-    const int r = blockIdx.x, t = threadIdx.x;
+    const int r = blockIdx.x, lane = k3_lane(), wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6);
+    for (int i = threadIdx.x; i < 3 * KSOLVE_NQ; i += blockDim.x)
+        sc[i] = i < KSOLVE_NQ ? p.c.prior[i] : i < 2 * KSOLVE_NQ ? p.c.logp[i - KSOLVE_NQ] : p.c.log1mp[i - 2 * KSOLVE_NQ];
     const size_t npos = (size_t)p.R * KSOLVE_NQ * p.S2;
-    if (t < KSOLVE_NQ) {
-        const long long* pe = p.tables + ((size_t)r * KSOLVE_NQ + t) * p.S2;
+    for (int q = wave; q < KSOLVE_NQ; q += nwaves) {
+        const long long* pe = p.tables + ((size_t)r * KSOLVE_NQ + q) * p.S2;
         const long long* pt = pe + npos;
-        long long e = 0, tt = 0;
-        for (int c = 0; c < p.S2; ++c) { e += pe[c]; tt += pt[c]; }
-        qe[t] = e; qt[t] = tt;
+        long long e = 0, t = 0;
+        for (int c = lane; c < p.S2; c += 64) { e += pe[c]; t += pt[c]; }
+        e = wave_sum_ll(e); t = wave_sum_ll(t);
+        if (lane == 0) { qe[q] = e; qt[q] = t; }
     }
     __syncthreads();
-    if (t == 0) {
-        long long e = 0, tt = 0;
-        for (int q = 0; q < KSOLVE_NQ; ++q) { e += qe[q]; tt += qt[q]; }
+    if (wave == 0) {
+        const long long e = wave_sum_ll(lane < KSOLVE_NQ ? qe[lane] : 0ll);
+        const long long t = wave_sum_ll(lane < KSOLVE_NQ ? qt[lane] : 0ll);
         const int prior = p.meanq[r];
-        const int post = solve_cell(p.c, prior, e, tt, p.aux[r]);
-        post_rg = post;
-        if (p.dq) p.dq[r] = post - prior;
+        const int post = solve_cell_wave(sc, prior, e, t, p.aux[r]);
+        if (lane == 0) { post_rg = post; if (p.dq) p.dq[r] = post - prior; }
     }
     __syncthreads();
-    if (t < KSOLVE_NQ) {
-        const int prior = post_rg;
-        const int post = solve_cell(p.c, prior, qe[t], qt[t], p.aux[p.R + (size_t)r * KSOLVE_NQ + t]);
-        p.post_q[r * KSOLVE_NQ + t] = post;
-        if (p.dq) p.dq[p.R + r * KSOLVE_NQ + t] = post - prior;
+    const int prior = post_rg;
+    for (int q = wave; q < KSOLVE_NQ; q += nwaves) {
+        const int post = solve_cell_wave(sc, prior, qe[q], qt[q], p.aux[p.R + (size_t)r * KSOLVE_NQ + q]);
+        if (lane == 0) {
+            p.post_q[r * KSOLVE_NQ + q] = post;
+            if (p.dq) p.dq[p.R + r * KSOLVE_NQ + q] = post - prior;
+        }
     }
 }
 
+// one WAVE per (read group, quality, cycle | context) cell
 __global__ __launch_bounds__(256) void k3_level_c(K3FusedParams p)
 {
+    __shared__ double sc[3 * KSOLVE_NQ];
+    for (int i = threadIdx.x; i < 3 * KSOLVE_NQ; i += blockDim.x)
+        sc[i] = i < KSOLVE_NQ ? p.c.prior[i] : i < 2 * KSOLVE_NQ ? p.c.logp[i - KSOLVE_NQ] : p.c.log1mp[i - 2 * KSOLVE_NQ];
+    __syncthreads();
+    const int lane = k3_lane(), wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6);
     const long long npos = (long long)p.R * KSOLVE_NQ * p.S2;
     const long long ndn = (long long)p.R * KSOLVE_NQ * 16;
     const long long* pos_errs = p.tables;
@@ -96,30 +158,33 @@ __global__ __launch_bounds__(256) void k3_level_c(K3FusedParams p)
     const double* comb_dn = comb_pos + npos;
     int* dq_pos = p.dq ? p.dq + p.R + p.R * KSOLVE_NQ : nullptr;
     int* dq_dn = p.dq ? dq_pos + npos : nullptr;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npos + ndn;
-         i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = (long long)blockIdx.x * nwaves + wave; i < npos + ndn; i += (long long)gridDim.x * nwaves) {
         if (i < npos) {
             const long long cell = i / p.S2;               // r * 43 + q
             const int col = (int)(i - cell * p.S2);
             const int prior = p.post_q[cell];
-            const int post = solve_cell(p.c, prior, pos_errs[i], pos_total[i], comb_pos[i]);
-            p.lut[cell * p.rs + col] = (int16_t)post;      // meanq + rgdq + qdq + posdq
-            if (dq_pos) dq_pos[i] = post - prior;
+            const int post = solve_cell_wave(sc, prior, pos_errs[i], pos_total[i], comb_pos[i]);
+            if (lane == 0) {
+                p.lut[cell * p.rs + col] = (int16_t)post;  // meanq + rgdq + qdq + posdq
+                if (dq_pos) dq_pos[i] = post - prior;
+            }
         } else {
             const long long j = i - npos;
             const long long cell = j >> 4;
             const int d = (int)(j & 15);
             const int prior = p.post_q[cell];
-            const int v = solve_cell(p.c, prior, dn_errs[j], dn_total[j], comb_dn[j]) - prior;
+            const int v = solve_cell_wave(sc, prior, dn_errs[j], dn_total[j], comb_dn[j]) - prior;
             int16_t* row = p.lut + cell * p.rs + p.S2;
-            row[5 * (d >> 2) + (d & 3)] = (int16_t)v;
-            if (dq_dn) dq_dn[cell * 17 + d] = v;
+            if (lane == 0) {
+                row[5 * (d >> 2) + (d & 3)] = (int16_t)v;
+                if (dq_dn) dq_dn[cell * 17 + d] = v;
+            }
             if (d == 0) {
                 // contexts with an N / without a previous base: the zero pad column
                 // (applybqsr.py:98-101); then the row padding
-                for (int a = 0; a < 5; ++a) { row[5 * a + 4] = 0; row[20 + a] = 0; }
-                for (int s = p.S2 + 25; s < p.rs; ++s) p.lut[cell * p.rs + s] = 0;
-                if (dq_dn) dq_dn[cell * 17 + 16] = 0;
+                if (lane < 5) { row[5 * lane + 4] = 0; row[20 + lane] = 0; }
+                for (int s2 = p.S2 + 25 + lane; s2 < p.rs; s2 += 64) p.lut[cell * p.rs + s2] = 0;
+                if (lane == 0 && dq_dn) dq_dn[cell * 17 + 16] = 0;
             }
         }
     }
