@@ -204,9 +204,9 @@ int    kbbq_solve_dev(kbbq_ctx* ctx, const int64_t* d_tables, int R, int S2, int
  * (skip mask = benchmark.get_full_skips, benchmark.py:22-39); cigar ops are
  * (length << 4 | op) with BAM op codes.  Outputs one byte per base (0 / 1) in the err and
  * skip planes; flip[r] != 0 reverses both for reverse-strand reads (benchmark.py:70-72).
- * The planes (seq, err, skip) are 16-byte aligned; reference windows are read with unaligned
- * 16-byte loads that may run up to 15 bytes past a read's window: genome and skipmask need 16
- * readable bytes after their last byte.
+ * The planes (seq, err, skip) are 16-byte aligned; genome / skipmask hold genome_len bytes each and
+ * need no alignment or padding (reference windows are read with unaligned 16-byte loads, byte by
+ * byte at the very end of the arrays).
  * Python's negative-index wraps of the reference (skips[-1], subset[-1]) are reproduced;
  * its IndexError / ValueError cases arrive through kbbq_ctx_status as KBBQ_E_INDEX /
  * KBBQ_E_RANGE.
@@ -216,8 +216,8 @@ int    kbbq_solve_dev(kbbq_ctx* ctx, const int64_t* d_tables, int R, int S2, int
 int kbbq_find_errors_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint32_t* d_len, int64_t nreads, int pitch,
                          const int64_t* d_ref_start, const int32_t* d_ref_len,
                          const uint32_t* d_cig_off, const uint32_t* d_cig_n, const uint32_t* d_cigar,
-                         const uint8_t* d_genome, const uint8_t* d_skipmask, const uint8_t* d_flip,
-                         uint8_t* d_err, uint8_t* d_skip);
+                         const uint8_t* d_genome, const uint8_t* d_skipmask, int64_t genome_len,
+                         const uint8_t* d_flip, uint8_t* d_err, uint8_t* d_skip);
 /* kbbq_canonical_reads_dev: first half of gatk.bqsr.bam_to_bqsr_covariates (gatk/bqsr.py:52-123;
  * strand-aware covariates :23-50, skips :86-88).  Rewrites aligned reads into sequencing
  * orientation so that kbbq_accumulate_dev tallies them: per read the aligned part
@@ -229,8 +229,7 @@ int kbbq_find_errors_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint32_t* d_
  * S | read group (flags >> 16) << 16 | read 2 (flags bit 1) << 31.  The reference's TypeError
  * (a looked-up dinucleotide with a letter outside ACGT on a forward read, decided on the
  * ORIGINAL qualities with dinuc_minscore) arrives as KBBQ_E_TYPE.  All planes 16-byte
- * aligned; the four input planes need 16 readable bytes after their last row (windows of
- * the last chunk of a read are fetched whole).                                          */
+ * aligned, nreads * pitch bytes each, no padding rows needed.                           */
 int kbbq_canonical_reads_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_oq, const uint8_t* d_err,
                              const uint8_t* d_skip, const uint32_t* d_len, const uint32_t* d_clip,
                              const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads, int pitch, int S,

@@ -617,21 +617,21 @@ int kbbq_solve_dev(kbbq_ctx* c, const int64_t* d_tables, int R, int S2, int mins
 int kbbq_find_errors_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint32_t* d_len, int64_t nreads, int pitch,
                          const int64_t* d_ref_start, const int32_t* d_ref_len,
                          const uint32_t* d_cig_off, const uint32_t* d_cig_n, const uint32_t* d_cigar,
-                         const uint8_t* d_genome, const uint8_t* d_skipmask, const uint8_t* d_flip,
-                         uint8_t* d_err, uint8_t* d_skip)
+                         const uint8_t* d_genome, const uint8_t* d_skipmask, int64_t genome_len,
+                         const uint8_t* d_flip, uint8_t* d_err, uint8_t* d_skip)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
-    if (nreads < 0 || pitch <= 0 || (pitch & 15)) return fail(KBBQ_E_ARG, "kbbq_find_errors_dev: bad nreads/pitch");
+    if (nreads < 0 || pitch <= 0 || (pitch & 15) || genome_len < 0) return fail(KBBQ_E_ARG, "kbbq_find_errors_dev: bad nreads/pitch/genome_len");
     if (nreads == 0) return KBBQ_OK;
     HIPCHK(hipSetDevice(c->device));
     K4Params p;
     p.seq = d_seq; p.len = d_len; p.nreads = nreads; p.pitch = pitch;
     p.ref_start = (const long long*)d_ref_start; p.ref_len = d_ref_len;
     p.cig_off = d_cig_off; p.cig_n = d_cig_n; p.cigar = d_cigar;
-    p.genome = d_genome; p.skipmask = d_skipmask; p.flip = d_flip; p.err = d_err; p.skip = d_skip;
+    p.genome = d_genome; p.skipmask = d_skipmask; p.genome_len = genome_len; p.flip = d_flip; p.err = d_err; p.skip = d_skip;
     p.status = c->d_status;
-    if (((uintptr_t)d_seq | (uintptr_t)d_genome | (uintptr_t)d_skipmask | (uintptr_t)d_err | (uintptr_t)d_skip) & 15)
-        return fail(KBBQ_E_ARG, "kbbq_find_errors_dev: buffers must be 16-byte aligned");
+    if (((uintptr_t)d_seq | (uintptr_t)d_err | (uintptr_t)d_skip) & 15)
+        return fail(KBBQ_E_ARG, "kbbq_find_errors_dev: planes must be 16-byte aligned");
     const int rpb4 = (pitch / 16) <= 256 ? 256 / (pitch / 16) : 1;              // reads per workgroup iteration
     int gx = (int)std::min<int64_t>((nreads + rpb4 - 1) / rpb4, (int64_t)c->cus * 16);
     hipLaunchKernelGGL(k4_find_errors, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);

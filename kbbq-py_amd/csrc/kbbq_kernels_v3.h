@@ -563,6 +563,7 @@ struct K4Params {
     const int* ref_len;              // reference_end - reference_start (the read's reference window)
     const u32* cig_off; const u32* cig_n; const u32* cigar;   // per read: first op, op count; ops = len << 4 | op
     const uint8_t* genome; const uint8_t* skipmask; const uint8_t* flip;
+    long long genome_len;            // bytes in genome / skipmask
     uint8_t* err; uint8_t* skip; u64* status;
 };
 
@@ -574,6 +575,15 @@ __device__ __forceinline__ void load16_any(const uint8_t* base, long long off, u
     uint4 v;
     __builtin_memcpy(&v, base + off, 16);
     out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+
+// the same, for windows that may run past the end of the array (`limit` = its size in bytes): bytes past
+// the end read as zero.  Only the last chunk of the last rows / of the genome ever takes the byte path.
+__device__ __forceinline__ void load16_upto(const uint8_t* base, long long off, long long limit, u32 out[4])
+{
+    if (off + 16 <= limit) { load16_any(base, off, out); return; }
+    out[0] = out[1] = out[2] = out[3] = 0u;
+    for (int b = 0; b < 16 && off + b < limit; ++b) out[b >> 2] |= (u32)base[off + b] << (8 * (b & 3));
 }
 
 // 0x01 in every byte of x that is non-zero
@@ -666,8 +676,8 @@ __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
                         const long long goff = g0 + refidx + (a - readidx) - d;
                         if (goff >= 0) {
                             u32 gw[4], mw[4];
-                            load16_any(p.genome, goff, gw);
-                            load16_any(p.skipmask, goff, mw);
+                            load16_upto(p.genome, goff, p.genome_len, gw);
+                            load16_upto(p.skipmask, goff, p.genome_len, mw);
 #pragma unroll
                             for (int w = 0; w < 4; ++w) {
                                 const u32 rm = range_mask(d, b - in_lo, w);
@@ -788,10 +798,11 @@ __global__ __launch_bounds__(256) void k6_canonical_reads(K6Params p)
             const int cnt = L - c0 < 16 ? L - c0 : 16;
             const int i0 = rev ? (cnt == 16 ? qe - c0 - 16 : qs) : qs + c0;
             u32 s[4], q[4], e[4], k[4];
-            load16_any(p.seq, (long long)row + i0, s);
-            load16_any(p.oq, (long long)row + i0, q);
-            load16_any(p.err, (long long)row + i0, e);
-            load16_any(p.skip, (long long)row + i0, k);
+            const long long plane = p.nreads * (long long)p.pitch;
+            load16_upto(p.seq, (long long)row + i0, plane, s);
+            load16_upto(p.oq, (long long)row + i0, plane, q);
+            load16_upto(p.err, (long long)row + i0, plane, e);
+            load16_upto(p.skip, (long long)row + i0, plane, k);
             bool odd = false;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {

@@ -64,7 +64,7 @@ PROTOTYPES = {
     'kbbq_solve_aux_count': (_sz, [_i, _i]),
     'kbbq_solve_dq_count': (_sz, [_i, _i]),
     'kbbq_solve_dev': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'kbbq_find_errors_dev': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'kbbq_find_errors_dev': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     'kbbq_count_q_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     'kbbq_canonical_reads_dev': (_i, [_vp] * 9 + [_i64, _i, _i, _i, _i] + [_vp] * 4),
     'kbbq_fastq_open': (_i, [_c.c_char_p, _c.POINTER(_vp)]),

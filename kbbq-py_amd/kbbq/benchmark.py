@@ -68,15 +68,14 @@ class _Genome:
             parts.append(aln.codes(arr)); masks.append(np.asarray(fullskips[chrom], dtype=np.uint8))
             pos += len(arr)
         self.length = pos
-        slack = np.zeros(32, dtype=np.uint8)            # K4 fetches unaligned 16-byte windows as two aligned loads
-        cat = lambda xs: np.concatenate(list(xs) + [slack])
+        cat = lambda xs: np.concatenate(list(xs)) if xs else np.zeros(0, dtype=np.uint8)
         self.genome = torch.from_numpy(np.ascontiguousarray(cat(parts))).cuda()
         self.mask = torch.from_numpy(np.ascontiguousarray(cat(masks))).cuda()
         self.sizes = {c: len(a) for c, a in refdict.items()}
 
 
 def _flag_batch(reads, genome, flip_reverse, keep=None):
-    """K4 over a list of aligned reads -> (err, skip) device planes [n (+1 slack row), pitch], lens
+    """K4 over a list of aligned reads -> (err, skip) device planes [n, pitch], lens
     (host).  `keep`, a dict, receives the device seq plane for callers that go on to K6."""
     from . import _device as dev
     from . import _native as N
@@ -84,7 +83,7 @@ def _flag_batch(reads, genome, flip_reverse, keep=None):
     n = len(reads)
     lens = np.array([len(r.query_sequence) for r in reads], dtype=np.uint32)
     pitch = fastx.pitch_for(int(lens.max()) if n else 1)
-    seq = np.zeros((max(n, 1) + 1, pitch), dtype=np.uint8)         # one spare row: slack for K4's window loads
+    seq = np.zeros((max(n, 1), pitch), dtype=np.uint8)
     ref_start = np.zeros(max(n, 1), dtype=np.int64); ref_len = np.zeros(max(n, 1), dtype=np.int32)
     cig_off = np.zeros(max(n, 1), dtype=np.uint32); cig_n = np.zeros(max(n, 1), dtype=np.uint32)
     flip = np.zeros(max(n, 1), dtype=np.uint8)
@@ -104,8 +103,8 @@ def _flag_batch(reads, genome, flip_reverse, keep=None):
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     d_seq, d_len = up(seq), up(lens.view(np.int32) if n else np.zeros(1, np.int32))
     d_cigar = up(np.array(cigar if cigar else [0], dtype=np.uint32).view(np.int32))
-    err = torch.zeros((max(n, 1) + 1, pitch), dtype=torch.uint8, device='cuda')
-    skip = torch.zeros((max(n, 1) + 1, pitch), dtype=torch.uint8, device='cuda')
+    err = torch.zeros((max(n, 1), pitch), dtype=torch.uint8, device='cuda')
+    skip = torch.zeros((max(n, 1), pitch), dtype=torch.uint8, device='cuda')
     if keep is not None:
         keep['seq'] = d_seq
     ctx = dev.context()
@@ -114,7 +113,7 @@ def _flag_batch(reads, genome, flip_reverse, keep=None):
     d_co, d_cn = up(cig_off.view(np.int32)), up(cig_n.view(np.int32))
     N.check(N.load().kbbq_find_errors_dev(ctx.handle, N.ptr(d_seq), N.ptr(d_len), n, pitch,
                                           N.ptr(d_rs), N.ptr(d_rl), N.ptr(d_co), N.ptr(d_cn),
-                                          N.ptr(d_cigar), N.ptr(genome.genome), N.ptr(genome.mask),
+                                          N.ptr(d_cigar), N.ptr(genome.genome), N.ptr(genome.mask), genome.length,
                                           N.ptr(d_flip), N.ptr(err), N.ptr(skip)))
     ctx.status()
     return err, skip, lens, pitch

@@ -152,7 +152,7 @@ def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxsc
     genome = benchmark._Genome(ref, fullskips)
     kept = {}
     err, skip, lens, pitch = benchmark._flag_batch(reads, genome, flip_reverse=False, keep=kept)
-    oq = np.zeros((n + 1, pitch), dtype=np.uint8)
+    oq = np.zeros((n, pitch), dtype=np.uint8)
     clip = np.zeros(n, dtype=np.uint32); trim = np.zeros(n, dtype=np.uint32); flags = np.zeros(n, dtype=np.uint32)
     bad_length = None
     for i, r in enumerate(reads):

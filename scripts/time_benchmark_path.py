@@ -16,14 +16,14 @@ pitch = (L + 15) // 16 * 16
 g = torch.randint(0, 4, (G,), dtype=torch.uint8, device='cuda')
 genome = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device='cuda')[g.long()]
 mask = (torch.rand(G, device='cuda') < 0.01).to(torch.uint8)
-start = torch.randint(0, G - 2 * L - 64, (n,), dtype=torch.int64, device='cuda')
+start = torch.randint(0, G - L, (n,), dtype=torch.int64, device='cuda')
+start[:64] = G - L                                   # some windows end exactly at the genome's last byte
 if a.sorted:
     start = torch.sort(start).values
-idx = start[:, None] + torch.arange(pitch, device='cuda')[None, :]
+idx = (start[:, None] + torch.arange(pitch, device="cuda")[None, :]).clamp_(max=G - 1)
 seq = genome[idx]                                    # reads = reference windows ...
 err_at = torch.rand((n, pitch), device='cuda') < 0.01
 seq = torch.where(err_at, torch.tensor(65, dtype=torch.uint8, device='cuda'), seq)   # ... with 1 % substitutions
-seq = torch.cat([seq, torch.zeros((1, pitch), dtype=torch.uint8, device='cuda')])     # slack row
 lens = torch.full((n,), L, dtype=torch.int32, device='cuda')
 # CIGAR: 80 % "LM", 20 % "50M2I(L-52)M" (ref window L-2)
 ins = torch.rand(n, device='cuda') < 0.2
@@ -36,13 +36,13 @@ o = cig_off.long()
 cigar[o[~ins]] = (L << 4) | 0
 cigar[o[ins]] = (50 << 4) | 0; cigar[o[ins] + 1] = (2 << 4) | 1; cigar[o[ins] + 2] = ((L - 52) << 4) | 0
 flip = (torch.rand(n, device='cuda') < 0.5).to(torch.uint8)
-err = torch.zeros((n + 1, pitch), dtype=torch.uint8, device='cuda'); skip = torch.zeros_like(err)
-qual = torch.randint(2, 42, (n + 1, pitch), dtype=torch.uint8, device='cuda')
+err = torch.zeros((n, pitch), dtype=torch.uint8, device='cuda'); skip = torch.zeros_like(err)
+qual = torch.randint(2, 42, (n, pitch), dtype=torch.uint8, device='cuda')
 counts = torch.zeros(512, dtype=torch.int64, device='cuda')
 ctx = dev.context(); lib = N.load()
 def k4():
     N.check(lib.kbbq_find_errors_dev(ctx.handle, N.ptr(seq), N.ptr(lens), n, pitch, N.ptr(start), N.ptr(ref_len),
-                                     N.ptr(cig_off), N.ptr(cig_n), N.ptr(cigar), N.ptr(genome), N.ptr(mask), N.ptr(flip),
+                                     N.ptr(cig_off), N.ptr(cig_n), N.ptr(cigar), N.ptr(genome), N.ptr(mask), G, N.ptr(flip),
                                      N.ptr(err), N.ptr(skip)))
 def k5():
     N.check(lib.kbbq_count_q_dev(ctx.handle, N.ptr(qual), N.ptr(err), N.ptr(skip), N.ptr(lens), n, pitch, 0, N.ptr(counts)))
@@ -60,7 +60,7 @@ batch = dev.ReadBatch(n, pitch, with_corrected=True)
 tables = dev.Tables(1, 2 * L)
 def k4n():
     N.check(lib.kbbq_find_errors_dev(ctx.handle, N.ptr(seq), N.ptr(lens), n, pitch, N.ptr(start), N.ptr(ref_len),
-                                     N.ptr(cig_off), N.ptr(cig_n), N.ptr(cigar), N.ptr(genome), N.ptr(mask), N.ptr(noflip),
+                                     N.ptr(cig_off), N.ptr(cig_n), N.ptr(cigar), N.ptr(genome), N.ptr(mask), G, N.ptr(noflip),
                                      N.ptr(err), N.ptr(skip)))
 def k6():
     N.check(lib.kbbq_canonical_reads_dev(ctx.handle, N.ptr(seq), N.ptr(oq), N.ptr(err), N.ptr(skip), N.ptr(lens),
