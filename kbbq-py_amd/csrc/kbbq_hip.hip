@@ -315,6 +315,7 @@ int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_c
         q.nrows = KQ + 1 - minscore;
         q.row_bytes = (u32)((3 * S) | 1) * 4u;
         q.slack_bytes = (u32)(S + 32) * 4u;              // x <= 4S + 12 for the padding of the shortest read
+        q.maxlen = S; q.gap = 0;
         q.tables = reinterpret_cast<u64*>(d_tables); q.status = c->d_status;
         q.dn_flush_iters = std::max(1, 65535 / ((K1V3_THREADS / K1V3_DNREP) * 16 * q.cpr));
         const size_t lds3 = (size_t)q.nrows * 128 * K1V3_DNREP + (size_t)q.nrows * q.row_bytes + q.slack_bytes;
@@ -459,6 +460,8 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
         q.lut16 = reinterpret_cast<const int16_t*>(d_lut); q.rs16 = lut_row_stride(S2);
         q.full = reinterpret_cast<const int8_t*>(d_lut) + lut_full_offset(R, Qt, S2);
         q.full_bytes = (int)full_bytes;
+        q.rb = (u32)full_lut_row_bytes(S2); q.W = (u32)full_lut_width(S2); q.ctx_off = 2u * q.W;
+        q.maxlen = S2; q.pairs = 0;
         q.out = d_out; q.status = c->d_status;
 #ifdef K2V3_PER_CU
         int per_cu = K2V3_PER_CU;
@@ -609,6 +612,159 @@ int kbbq_solve_dev(kbbq_ctx* c, const int64_t* d_tables, int R, int S2, int mins
     f.status = c->d_status;
     HIPCHK(hipMemsetAsync(f.flags, 0, 16, c->stream));
     hipLaunchKernelGGL(k3_fill_full_lut, dim3((unsigned)(R * (33 + KQ))), dim3(256), 0, c->stream, f);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+// ---- mate-pair rows ---------------------------------------------------------
+int kbbq_pair_pitch(int S2) { return pair_pitch(S2); }
+size_t kbbq_pair_lut_bytes(int R, int Qt, int S2) { return (size_t)R * (33 + Qt) * pair_lut_row_bytes(S2); }
+
+static int check_pairs(const char* who, int64_t npairs, int S2)
+{
+    if (npairs < 0) return fail(KBBQ_E_ARG, "%s: npairs < 0", who);
+    if (S2 <= 0 || (S2 & 1) || S2 > 65534) return fail(KBBQ_E_ARG, "%s: S2 must be positive and even (%d)", who, S2);
+    return KBBQ_OK;
+}
+
+int kbbq_pack_pairs_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
+                        const uint32_t* d_meta, int64_t npairs, int pitch, int S2,
+                        uint8_t* d_pseq, uint8_t* d_pcseq, uint8_t* d_pqual, uint32_t* d_pmeta)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    int rc = check_pairs("kbbq_pack_pairs_dev", npairs, S2);
+    if (rc) return rc;
+    if (pitch <= 0 || (pitch & 15) || pitch < S2 / 2) return fail(KBBQ_E_ARG, "kbbq_pack_pairs_dev: bad pitch %d", pitch);
+    if (!d_seq || !d_qual || !d_meta || !d_pseq || !d_pqual || !d_pmeta || (d_cseq && !d_pcseq))
+        return fail(KBBQ_E_ARG, "kbbq_pack_pairs_dev: NULL pointer");
+    if (((uintptr_t)d_pseq | (uintptr_t)d_pcseq | (uintptr_t)d_pqual) & 15) return fail(KBBQ_E_ARG, "kbbq_pack_pairs_dev: planes must be 16-byte aligned");
+    if (npairs == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    PairPackParams p;
+    p.src[0] = d_seq; p.src[1] = d_cseq; p.src[2] = d_qual;
+    p.dst[0] = d_pseq; p.dst[1] = d_pcseq; p.dst[2] = d_pqual;
+    p.fill[0] = 'N'; p.fill[1] = 'N'; p.fill[2] = 0;
+    p.meta = d_meta; p.pmeta = d_pmeta; p.npairs = npairs; p.pitch = pitch; p.ppitch = pair_pitch(S2); p.S = S2 / 2; p.unpack = 0;
+    const int64_t nchunks = npairs * (p.ppitch / 16);
+    int gx = (int)std::min<int64_t>((nchunks + 255) / 256, (int64_t)c->cus * 16);
+    hipLaunchKernelGGL(k7_pack_pairs, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+int kbbq_unpack_pairs_dev(kbbq_ctx* c, const uint8_t* d_pplane, int64_t npairs, int S2, int pitch, uint8_t* d_plane)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    int rc = check_pairs("kbbq_unpack_pairs_dev", npairs, S2);
+    if (rc) return rc;
+    if (pitch <= 0 || (pitch & 15) || pitch < S2 / 2) return fail(KBBQ_E_ARG, "kbbq_unpack_pairs_dev: bad pitch %d", pitch);
+    if (!d_pplane || !d_plane || ((uintptr_t)d_plane & 15)) return fail(KBBQ_E_ARG, "kbbq_unpack_pairs_dev: bad pointer");
+    if (npairs == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    PairPackParams p;
+    p.src[0] = d_pplane; p.src[1] = nullptr; p.src[2] = nullptr; p.dst[0] = d_plane; p.dst[1] = nullptr; p.dst[2] = nullptr;
+    p.fill[0] = p.fill[1] = p.fill[2] = 0;
+    p.meta = nullptr; p.pmeta = nullptr; p.npairs = npairs; p.pitch = pitch; p.ppitch = pair_pitch(S2); p.S = S2 / 2; p.unpack = 1;
+    const int64_t nchunks = 2 * npairs * (pitch / 16);
+    int gx = (int)std::min<int64_t>((nchunks + 255) / 256, (int64_t)c->cus * 16);
+    hipLaunchKernelGGL(k7_pack_pairs, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+int kbbq_accumulate_pairs_dev(kbbq_ctx* c, const uint8_t* d_pseq, const uint8_t* d_pcseq, const uint8_t* d_pqual,
+                              const uint32_t* d_pmeta, int64_t npairs, int R, int S2, int minscore,
+                              int dinuc_minscore, int64_t* d_tables)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    int rc = check_pairs("kbbq_accumulate_pairs_dev", npairs, S2);
+    if (rc) return rc;
+    const int pitch = pair_pitch(S2);
+    rc = check_planes("kbbq_accumulate_pairs_dev", npairs, pitch, d_pseq, d_pcseq, d_pqual);
+    if (rc) return rc;
+    if (R <= 0 || R > 32767) return fail(KBBQ_E_ARG, "kbbq_accumulate_pairs_dev: R out of range (%d)", R);
+    if (minscore < 0 || minscore > KQ - 1) return fail(KBBQ_E_ARG, "kbbq_accumulate_pairs_dev: minscore out of range (%d)", minscore);
+    if (dinuc_minscore < 0 || dinuc_minscore > 222) return fail(KBBQ_E_ARG, "kbbq_accumulate_pairs_dev: dinuc_minscore out of range (%d)", dinuc_minscore);
+    if (npairs == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const int S = S2 / 2;
+    K1v3Params q;
+    q.seq = d_pseq; q.cseq = d_pcseq; q.qual = d_pqual; q.meta = d_pmeta;
+    q.nreads = npairs; q.pitch = pitch; q.cpr = pitch / 16; q.cpr_magic = magic_for(q.cpr);
+    q.R = R; q.S = S; q.minscore = minscore; q.type_minscore = dinuc_minscore;
+    q.qlo_m1 = 32u + (u32)minscore; q.dlo = 33u + (u32)dinuc_minscore;
+    q.nrows = KQ + 1 - minscore;
+    q.row_bytes = (u32)((3 * S) | 1) * 4u;
+    q.slack_bytes = (u32)(S + 32) * 4u;
+    q.maxlen = S2 + 1; q.gap = 1;
+    q.tables = reinterpret_cast<u64*>(d_tables); q.status = c->d_status;
+    q.dn_flush_iters = std::max(1, 65535 / ((K1V3_THREADS / K1V3_DNREP) * 16 * q.cpr));
+    const size_t lds3 = (size_t)q.nrows * 128 * K1V3_DNREP + (size_t)q.nrows * q.row_bytes + q.slack_bytes;
+    if (lds3 > (size_t)c->lds_bytes)
+        return fail(KBBQ_E_LUT, "kbbq_accumulate_pairs_dev: %d-base reads with minscore %d do not fit the LDS tables; use one read per row", S, minscore);
+    const bool split = dinuc_minscore > minscore;
+    const int64_t nblocks = (npairs + 63) / 64;
+    const int64_t iters = (nblocks + (K1V3_THREADS / 64) - 1) / (K1V3_THREADS / 64);
+    int gx = (int)std::min<int64_t>(iters, std::max(1, c->cus / R));
+    dim3 grid((unsigned)gx, (unsigned)R, 1), block(K1V3_THREADS, 1, 1);
+    {
+        Timed t(c, 0);
+        if (split) hipLaunchKernelGGL(k1v3_accumulate<true>, grid, block, lds3, c->stream, q);
+        else hipLaunchKernelGGL(k1v3_accumulate<false>, grid, block, lds3, c->stream, q);
+    }
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+int kbbq_pair_lut_dev(kbbq_ctx* c, const void* d_lut_blob, int R, int S2, int minscore, void* d_pair_lut)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    int rc = check_pairs("kbbq_pair_lut_dev", 0, S2);
+    if (rc) return rc;
+    if (R <= 0 || R > 32767 || !d_lut_blob || !d_pair_lut) return fail(KBBQ_E_ARG, "kbbq_pair_lut_dev: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    PairLutParams f;
+    f.lut16 = reinterpret_cast<const int16_t*>(d_lut_blob); f.rs16 = lut_row_stride(S2); f.R = R; f.Qt = KQ; f.S2 = S2;
+    f.minscore = std::min(std::max(minscore, 0), KQ);
+    f.out = reinterpret_cast<int8_t*>(d_pair_lut);
+    hipLaunchKernelGGL(k3_fill_pair_lut, dim3((unsigned)(R * (33 + KQ))), dim3(256), 0, c->stream, f);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+int kbbq_apply_pairs_dev(kbbq_ctx* c, const uint8_t* d_pseq, const uint8_t* d_pqual, const uint32_t* d_pmeta,
+                         int64_t npairs, int R, int S2, int minscore, const void* d_lut_blob, const void* d_pair_lut,
+                         uint8_t* d_pout)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    int rc = check_pairs("kbbq_apply_pairs_dev", npairs, S2);
+    if (rc) return rc;
+    const int pitch = pair_pitch(S2);
+    rc = check_planes("kbbq_apply_pairs_dev", npairs, pitch, d_pseq, d_pqual, d_pout);
+    if (rc) return rc;
+    if (R <= 0 || R > 32767 || !d_lut_blob || !d_pair_lut || ((uintptr_t)d_pair_lut & 15)) return fail(KBBQ_E_ARG, "kbbq_apply_pairs_dev: bad argument");
+    if (minscore < 0 || minscore > 222) return fail(KBBQ_E_ARG, "kbbq_apply_pairs_dev: minscore out of range");
+    const size_t bytes = kbbq_pair_lut_bytes(R, KQ, S2);
+    if (bytes > (size_t)c->lds_bytes) return fail(KBBQ_E_LUT, "kbbq_apply_pairs_dev: the pair LUT (%zu B) does not fit the LDS; use one read per row", bytes);
+    if (npairs == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    K2v3Params q;
+    q.seq = d_pseq; q.qual = d_pqual; q.meta = d_pmeta; q.nreads = npairs; q.pitch = pitch;
+    q.cpr = pitch / 16; q.cpr_magic = magic_for(q.cpr);
+    q.R = R; q.Qt = KQ; q.S2 = S2; q.minscore = minscore; q.qlo = 33u + (u32)minscore;
+    q.lut16 = reinterpret_cast<const int16_t*>(d_lut_blob); q.rs16 = lut_row_stride(S2);
+    q.full = reinterpret_cast<const int8_t*>(d_pair_lut); q.full_bytes = (int)bytes;
+    q.rb = (u32)pair_lut_row_bytes(S2); q.W = 0u; q.ctx_off = (u32)pair_pitch(S2);
+    q.maxlen = S2 + 1; q.pairs = 1;
+    q.out = d_pout; q.status = c->d_status;
+    int per_cu = std::max(1, std::min<int>((int)(c->lds_bytes / bytes), (K2V3_WAVES * 4 * 64) / K2V3_THREADS));
+    const int64_t nblocks = (npairs + 63) / 64;
+    const int64_t want = (nblocks + (K2V3_THREADS / 64) - 1) / (K2V3_THREADS / 64);
+    int gx = (int)std::min<int64_t>(want, (int64_t)c->cus * per_cu);
+    {
+        Timed t(c, 1);
+        hipLaunchKernelGGL(k2v3_apply, dim3((unsigned)std::max(gx, 1)), dim3(K2V3_THREADS), bytes, c->stream, q);
+    }
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
 }

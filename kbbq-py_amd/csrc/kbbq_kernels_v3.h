@@ -45,6 +45,8 @@ struct K1v3Params {
     u32 row_bytes;              // pos row stride in bytes ((3S | 1) words)
     u32 slack_bytes;            // after the last (trash) row: padding bytes of short reads index past its end
     int dn_flush_iters;         // workgroup iterations between flushes of the (16-bit packed) context table
+    int maxlen;                 // longest row the tables take: S, or 2S + 1 for mate-pair rows
+    int gap;                    // mate-pair rows: 1 (the separator byte between the mates), else 0
     u64* tables; u64* status;
 };
 
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                 const u32 v = prow[x];
                 if (v) {
                     prow[x] = 0u;
-                    const int col = x < S ? x : (S2 - 1 - (x - S));
+                    if (p.gap && x == S) continue;                            // the separator byte of a mate-pair row is never counted
+                    const int col = x < S ? x : (S2 - 1 - (x - S - p.gap));
                     atomicAdd(&pos_total[grow + col], (u64)(v & 0xFFFFu));
                     if (v >> 16) atomicAdd(&pos_errs[grow + col], (u64)(v >> 16));
                 }
@@ -221,11 +224,11 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                 if (j == 0) { prev_code5 = 20u; prev_char = 0u; }                    // dinuc[0] = -1
                 if (act) {
                     const long long read = read0 + ch.off;
-                    if (hiq || len > S) flag(p.status, ST_INDEX, read);              // recalibrate.py:114-115; read longer than the tables
+                    if (hiq || len > p.maxlen) flag(p.status, ST_INDEX, read);       // recalibrate.py:114-115; read longer than the tables
                     if (badbits && chunk_type_error(ch.s[0], ch.s[1], ch.s[2], ch.s[3], ch.q[0], ch.q[1], ch.q[2], ch.q[3],
                                                     prev_char, nb, pos0, p.type_minscore))
                         flag(p.status, ST_TYPE, read);                               // compare_reads.py:224,292
-                    if (!hiq && len <= S) {
+                    if (!hiq && len <= p.maxlen) {
                         // A: pos address less the row term; both mates ascend with the base index
                         const u32 half = second ? (u32)(S + 2 * (S - len)) : 0u;     // column 2*len-1-pos
                         const u32 A = pos_base + (half + (u32)pos0) * 4u;
@@ -320,6 +323,11 @@ struct K2v3Params {
     const int16_t* lut16;      // canonical LUT (exact path)
     const int8_t* full;        // full LUT (global copy, staged into LDS)
     int full_bytes; int rs16;
+    u32 rb;                    // bytes per row of the staged LUT
+    u32 W;                     // offset of the second-in-pair (mirrored) cycle entries within a row
+    u32 ctx_off;               // offset of the context entries within a row
+    int maxlen;                // longest row the LUT serves: S2 (H1: any single read), or S2 + 1 for mate-pair rows
+    int pairs;                 // mate-pair rows: rows the fast path cannot serve are reported (KBBQ_E_LUT), not emulated
     uint8_t* out; u64* status;
 };
 
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = blockDim.x >> 6;
     const long long nblocks = (p.nreads + 63) >> 6;
-    const u32 rb = (u32)full_lut_row_bytes(p.S2);
+    const u32 rb = p.rb;
     const u32 rg_bytes = (u32)(33 + p.Qt) * rb;
     const u32 hi_add = (u32)(0x80 - (p.Qt + 33)) * 0x01010101u;   // byte >= Qt+33 <=> bit 7 after the add
     const int lane_k0 = p.cpr == 1 ? lane : (int)__umulhi((u32)lane, p.cpr_magic);
@@ -421,17 +429,18 @@ __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2
                         d5[wd] = __builtin_amdgcn_alignbyte(code5[wd], pc5, 3) + code[wd];   // 5*prev + cur per byte
                         pc5 = code5[wd];
                     }
-                    const bool trouble = hiq != 0u || rg >= p.R || len > p.S2;
-                    if (trouble) {
+                    const bool trouble = hiq != 0u || rg >= p.R || len > p.maxlen;
+                    if (trouble && p.pairs) {
+                        flag(p.status, ST_LUT, 0);                       // the caller re-runs on one-read-per-row planes
+                    } else if (trouble) {
                         const uint4 e = chunk_apply_exact(p.lut16, p.rs16, p.R, p.Qt, p.S2, p.qlo, rg, second, pos0, nb,
                                                           ch.q[0], ch.q[1], ch.q[2], ch.q[3], d5[0], d5[1], d5[2], d5[3],
                                                           p.status, read);
                         o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = e.w;
                     } else {
                         const u32 rgb = (u32)rg * rg_bytes;
-                        const u32 W = (u32)full_lut_width(p.S2);
-                        const u32 A = rgb + (second ? W : 0u) + (u32)pos0;
-                        const u32 C = rgb + 2u * W;
+                        const u32 A = rgb + (second ? p.W : 0u) + (u32)pos0;
+                        const u32 C = rgb + p.ctx_off;
 #pragma unroll
                         for (int wd = 0; wd < 4; ++wd) {
                             // issue the word's eight LDS reads before combining any of them
@@ -846,6 +855,114 @@ __global__ __launch_bounds__(256) void k6_canonical_reads(K6Params p)
         *reinterpret_cast<uint4*>(p.out_seq + off) = make_uint4(os[0], os[1], os[2], os[3]);
         *reinterpret_cast<uint4*>(p.out_cseq + off) = make_uint4(oc[0], oc[1], oc[2], oc[3]);
         *reinterpret_cast<uint4*>(p.out_qual + off) = make_uint4(oqv[0], oqv[1], oqv[2], oqv[3]);
+    }
+}
+
+// ---------------------------------------------------------------- mate-pair rows
+// Optional device layout for paired reads of one length S (2 x 150 bp): ONE row per pair,
+//     [mate 1: S bytes][separator][mate 2: S bytes][padding to a multiple of 16]
+// separator and padding are 'N' (seq, cseq) / 0 (qual), i.e. uncounted bases.  2S + 1 = 301 -> pitch 304
+// instead of 2 x 160: 5 % fewer bytes through HBM for the same bases, and K1 / K2 run unchanged on the
+// rows as if they were single reads: byte offset b IS the stored cycle index (K1's table keeps
+// second-in-pair cycles mirrored from S upwards, here from S + 1; K2's pair LUT likewise), and the 'N'
+// separator gives mate 2's first base "no previous base" exactly like position 0 of a read.
+__host__ __device__ __forceinline__ int pair_pitch(int S2) { return (S2 + 1 + 15) & ~15; }
+__host__ __device__ __forceinline__ int pair_lut_row_bytes(int S2)
+{
+    int rb = pair_pitch(S2) + 32;
+    if (((rb >> 2) & 1) == 0) rb += 4;        // odd number of dwords per row
+    return rb;
+}
+
+struct PairLutParams {
+    const int16_t* lut16; int rs16; int R; int Qt; int S2; int minscore;
+    int8_t* out;
+};
+
+// one workgroup per row (read group, raw quality byte) of the pair LUT
+__global__ __launch_bounds__(256) void k3_fill_pair_lut(PairLutParams p)
+{
+    const int rb = pair_lut_row_bytes(p.S2), cyc = pair_pitch(p.S2), S = p.S2 >> 1;
+    const int NR = 33 + p.Qt;
+    const int row = blockIdx.x;
+    const int r = row / NR, qb = row - r * NR;
+    const bool model = qb >= 33 + p.minscore;
+    const int16_t* src = p.lut16 + ((size_t)r * p.Qt + (qb >= 33 ? qb - 33 : 0)) * p.rs16;
+    int8_t* dst = p.out + (size_t)row * rb;
+    for (int x = threadIdx.x; x < rb; x += blockDim.x) {
+        int v = 0;
+        if (!model) {
+            if (x < cyc) v = qb == 0 ? -33 : qb - 33;                     // padding -> 0 ; uncounted -> unchanged
+        } else {
+            if (x < S) v = src[x];                                        // mate 1: column = position
+            else if (x > S && x <= p.S2) v = src[p.S2 - 1 - (x - S - 1)]; // mate 2, position i = x-S-1: column 2S-1-i
+            else if (x >= cyc && x < cyc + 25) v = src[p.S2 + (x - cyc)];
+        }
+        dst[x] = (int8_t)v;
+    }
+}
+
+struct PairPackParams {
+    const uint8_t* src[3]; uint8_t* dst[3]; uint8_t fill[3];
+    const u32* meta; u32* pmeta;
+    long long npairs; int pitch; int ppitch; int S; int unpack;
+};
+
+// lane <-> 16-byte chunk of a destination row.  pack: two reads -> one pair row (three planes);
+// unpack: one pair row -> two rows of one plane (the K2 output).
+__global__ __launch_bounds__(256) void k7_pack_pairs(PairPackParams p)
+{
+    const int S = p.S;
+    if (!p.unpack) {
+        const int cpr = p.ppitch >> 4;
+        const long long nchunks = p.npairs * cpr;
+        for (long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks;
+             ch += (long long)gridDim.x * blockDim.x) {
+            const long long pr = ch / cpr;
+            const int j = (int)(ch - pr * cpr);
+            if (j == 0) p.pmeta[pr] = (u32)(2 * S + 1) | (p.meta[2 * pr] & 0x7FFF0000u);
+            const long long limit = 2 * p.npairs * (long long)p.pitch;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                if (!p.src[pl]) continue;
+                const u32 f4 = p.fill[pl] * 0x01010101u;
+                u32 a[4], b[4], o[4];
+                // bytes [16j, 16j+16) of the pair row: mate 1 from offset 16j, mate 2 from offset 16j - S - 1
+                load16_upto(p.src[pl], (2 * pr) * (long long)p.pitch + 16 * j, limit, a);
+                const long long off2 = (2 * pr + 1) * (long long)p.pitch + (16 * j - S - 1);
+                if (16 * j + 15 > S) {
+                    if (16 * j - S - 1 >= 0) load16_upto(p.src[pl], off2, limit, b);
+                    else {                                                   // the chunk holding the separator
+                        b[0] = b[1] = b[2] = b[3] = 0u;
+                        for (int k = S + 1 - 16 * j; k < 16; ++k)
+                            b[k >> 2] |= (u32)p.src[pl][off2 + k] << (8 * (k & 3));
+                    }
+                } else { b[0] = b[1] = b[2] = b[3] = 0u; }
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const u32 m1 = byte_mask(S - 16 * j, w);                         // bytes of mate 1
+                    const u32 m2 = range_mask(S + 1 - 16 * j, 2 * S + 1 - 16 * j, w);   // bytes of mate 2
+                    o[w] = (a[w] & m1) | (b[w] & m2) | (f4 & ~(m1 | m2));
+                }
+                *reinterpret_cast<uint4*>(p.dst[pl] + pr * (long long)p.ppitch + 16 * j) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    } else {
+        const int cpr = p.pitch >> 4;
+        const long long nchunks = 2 * p.npairs * cpr;
+        const long long limit = p.npairs * (long long)p.ppitch;
+        for (long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks;
+             ch += (long long)gridDim.x * blockDim.x) {
+            const long long rd = ch / cpr;
+            const int j = (int)(ch - rd * cpr);
+            const long long pr = rd >> 1;
+            const int base = (rd & 1) ? S + 1 : 0;
+            u32 a[4];
+            load16_upto(p.src[0], pr * (long long)p.ppitch + base + 16 * j, limit, a);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a[w] &= byte_mask(S - 16 * j, w);            // past the read: zero, as K2 writes
+            *reinterpret_cast<uint4*>(p.dst[0] + rd * (long long)p.pitch + 16 * j) = make_uint4(a[0], a[1], a[2], a[3]);
+        }
     }
 }
 

@@ -124,9 +124,79 @@ class ReadBatch:
         return (self.meta[:self.n].cpu().numpy().view(np.uint32) & 0xFFFF).astype(np.int64)
 
 
+class PairBatch:
+    """Device-resident mate-pair rows (include/kbbq_hip.h "mate-pair rows"): one row per read pair,
+    [mate 1][separator][mate 2][padding], pitch = roundup16(2S + 1) -- 304 instead of 2 x 160 bytes
+    for 2 x 150 bp.  accumulate() / apply() take it like a ReadBatch and give identical results;
+    `n` counts rows (pairs)."""
+
+    def __init__(self, npairs, S, with_corrected=True, device=None):
+        torch = _torch()
+        dev = 'cuda' if device is None else device
+        self.n, self.S = int(npairs), int(S)
+        self.pitch = int(N.load().kbbq_pair_pitch(2 * self.S))
+        rows = max(self.n, 1)
+        self.seq = torch.empty((rows, self.pitch), dtype=torch.uint8, device=dev)
+        self.qual = torch.empty((rows, self.pitch), dtype=torch.uint8, device=dev)
+        self.cseq = torch.empty((rows, self.pitch), dtype=torch.uint8, device=dev) if with_corrected else None
+        self.meta = torch.empty(rows, dtype=torch.int32, device=dev)
+        self.read_pitch = None
+
+    @staticmethod
+    def worthwhile(S, pitch):
+        """True when pair rows move fewer bytes than two rows of `pitch`."""
+        return int(N.load().kbbq_pair_pitch(2 * int(S))) < 2 * int(pitch)
+
+    @classmethod
+    def from_reads(cls, batch):
+        """Re-lay a ReadBatch whose reads alternate first / second in pair, all of one length, mates in
+        one read group.  ValueError otherwise (use the ReadBatch as it is)."""
+        torch = _torch()
+        n = batch.n
+        meta = batch.meta[:n]
+        if n == 0 or n % 2:
+            raise ValueError('mate-pair rows need an even, non-zero number of reads')
+        lens = meta & 0xFFFF
+        S = int(lens[0].item())
+        first, second = meta[0::2], meta[1::2]
+        ok = bool((lens == S).all().item()) and bool((first >= 0).all().item()) and bool((second < 0).all().item()) \
+            and bool((((first ^ second) >> 16) & 0x7FFF == 0).all().item())
+        if not ok or S == 0:
+            raise ValueError('reads are not uniform first/second pairs of one length and read group')
+        pb = cls(n // 2, S, with_corrected=batch.cseq is not None, device=batch.seq.device)
+        pb.read_pitch = batch.pitch
+        ctx = context(batch.seq.device.index)
+        N.check(N.load().kbbq_pack_pairs_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual),
+                                             N.ptr(batch.meta), pb.n, batch.pitch, 2 * S,
+                                             N.ptr(pb.seq), N.ptr(pb.cseq), N.ptr(pb.qual), N.ptr(pb.meta)))
+        return pb
+
+    def unpack(self, plane, pitch=None):
+        """A pair-row plane (the apply output) as one-read-per-row [2 n, pitch]."""
+        torch = _torch()
+        pitch = int(pitch or self.read_pitch or (self.S + 15) // 16 * 16)
+        out = torch.empty((max(2 * self.n, 1), pitch), dtype=torch.uint8, device=plane.device)
+        ctx = context(plane.device.index)
+        N.check(N.load().kbbq_unpack_pairs_dev(ctx.handle, N.ptr(plane), self.n, 2 * self.S, pitch, N.ptr(out)))
+        return out
+
+
+_pair_luts = {}
+
+
 def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None):
     """K1 over a device batch, adding into `tables` (recalibrate.py:57-119)."""
     ctx = context(batch.seq.device.index)
+    if isinstance(batch, PairBatch):
+        if tables.S2 != 2 * batch.S:
+            raise ValueError('mate-pair rows of %d-base reads need tables with 2S = %d columns' % (batch.S, 2 * batch.S))
+        N.check(N.load().kbbq_accumulate_pairs_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual),
+                                                   N.ptr(batch.meta), batch.n, tables.R, tables.S2, minscore,
+                                                   minscore if dinuc_minscore is None else dinuc_minscore,
+                                                   N.ptr(tables.buf)))
+        if check:
+            ctx.status()
+        return
     N.check(N.load().kbbq_accumulate_ex_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq),
                                             N.ptr(batch.qual), N.ptr(batch.meta), batch.n, batch.pitch,
                                             tables.R, tables.S2, minscore,
@@ -163,6 +233,23 @@ def apply(batch, lut_dev, shape, out=None, minscore=MINSCORE, check=True):
     ctx = context(batch.seq.device.index)
     if out is None:
         out = torch.empty_like(batch.qual)
+    if isinstance(batch, PairBatch):
+        # pair rows use their own layout of the table-driven LUT, derived on the device from the blob; rows it
+        # cannot serve (and a LUT that is not range-safe) surface as LutNeedsCheckedApply: unpack and re-run
+        if Qt != NQ or S2 != 2 * batch.S or mode != N.APPLY_FAST:
+            raise N.LutNeedsCheckedApply('mate-pair rows need the fast LUT of a %d-column model' % (2 * batch.S))
+        lib = N.load()
+        key = (batch.seq.device.index, R, S2)
+        plut = _pair_luts.get(key)
+        if plut is None:
+            plut = torch.empty(lib.kbbq_pair_lut_bytes(R, NQ, S2), dtype=torch.uint8, device=batch.seq.device)
+            _pair_luts[key] = plut
+        N.check(lib.kbbq_pair_lut_dev(ctx.handle, N.ptr(lut_dev), R, S2, minscore, N.ptr(plut)))
+        N.check(lib.kbbq_apply_pairs_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.qual), N.ptr(batch.meta), batch.n,
+                                         R, S2, minscore, N.ptr(lut_dev), N.ptr(plut), N.ptr(out)))
+        if check:
+            ctx.status()
+        return out
 
     def launch(m):
         N.check(N.load().kbbq_apply_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.qual), N.ptr(batch.meta),

@@ -1,0 +1,122 @@
+"""
+GPU tests (-m gpu) of the mate-pair row layout (include/kbbq_hip.h "mate-pair rows"): the same K1 / K2 on
+rows that hold a read pair each.  Everything must equal the one-read-per-row path, which the other GPU tests
+pin to the oracle and the reference's goldens; the oracle is consulted directly as well.
+"""
+import numpy as np
+import pytest
+
+from test_gpu_parity import dev                      # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs_numpy(plane, meta, S, ppitch, fill):
+    n = plane.shape[0]
+    out = np.full((n // 2, ppitch), fill, dtype=np.uint8)
+    out[:, :S] = plane[0::2, :S]
+    out[:, S + 1:2 * S + 1] = plane[1::2, :S]
+    return out
+
+
+@pytest.mark.parametrize('S,nrg', [(150, 1), (150, 4), (100, 2), (151, 1), (16, 3), (75, 1), (33, 2)])
+def test_pack_accumulate_apply_equal_the_row_per_read_path(dev, oracle, S, nrg):
+    import torch
+    n = 6002 if S != 16 else 1280
+    b = dev.ReadBatch.synthetic(0, n, n, seed=3 + S, len_lo=S, len_hi=S, nrg=nrg)
+    pb = dev.PairBatch.from_reads(b)
+    assert pb.n == n // 2 and pb.pitch == (2 * S + 1 + 15) // 16 * 16
+    # the layout itself
+    meta = b.meta[:n].cpu().numpy().view(np.uint32)
+    for plane, pplane, fill in ((b.seq, pb.seq, ord('N')), (b.cseq, pb.cseq, ord('N')), (b.qual, pb.qual, 0)):
+        assert np.array_equal(pplane[:pb.n].cpu().numpy(), _pairs_numpy(plane[:n].cpu().numpy(), meta, S, pb.pitch, fill))
+    want_meta = (2 * S + 1) | (meta[0::2] & 0x7FFF0000)
+    assert np.array_equal(pb.meta[:pb.n].cpu().numpy().view(np.uint32), want_meta)
+    # K1: identical tables, and they are the oracle's
+    t_reads, t_pairs = dev.Tables(nrg, 2 * S), dev.Tables(nrg, 2 * S)
+    dev.accumulate(b, t_reads)
+    dev.accumulate(pb, t_pairs)
+    assert torch.equal(t_reads.buf, t_pairs.buf)
+    host = [x.cpu().numpy() for x in (b.seq[:n], b.cseq[:n], b.qual[:n])]
+    want = oracle.accumulate(host[0], host[1], host[2], meta, nrg, S)
+    for got, w in zip(t_pairs.to_host(), want[5:9]):             # pos_errs, pos_total, dinuc_errs, dinuc_total
+        assert np.array_equal(got, w)
+    # K3 -> K2: identical new qualities after unpacking
+    lut, shape, _, _ = dev.solve(t_pairs)
+    out_reads = dev.apply(b, lut, shape)
+    out_pairs = dev.apply(pb, lut, shape)
+    assert torch.equal(pb.unpack(out_pairs)[:n], out_reads[:n])
+    # padding and separator bytes of the pair plane stay zero
+    op = out_pairs[:pb.n].cpu().numpy()
+    assert not op[:, S].any() and not op[:, 2 * S + 1:].any()
+    # adds into the tables like the other path
+    dev.accumulate(pb, t_pairs)
+    assert torch.equal(t_pairs.buf, 2 * t_reads.buf)
+
+
+def test_minscore_and_split_thresholds(dev, oracle):
+    import torch
+    n, S = 4000, 150
+    b = dev.ReadBatch.synthetic(0, n, n, seed=17, len_lo=S, len_hi=S, nrg=2, qlo=2, qhi=41)
+    pb = dev.PairBatch.from_reads(b)
+    for minscore, dmin in ((6, None), (20, None), (4, 6), (10, 6), (4, 12)):
+        a, c = dev.Tables(2, 2 * S), dev.Tables(2, 2 * S)
+        dev.accumulate(b, a, minscore, dinuc_minscore=dmin)
+        dev.accumulate(pb, c, minscore, dinuc_minscore=dmin)
+        assert torch.equal(a.buf, c.buf), (minscore, dmin)
+    # more quality rows than the LDS tables hold: the pair path declines, the row-per-read path has a fallback
+    from kbbq import _native as N
+    with pytest.raises(N.LutNeedsCheckedApply):
+        dev.accumulate(pb, dev.Tables(2, 2 * S), 0)
+    dev.accumulate(b, dev.Tables(2, 2 * S), 0)
+
+
+def test_not_pairable_and_error_reporting(dev):
+    import torch
+    n, S = 512, 60
+    b = dev.ReadBatch.synthetic(0, n, n, seed=5, len_lo=40, len_hi=S, nrg=1)          # ragged lengths
+    with pytest.raises(ValueError):
+        dev.PairBatch.from_reads(b)
+    b = dev.ReadBatch.synthetic(0, n - 1, n - 1, seed=5, len_lo=S, len_hi=S, nrg=1)  # odd count
+    with pytest.raises(ValueError):
+        dev.PairBatch.from_reads(b)
+    b = dev.ReadBatch.synthetic(0, n, n, seed=5, len_lo=S, len_hi=S, nrg=1)
+    b.meta[7] = b.meta[7] ^ (1 << 16)                                                  # mates in different read groups
+    with pytest.raises(ValueError):
+        dev.PairBatch.from_reads(b)
+    b = dev.ReadBatch.synthetic(0, n, n, seed=5, len_lo=S, len_hi=S, nrg=1)
+    assert not dev.PairBatch.worthwhile(75, 80) and dev.PairBatch.worthwhile(150, 160)
+    pb = dev.PairBatch.from_reads(b)
+    t = dev.Tables(1, 2 * S)
+    pb.qual[9, S + 5] = 33 + 43                                                        # quality 43 in mate 2 of pair 9
+    with pytest.raises(IndexError):
+        dev.accumulate(pb, t)
+    pb = dev.PairBatch.from_reads(b)
+    pb.seq[3, 10] = ord('R'); pb.qual[3, 10] = 33 + 30
+    with pytest.raises(TypeError):
+        dev.accumulate(pb, dev.Tables(1, 2 * S))
+    # a row the fast apply cannot serve: reported, never silently wrong
+    pb = dev.PairBatch.from_reads(b)
+    t = dev.Tables(1, 2 * S); dev.accumulate(pb, t)
+    lut, shape, _, _ = dev.solve(t)
+    pb.qual[5, 3] = 33 + 60
+    from kbbq import _native as N
+    with pytest.raises(N.LutNeedsCheckedApply):
+        dev.apply(pb, lut, shape)
+
+
+def test_large_batch_properties(dev):
+    """20 M reads: pair rows give the very tables and qualities of the row-per-read path."""
+    import torch
+    n, S = 20_000_000, 150
+    b = dev.ReadBatch.synthetic(0, n, n, seed=1, len_lo=S, len_hi=S, nrg=1)
+    pb = dev.PairBatch.from_reads(b)
+    a, c = dev.Tables(1, 2 * S), dev.Tables(1, 2 * S)
+    dev.accumulate(b, a); dev.accumulate(pb, c)
+    assert torch.equal(a.buf, c.buf)
+    lut, shape, _, _ = dev.solve(c)
+    out_reads = dev.apply(b, lut, shape)
+    out_pairs = dev.apply(pb, lut, shape)
+    del b
+    un = pb.unpack(out_pairs)
+    assert torch.equal(un[:n], out_reads[:n])
