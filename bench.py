@@ -150,7 +150,8 @@ def main():
         traffic = None
         try:
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
-                traffic = json.load(fh)[dom]['hbm_bytes_per_base'] * bases_per_rank
+                pmc = json.load(fh)
+                traffic = (pmc['pairs'] if layout.startswith('mate-pair') else pmc)[dom]['hbm_bytes_per_base'] * bases_per_rank
         except Exception:
             pass
         res = {
