@@ -120,3 +120,20 @@ def test_large_batch_properties(dev):
     del b
     un = pb.unpack(out_pairs)
     assert torch.equal(un[:n], out_reads[:n])
+
+
+def test_product_fastq_path_takes_pair_rows_when_it_can(dev, oracle, tmp_path):
+    """kbbq.recalibrate tallies uniform pairs on mate-pair rows (goldens c1 / c3cut: the printed FASTQ is the
+    reference's, tests/test_gpu_parity.py) and ragged reads one read per row."""
+    from conftest import load_golden
+    from kbbq import recalibrate
+    from test_gpu_parity import VEC, _files
+    for name, expect_pairs in (('c1_10k_1rg', True), ('c3cut_2k_8rg', True), ('c5cut_2k_mixed', False)):
+        info, gold = load_golden(name)
+        d = tmp_path / name; d.mkdir()
+        fa, fb = _files(oracle, info, d)
+        packed, tables = recalibrate._pack_and_tally([fa, fb], info['case']['infer_rg'], 6, 42)
+        assert (packed['pairs'] is not None) == expect_pairs, name
+        got = recalibrate._vectors_from_tables(*tables.to_host(), 42)
+        for k, v in zip(VEC, got):
+            assert np.array_equal(v, gold[k]), (name, k)
