@@ -288,6 +288,9 @@ const char* kbbq_fastq_rg_name(const kbbq_fastq* f, int i);
 int         kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* info5);
 int         kbbq_fastq_fill(const kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t n, int pitch,
                             uint8_t* seq, uint8_t* cseq, uint8_t* qual, uint32_t* meta);
+/* the same for reads [first, first + n) -> rows [0, n): one rank's shard; read-group ids are those of the scan */
+int kbbq_fastq_fill_range(const kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t first, int64_t n, int pitch,
+                          uint8_t* seq, uint8_t* cseq, uint8_t* qual, uint32_t* meta);
 int64_t     kbbq_fastq_format(const kbbq_fastq* a, int64_t first, int64_t n, int pitch,
                               const uint8_t* newqual, char* out, int64_t cap);
 

@@ -238,20 +238,29 @@ int kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* i
 int kbbq_fastq_fill(const kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t n, int pitch,
                     uint8_t* seq, uint8_t* cseq, uint8_t* qual, uint32_t* meta)
 {
-    if (!a || !seq || !qual || !meta || (b && !cseq)) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_fill: NULL argument");
-    if (n < 0 || n > (int64_t)a->h0.size() || (b && n > (int64_t)b->h0.size())) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_fill: n out of range");
+    return kbbq_fastq_fill_range(a, b, infer_rg, 0, n, pitch, seq, cseq, qual, meta);
+}
+
+// reads [first, first + n) into rows [0, n): the shard of one rank (read groups keep the ids of the scan)
+int kbbq_fastq_fill_range(const kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t first, int64_t n, int pitch,
+                          uint8_t* seq, uint8_t* cseq, uint8_t* qual, uint32_t* meta)
+{
+    if (!a || (n > 0 && (!seq || !qual || !meta || (b && !cseq)))) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_fill: NULL argument");
+    if (first < 0 || n < 0 || first + n > (int64_t)a->h0.size() || (b && first + n > (int64_t)b->h0.size()))
+        return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_fill: range out of bounds");
     std::unordered_map<std::string, int> rgmap;
     for (size_t i = 0; i < a->rg_names.size(); ++i) rgmap.emplace(a->rg_names[i], (int)i);
     std::atomic<int> bad(0);
     parallel_for(n, nthreads_for((size_t)n * (size_t)pitch * 3), [&](int64_t lo, int64_t hi) {
-        for (int64_t i = lo; i < hi; ++i) {
+        for (int64_t row = lo; row < hi; ++row) {
+            const int64_t i = first + row;
             const uint32_t L = a->slen[i];
             if ((int)L > pitch || (b && b->slen[i] != L)) { bad = 1; continue; }
-            uint8_t* s = seq + (size_t)i * pitch; uint8_t* q = qual + (size_t)i * pitch;
+            uint8_t* s = seq + (size_t)row * pitch; uint8_t* q = qual + (size_t)row * pitch;
             memcpy(s, a->buf + a->s0[i], L); memset(s + L, 'N', (size_t)pitch - L);
             memcpy(q, a->buf + a->q0[i], L); memset(q + L, 0, (size_t)pitch - L);
             if (b) {
-                uint8_t* c = cseq + (size_t)i * pitch;
+                uint8_t* c = cseq + (size_t)row * pitch;
                 memcpy(c, b->buf + b->s0[i], L); memset(c + L, 'N', (size_t)pitch - L);
             }
             const char* nm = (const char*)a->buf + a->h0[i]; const int nl = (int)a->hlen[i];
@@ -263,7 +272,7 @@ int kbbq_fastq_fill(const kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int6
                 if (it == rgmap.end()) { bad = 2; continue; }
                 rgid = (uint32_t)it->second;
             }
-            meta[i] = L | (rgid << 16) | ((uint32_t)name_second(nm, nl) << 31);
+            meta[row] = L | (rgid << 16) | ((uint32_t)name_second(nm, nl) << 31);
         }
     });
     if (bad.load()) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_fill: input does not match the scan (call kbbq_fastq_scan first)");

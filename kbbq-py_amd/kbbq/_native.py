@@ -82,6 +82,7 @@ PROTOTYPES = {
     'kbbq_fastq_rg_name': (_c.c_char_p, [_vp, _i]),
     'kbbq_fastq_scan': (_i, [_vp, _vp, _i, _vp]),
     'kbbq_fastq_fill': (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
+    'kbbq_fastq_fill_range': (_i, [_vp, _vp, _i, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
     'kbbq_fastq_format': (_i64, [_vp, _i64, _i64, _i, _vp, _vp, _i64]),
     'kbbq_synth_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _u64,
                             _i, _i, _i, _i, _i, _vp]),
@@ -204,7 +205,11 @@ class Context:
     def status(self):
         """Raise the error the reference would have raised, if a kernel flagged one."""
         idx = ctypes.c_int64(-1)
-        check(load().kbbq_ctx_status(self._h, ctypes.byref(idx)))
+        try:
+            check(load().kbbq_ctx_status(self._h, ctypes.byref(idx)))
+        except Exception as exc:
+            exc.read_index = int(idx.value)          # row of the batch the kernel flagged (multi-rank error agreement)
+            raise
 
     def timing(self, enable):
         check(load().kbbq_ctx_timing(self._h, 1 if enable else 0))

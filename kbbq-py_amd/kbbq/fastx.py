@@ -280,14 +280,15 @@ class NativeFastq:
                                            1 if infer_rg_flag else 0, _N.ptr(info)))
         return [int(x) for x in info]
 
-    def fill(self, other, infer_rg_flag, n, pitch):
+    def fill(self, other, infer_rg_flag, n, pitch, first=0):
+        """Planes and sidecar of reads [first, first + n) (rows 0..n-1)."""
         seq = np.empty((n, pitch), dtype=np.uint8)
         qual = np.empty((n, pitch), dtype=np.uint8)
         cseq = np.empty((n, pitch), dtype=np.uint8) if other is not None else None
         meta = np.empty(n, dtype=np.uint32)
-        _N.check(_N.load().kbbq_fastq_fill(self._h, other._h if other is not None else None,
-                                           1 if infer_rg_flag else 0, n, pitch, _N.ptr(seq), _N.ptr(cseq),
-                                           _N.ptr(qual), _N.ptr(meta)))
+        _N.check(_N.load().kbbq_fastq_fill_range(self._h, other._h if other is not None else None,
+                                                 1 if infer_rg_flag else 0, first, n, pitch, _N.ptr(seq),
+                                                 _N.ptr(cseq), _N.ptr(qual), _N.ptr(meta)))
         return seq, cseq, qual, meta
 
     def format(self, first, n, newqual):
@@ -313,28 +314,41 @@ _SCAN_ERRORS = {
 }
 
 
-def pack_pair(path_a, path_b, infer_rg_flag):
+def _shard(n, shard):
+    """Records [lo, hi) of this rank among n (pairs stay together), or everything."""
+    if shard is None:
+        return 0, n
+    from .parallel import shard_range
+    return shard_range(n, shard[0], shard[1])
+
+
+def pack_pair(path_a, path_b, infer_rg_flag, shard=None):
     """Pass-1 input (recalibrate.py:56-57) through the C++ packer; same dictionary as pack_pair_py
-    except that `text` is the NativeFastq of file A and `names` is filled lazily by callers."""
+    except that `text` is the NativeFastq of file A and `names` is filled lazily by callers.
+    shard = (rank, world): every rank scans the whole pair (so read-group ids, the longest read and
+    the first host-detectable error are global) and packs only its own records [first, first + n);
+    `total` is the global number of usable reads."""
     A, B = NativeFastq(path_a), NativeFastq(path_b)
-    n, S, R, kind, idx = A.scan(B, infer_rg_flag)
+    total, S, R, kind, idx = A.scan(B, infer_rg_flag)
     pending = (idx, _SCAN_ERRORS[kind](idx), kind == 5) if kind else None
     pitch = pitch_for(S)
-    seq, cseq, qual, meta = A.fill(B, infer_rg_flag, n, pitch)
+    lo, hi = _shard(total, shard)
+    seq, cseq, qual, meta = A.fill(B, infer_rg_flag, hi - lo, pitch, first=lo)
     rgs = A.rg_names()
-    return dict(seq=seq, cseq=cseq, qual=qual, meta=meta, n=n, pitch=pitch, S=S, R=R,
+    return dict(seq=seq, cseq=cseq, qual=qual, meta=meta, n=hi - lo, first=lo, total=total, pitch=pitch, S=S, R=R,
                 rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)},
                 text=A, pending_error=pending)
 
 
-def pack_single(text, infer_rg_flag):
+def pack_single(text, infer_rg_flag, shard=None):
     """Pass-2 input: every read of file A with its own first-appearance RG map
-    (recalibrate.py:141-148)."""
-    n, S, R, kind, idx = text.scan(None, infer_rg_flag)
+    (recalibrate.py:141-148); shard = (rank, world) as in pack_pair."""
+    total, S, R, kind, idx = text.scan(None, infer_rg_flag)
     if kind:
         raise _SCAN_ERRORS[kind](idx)
     pitch = pitch_for(S)
-    seq, _, qual, meta = text.fill(None, infer_rg_flag, n, pitch)
+    lo, hi = _shard(total, shard)
+    seq, _, qual, meta = text.fill(None, infer_rg_flag, hi - lo, pitch, first=lo)
     rgs = text.rg_names()
-    return dict(seq=seq, qual=qual, meta=meta, n=n, pitch=pitch, S=S, R=R,
+    return dict(seq=seq, qual=qual, meta=meta, n=hi - lo, first=lo, total=total, pitch=pitch, S=S, R=R,
                 rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)})

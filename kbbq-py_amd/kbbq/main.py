@@ -10,6 +10,8 @@ from . import recalibrate as _recal
 
 
 def recalibrate(args):
+    from . import parallel
+    parallel.init_from_env()          # one process per GPU under torch.distributed.run; no-op otherwise
     _recal.recalibrate(bam=args.bam, fastq=args.fastq, infer_rg=args.infer_rg,
                        use_oq=args.use_oq, set_oq=args.set_oq, gatkreport=args.gatkreport)
 

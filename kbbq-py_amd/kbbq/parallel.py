@@ -44,6 +44,90 @@ def merge_rg_maps(local_names):
     return list(order), np.array([order[nm] for nm in local_names], dtype=np.int64)
 
 
+def world_rank():
+    """(world size, rank) of the initialised process group, (1, 0) without one."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def init_from_env():
+    """One process per GPU under torch.distributed.run: bind cuda:LOCAL_RANK and join the RCCL group
+    (backend "nccl" is RCCL on ROCm; KBBQ_DIST_BACKEND=gloo lets several ranks share one GPU for
+    rehearsals).  No-op outside a launcher or when already initialised."""
+    import os
+    import torch
+    import torch.distributed as dist
+    if 'RANK' not in os.environ or int(os.environ.get('WORLD_SIZE', '1')) <= 1 or dist.is_initialized():
+        return world_rank()
+    backend = os.environ.get('KBBQ_DIST_BACKEND', 'nccl')
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.is_available():
+        local = local % torch.cuda.device_count() if backend != 'nccl' else local
+        torch.cuda.set_device(local)
+    # stdout is the recalibrated FASTQ: the communication libraries' own banners (Gloo's "connected to peer
+    # ranks", RCCL's version line under NCCL_DEBUG) go to stderr -- they appear while the group is set up and
+    # at the first collective, so both happen under the redirection
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+            warm = torch.zeros(1, device='cuda')
+        else:
+            dist.init_process_group(backend)
+            warm = torch.zeros(1)
+        dist.all_reduce(warm)
+        dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    return world_rank()
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def raise_first_error(exc=None, index=None):
+    """Every rank calls this after a data-dependent step with the exception it caught (or None) and
+    the GLOBAL index of the read that caused it.  If any rank has one, ALL ranks raise the error of the
+    smallest read index -- what a single process walking the reads in order would have raised -- so no
+    rank is left waiting in a collective."""
+    import torch.distributed as dist
+    mine = None if exc is None else (int(index if index is not None else 0), type(exc).__name__, str(exc))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, mine)
+    else:
+        everyone = [mine]
+    found = [e for e in everyone if e is not None]
+    if not found:
+        return
+    idx, name, msg = min(found, key=lambda e: e[0])
+    if exc is not None and mine == (idx, name, msg):
+        raise exc
+    import builtins
+    raise getattr(builtins, name, RuntimeError)(msg)
+
+
+def in_rank_order(fn):
+    """Run fn() on rank 0, then rank 1, ...: ordered output on a shared stdout."""
+    world, rank = world_rank()
+    for r in range(world):
+        if r == rank:
+            fn()
+        barrier()
+
+
 def max_over_ranks(value):
     """Largest `value` over all ranks (the global longest read -> S)."""
     import torch

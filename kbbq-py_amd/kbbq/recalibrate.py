@@ -20,6 +20,7 @@ from . import compare_reads as utils
 from . import fastx
 from . import _device as dev
 from . import _solve
+from . import parallel
 from .gatk import applybqsr
 
 
@@ -37,22 +38,24 @@ def _vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore)
     return _solve.vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore)
 
 
-def _tally(packed, minscore, maxscore, upto=None):
-    """K1 over the packed pair (optionally only its first `upto` reads) -> device Tables.
+def _tally_local(packed, minscore, maxscore):
+    """K1 over this rank's packed reads -> device Tables (zero tables when the rank has no reads).
     Uniform first/second pairs are tallied on mate-pair rows (5 % fewer bytes through HBM, identical
     counts); anything that path reports is redone one read per row, which carries the reference's
     exact error semantics."""
     if maxscore != 42:
         raise ValueError('the Q axis of the device tables is fixed at 43 (maxscore = 42)')
-    n = packed['n'] if upto is None else upto
+    n = packed['n']
     R, S = max(packed['R'], 0), packed['S']
-    if n == 0 or R == 0:
+    packed['batch'] = packed['pairs'] = None
+    if R == 0 or S == 0:
         return None
+    tables = dev.Tables(R, 2 * S)
+    if n == 0:
+        return tables
     batch = dev.ReadBatch.from_host(packed['seq'][:n], packed['qual'][:n], packed['meta'][:n],
                                     cseq=packed['cseq'][:n])
-    tables = dev.Tables(R, 2 * S)
     packed['batch'] = batch                  # still resident: pass 2 re-uses it when it covers file A
-    packed['pairs'] = None
     if dev.PairBatch.worthwhile(S, batch.pitch):
         try:
             pairs = dev.PairBatch.from_reads(batch)
@@ -65,8 +68,25 @@ def _tally(packed, minscore, maxscore, upto=None):
     return tables
 
 
+def _tally(packed, minscore, maxscore):
+    """_tally_local on every rank, agreement on the first error any rank's kernel reported (all ranks
+    raise it), then ONE sum-allreduce of the count tables (RCCL over xGMI)."""
+    exc, tables = None, None
+    try:
+        tables = _tally_local(packed, minscore, maxscore)
+    except (IndexError, TypeError) as e:
+        if not hasattr(e, 'read_index'):
+            raise
+        exc = e
+    parallel.raise_first_error(exc, None if exc is None else packed.get('first', 0) + max(exc.read_index, 0))
+    if tables is not None:
+        parallel.allreduce_tables(tables.buf)
+    return tables
+
+
 def _pack_and_tally(fastq, infer_rg, minscore, maxscore):
-    packed = fastx.pack_pair(fastq[0], fastq[1], infer_rg)
+    world, rank = parallel.world_rank()
+    packed = fastx.pack_pair(fastq[0], fastq[1], infer_rg, shard=(rank, world) if world > 1 else None)
     err = packed.get('pending_error')
     if err is not None:
         # the reference fails at the FIRST offending read: let the kernel look at the reads
@@ -74,7 +94,10 @@ def _pack_and_tally(fastq, infer_rg, minscore, maxscore):
         idx, exc, inclusive = err
         _tally(packed, minscore, maxscore)
         raise exc
-    return packed, _tally(packed, minscore, maxscore)
+    tables = _tally(packed, minscore, maxscore)
+    if tables is not None and packed.get('total', packed['n']) == 0:
+        tables = None
+    return packed, tables
 
 
 def fastq_to_covariate_arrays(fastq, infer_rg=False, minscore=6, maxscore=42):
@@ -113,18 +136,35 @@ def load_model(path, rg_to_int):
     return dev.Tables.from_host(*vectors[5:9])
 
 
+def _collective(fn, first=0):
+    """fn() on every rank; if a kernel of any rank flagged bad input, all ranks raise the error of the
+    globally first offending read (a single process would have stopped there)."""
+    exc, res = None, None
+    try:
+        res = fn()
+    except (IndexError, TypeError, ValueError) as e:
+        exc = e
+    parallel.raise_first_error(exc, None if exc is None else first + max(getattr(exc, 'read_index', 0), 0))
+    return res
+
+
 def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
     """Recalibrate FASTQ file fastq[0] using its error-corrected version fastq[1];
     the recalibrated FASTQ is printed to stdout.  K1 -> K3 -> K2, tables and LUT stay on
     the device between the kernels.  gatkreport (the reference declares the option and raises
     NotImplementedError, recalibrate.py:167-168): an existing report replaces pass 1 (fastq[1]
-    is not read); otherwise the model of pass 1 is saved there."""
+    is not read); otherwise the model of pass 1 is saved there.
+    Under torch.distributed (one process per GPU, parallel.init_from_env) every rank takes a contiguous
+    shard of the records, the count tables are summed with one allreduce, the solve is replicated and
+    the ranks print their records in rank order: the concatenated output is the single-process output."""
+    world, rank = parallel.world_rank()
+    shard = (rank, world) if world > 1 else None
+    packed, single = None, None
     if gatkreport is not None and os.path.exists(gatkreport):
         text = fastx.NativeFastq(fastq[0])
         if text.n == 0:
             return
-        single = fastx.pack_single(text, infer_rg)
-        packed = dict(text=text, n=-1)
+        single = fastx.pack_single(text, infer_rg, shard)
         tables = load_model(gatkreport, single['rg_to_int'])
     else:
         packed, tables = _pack_and_tally(fastq, infer_rg, 6, 42)
@@ -134,34 +174,45 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
         if tables is None:
             raise IndexError('index 0 is out of bounds for axis 0 with size 0')   # no read was tallied
         if gatkreport is not None:
-            save_model(tables, packed['rg_to_int'], gatkreport)
+            if rank == 0:
+                save_model(tables, packed['rg_to_int'], gatkreport)
+            parallel.barrier()
     lut, shape, _, _ = dev.solve(tables)
-    if packed['n'] == text.n:
+    pairs = None
+    if packed is not None and packed['total'] == text.n:
         # pass 2 walks the same reads with the same first-appearance read groups (:141-148):
         # the planes of pass 1 are still on the device
-        batch, single = packed['batch'], packed
+        batch, single, pairs = packed['batch'], packed, packed['pairs']
     else:
         # file B was shorter (zip truncation), or the model came from a report: pass 2 covers
         # all of file A with its own first-appearance read groups
-        if packed['n'] >= 0:
-            single = fastx.pack_single(text, infer_rg)
-        batch = dev.ReadBatch.from_host(single['seq'], single['qual'], single['meta'])
-    pairs = packed.get('pairs') if batch is packed.get('batch') else None
-    out = None
-    if pairs is not None:
-        try:
-            out = pairs.unpack(dev.apply(pairs, lut, shape))
-        except dev.N.LutNeedsCheckedApply:
-            out = None                       # a LUT the fast kernel cannot serve: the checked row-per-read kernel
-    if out is None:
-        out = dev.apply(batch, lut, shape)
+        if single is None:
+            single = fastx.pack_single(text, infer_rg, shard)
+        batch = dev.ReadBatch.from_host(single['seq'], single['qual'], single['meta']) if single['n'] else None
+
+    def apply_shard():
+        out = None
+        if pairs is not None:
+            try:
+                out = pairs.unpack(dev.apply(pairs, lut, shape))
+            except dev.N.LutNeedsCheckedApply:
+                out = None                   # a LUT the fast kernel cannot serve: the checked row-per-read kernel
+        if out is None and batch is not None:
+            out = dev.apply(batch, lut, shape)
+        return out
+    out = _collective(apply_shard, single['first'])
+
     # recalibrate.py:153-156: '@' + name, sequence, '+', qualities -- rendered by the C++ writer in
     # slabs, written through print() like the reference
-    step = 1 << 20
-    for first in range(0, single['n'], step):
-        m = min(step, single['n'] - first)
-        newq = out[first:first + m].cpu().numpy()
-        print(packed['text'].format(first, m, newq).decode('latin-1'), end='')
+    def emit():
+        import sys
+        step = 1 << 20
+        for first in range(0, single['n'], step):
+            m = min(step, single['n'] - first)
+            newq = out[first:first + m].cpu().numpy()
+            print(text.format(single['first'] + first, m, newq).decode('latin-1'), end='')
+        sys.stdout.flush()
+    parallel.in_rank_order(emit)
 
 
 def recalibrate_bam(bam, use_oq=False, set_oq=False):

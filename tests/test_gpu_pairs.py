@@ -137,3 +137,45 @@ def test_product_fastq_path_takes_pair_rows_when_it_can(dev, oracle, tmp_path):
         got = recalibrate._vectors_from_tables(*tables.to_host(), 42)
         for k, v in zip(VEC, got):
             assert np.array_equal(v, gold[k]), (name, k)
+
+
+def _run_ranks(world, argv, timeout=300):
+    import os, socket, subprocess, sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, KBBQ_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'tests', 'dist_cli_worker.py')] + argv
+    return subprocess.run(cmd, env=env, capture_output=True, timeout=timeout)
+
+
+@pytest.mark.parametrize('name', ['c1_10k_1rg', 'c3cut_2k_8rg', 'c5cut_2k_mixed', 'short_64_1rg'])
+def test_two_ranks_print_the_reference_output(dev, oracle, name, tmp_path):
+    """`kbbq recalibrate` under torch.distributed.run with 2 ranks (gloo, both on this GPU: a rehearsal of
+    the one-process-per-GPU mode): shards, one allreduce of the tables, rank-ordered output = the reference's."""
+    from conftest import load_golden
+    from test_gpu_parity import _files
+    info, _ = load_golden(name)
+    fa, fb = _files(oracle, info, tmp_path)
+    argv = ['recalibrate', '-f', fa, fb] + (['--infer-rg'] if info['case']['infer_rg'] else [])
+    r = _run_ranks(2, argv)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    text = r.stdout.decode()
+    assert len(text) == info['output_len'] and oracle.sha256(text) == info['output_sha256']
+
+
+def test_two_ranks_agree_on_the_first_error(dev, oracle, tmp_path):
+    """A quality above 42 in the second rank's shard: every rank raises the IndexError (no rank is left in the
+    allreduce), nothing is printed."""
+    from conftest import load_golden
+    from test_gpu_parity import _files
+    info, _ = load_golden('c1_10k_1rg')
+    fa, fb = _files(oracle, info, tmp_path)
+    lines = open(fa).read().split('\n')
+    rec = 4 * 7777                                             # read 7777 lives on rank 1
+    lines[rec + 3] = lines[rec + 3][:20] + chr(33 + 50) + lines[rec + 3][21:]
+    open(fa, 'w').write('\n'.join(lines))
+    r = _run_ranks(2, ['recalibrate', '-f', fa, fb], timeout=200)
+    assert r.returncode != 0 and r.stdout == b''
+    assert r.stderr.decode().count('IndexError') >= 2

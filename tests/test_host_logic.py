@@ -359,3 +359,27 @@ def test_dispatcher_errors():
     assert list(recalibrate.find_corrected_sites(a, b)) == [False] * 5 + [True]
     with pytest.raises(AssertionError):
         recalibrate.find_corrected_sites(a, fastx.FastxRecord('s', 'ACGTAC', 'IIIIII'))
+
+
+def test_sharded_packing_concatenates_to_the_whole(oracle, tmp_path):
+    """pack_pair / pack_single with shard = (rank, world): every rank scans everything (global read groups,
+    longest read, first error) and packs its own contiguous records; pairs stay together."""
+    info, _ = load_golden('c5cut_2k_mixed')
+    c = info['case']
+    n = 301
+    seq, cseq, qual, meta = oracle.synth(0, n, c['n'], c['seed'], c['len_lo'], c['len_hi'], c['nrg'])
+    names = oracle.synth_names(0, n, c['nrg'], with_rg=True)
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, names, cseq, qual, meta)
+    whole = fastx.pack_pair(fa, fb, True)
+    for world in (2, 3, 8):
+        parts = [fastx.pack_pair(fa, fb, True, shard=(r, world)) for r in range(world)]
+        assert [p['first'] for p in parts] == [sum(q['n'] for q in parts[:i]) for i in range(world)]
+        assert all(p['first'] % 2 == 0 for p in parts) and sum(p['n'] for p in parts) == whole['n'] == parts[0]['total']
+        for k in ('seq', 'cseq', 'qual', 'meta'):
+            assert np.array_equal(np.concatenate([p[k] for p in parts]), whole[k]), k
+        assert all((p['S'], p['R'], p['pitch'], p['rg_to_int']) == (whole['S'], whole['R'], whole['pitch'], whole['rg_to_int'])
+                   for p in parts)
+        singles = [fastx.pack_single(whole['text'], True, shard=(r, world)) for r in range(world)]
+        assert np.array_equal(np.concatenate([p['qual'] for p in singles]), whole['qual'])

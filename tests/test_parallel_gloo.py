@@ -94,3 +94,47 @@ def test_shard_range():
             for (a, b), (c, d) in zip(spans, spans[1:]):
                 assert b == c and a <= b
             assert all(lo % 2 == 0 or lo == n for lo, _ in spans)
+
+
+def _agree_worker(rank, world, port, q):
+    import sys
+    for p in (os.path.join(ROOT, 'kbbq-py_amd'), os.path.join(ROOT, 'tests')):
+        sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from kbbq import parallel
+        out = []
+        parallel.raise_first_error(None)                                  # nobody has an error: returns
+        try:                                                              # rank 1 has one: everybody raises it
+            parallel.raise_first_error(IndexError('read 70') if rank == 1 else None, 70)
+        except IndexError as e:
+            out.append(('index', str(e)))
+        try:                                                              # both have one: the smaller read index wins
+            exc = TypeError('read 5') if rank == 1 else IndexError('read 9')
+            parallel.raise_first_error(exc, 5 if rank == 1 else 9)
+        except (TypeError, IndexError) as e:
+            out.append((type(e).__name__, str(e)))
+        order = []
+        parallel.in_rank_order(lambda: order.append(rank))
+        out.append(('world', parallel.world_rank()))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_error_agreement_and_rank_order():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        assert res[rank][0] == ('index', 'read 70')
+        assert res[rank][1] == ('TypeError', 'read 5')
+        assert res[rank][2] == ('world', (2, rank))
