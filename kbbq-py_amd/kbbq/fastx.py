@@ -291,16 +291,21 @@ class NativeFastq:
                                                  _N.ptr(cseq), _N.ptr(qual), _N.ptr(meta)))
         return seq, cseq, qual, meta
 
-    def format(self, first, n, newqual):
-        """FASTQ text (bytes) of reads [first, first+n) with qualities from rows of `newqual`."""
+    def format_array(self, first, n, newqual):
+        """FASTQ text of reads [first, first+n) with qualities from rows of `newqual`, as a uint8 array
+        (written once by the C++ writer: no zero fill, no copy)."""
         newqual = np.ascontiguousarray(newqual)
         pitch = newqual.shape[1]
         lib = _N.load()
-        need = -lib.kbbq_fastq_format(self._h, first, n, pitch, _N.ptr(newqual), None, 0)
-        buf = _ct.create_string_buffer(max(int(need), 1))
-        got = lib.kbbq_fastq_format(self._h, first, n, pitch, _N.ptr(newqual), buf, need)
+        need = int(-lib.kbbq_fastq_format(self._h, first, n, pitch, _N.ptr(newqual), None, 0))
+        buf = np.empty(max(need, 1), dtype=np.uint8)
+        got = lib.kbbq_fastq_format(self._h, first, n, pitch, _N.ptr(newqual), _N.ptr(buf), need)
         assert got == need
-        return buf.raw[:need]
+        return buf[:need]
+
+    def format(self, first, n, newqual):
+        """The same as bytes."""
+        return self.format_array(first, n, newqual).tobytes()
 
 
 _SCAN_ERRORS = {

@@ -206,11 +206,17 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
     # slabs, written through print() like the reference
     def emit():
         import sys
+        raw = getattr(sys.stdout, 'buffer', None)      # a text-only stdout (StringIO) gets print(), like the reference
         step = 1 << 20
         for first in range(0, single['n'], step):
             m = min(step, single['n'] - first)
             newq = out[first:first + m].cpu().numpy()
-            print(text.format(single['first'] + first, m, newq).decode('latin-1'), end='')
+            rendered = text.format_array(single['first'] + first, m, newq)
+            if raw is not None:
+                sys.stdout.flush()
+                raw.write(memoryview(rendered))
+            else:
+                print(rendered.tobytes().decode('latin-1'), end='')
         sys.stdout.flush()
     parallel.in_rank_order(emit)
 

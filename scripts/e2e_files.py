@@ -23,11 +23,13 @@ write(fa, seq); write(fb, cseq)
 bases = n * 150
 dev.context()
 for rep in range(2):
+    ta = time.perf_counter(); A_, B_ = fastx.NativeFastq(fa), fastx.NativeFastq(fb); tb = time.perf_counter(); sc = A_.scan(B_, False); tc = time.perf_counter()
+    print('  open+index %.3fs  scan %.3fs' % (tb - ta, tc - tb)); del A_, B_
     t0 = time.perf_counter(); packed = fastx.pack_pair(fa, fb, False); t1 = time.perf_counter()
     b = dev.ReadBatch.from_host(packed['seq'], packed['qual'], packed['meta'], cseq=packed['cseq']); torch.cuda.synchronize(); t2 = time.perf_counter()
     t = dev.Tables(1, 300); dev.accumulate(b, t); lut, shape, _, _ = dev.solve(t); out = dev.apply(b, lut, shape); torch.cuda.synchronize(); t3 = time.perf_counter()
     newq = out[:n].cpu().numpy(); t4 = time.perf_counter()
-    txt = packed['text'].format(0, n, newq); t5 = time.perf_counter()
+    txt = packed['text'].format_array(0, n, newq); t5 = time.perf_counter()
     print('rep %d: pack %.3fs (%.2f Gbases/s)  H2D %.3fs  kernels+solve %.3fs  D2H %.3fs  format %.3fs (%.1f MB)  total %.3fs = %.2f Gbases/s'
           % (rep, t1 - t0, bases / (t1 - t0) / 1e9, t2 - t1, t3 - t2, t4 - t3, t5 - t4, len(txt) / 1e6, t5 - t0, bases / (t5 - t0) / 1e9), flush=True)
 buf = io.StringIO()
@@ -37,4 +39,16 @@ with contextlib.redirect_stdout(buf):
 t1 = time.perf_counter()
 print('recalibrate_fastq() end to end incl. print into StringIO: %.3fs = %.2f Gbases/s; output %d chars, sha %s'
       % (t1 - t0, bases / (t1 - t0) / 1e9, len(buf.getvalue()), O.sha256(buf.getvalue())[:12]))
+# through a binary stdout (a file): the writer's bytes go out without a decode
+outp = os.path.join(a.dir, 'e2e_out.fq')
+sys.stdout.flush()
+saved = os.dup(1); fd = os.open(outp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC); os.dup2(fd, 1)
+t0 = time.perf_counter()
+recalibrate.recalibrate_fastq([fa, fb])
+sys.stdout.flush()
+t1 = time.perf_counter()
+os.dup2(saved, 1); os.close(fd); os.close(saved)
+print('recalibrate_fastq() end to end into a file: %.3fs = %.2f Gbases/s; %d bytes, sha %s'
+      % (t1 - t0, bases / (t1 - t0) / 1e9, os.path.getsize(outp), O.sha256(open(outp, 'rb').read())[:12]))
+os.remove(outp)
 os.remove(fa); os.remove(fb)
