@@ -98,6 +98,13 @@ def main():
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         layout = 'mate-pair rows, pitch %d per pair' % batch.pitch
+    if R > 1:
+        # many read groups: rows ordered by read group (set up once, like the layout above), so that every K1 / K2
+        # slice walks only its own rows
+        batch = dev.group_by_rg(batch, R)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        layout += ', rows grouped by read group'
     out = torch.empty_like(batch.qual)
     tables = dev.Tables(R, 2 * S)
     ctx = dev.context()

@@ -267,6 +267,21 @@ int    kbbq_apply_pairs_dev(kbbq_ctx* ctx, const uint8_t* d_pseq, const uint8_t*
                             int64_t npairs, int R, int S2, int minscore, const void* d_lut_blob,
                             const void* d_pair_lut, uint8_t* d_pout);
 
+/* ---- rows grouped by read group -----------------------------------------------------------
+ * With many read groups each K1 workgroup (its LDS tables hold ONE group) used to scan every row and keep
+ * its own, and K2's table-driven LUT outgrew the LDS.  If the caller orders the rows by read group
+ * (stable: any order within a group gives the same counts) and passes d_seg[R + 1] -- group g owns rows
+ * [d_seg[g], d_seg[g + 1]) -- every slice walks only its rows with all lanes busy and stages only its
+ * group's LUT rows: any number of read groups runs at the single-group rate.  `pairs` selects mate-pair
+ * rows (then pitch must be kbbq_pair_pitch(S2) and d_pair_lut comes from kbbq_pair_lut_dev; NULL otherwise).
+ * The fast apply LUT must be range-safe (blob flags 0); rows it cannot serve are reported (KBBQ_E_LUT).  */
+int    kbbq_accumulate_grouped_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
+                                   const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2,
+                                   int minscore, int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables);
+int    kbbq_apply_grouped_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta,
+                              int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
+                              const void* d_lut_blob, const void* d_pair_lut, const int64_t* d_seg, uint8_t* d_out);
+
 /* ---- host FASTQ ingest / egress (no GPU) ----------------------------------
  * Replaces, for this path, pysam.FastxFile iteration (recalibrate.py:56-57,141-142),
  * the name parsing of compare_reads.py:304-318 / recalibrate.py:59-64 and the print()

@@ -315,7 +315,7 @@ int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_c
         q.nrows = KQ + 1 - minscore;
         q.row_bytes = (u32)((3 * S) | 1) * 4u;
         q.slack_bytes = (u32)(S + 32) * 4u;              // x <= 4S + 12 for the padding of the shortest read
-        q.maxlen = S; q.gap = 0;
+        q.maxlen = S; q.gap = 0; q.seg = nullptr;
         q.tables = reinterpret_cast<u64*>(d_tables); q.status = c->d_status;
         q.dn_flush_iters = std::max(1, 65535 / ((K1V3_THREADS / K1V3_DNREP) * 16 * q.cpr));
         const size_t lds3 = (size_t)q.nrows * 128 * K1V3_DNREP + (size_t)q.nrows * q.row_bytes + q.slack_bytes;
@@ -461,7 +461,7 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
         q.full = reinterpret_cast<const int8_t*>(d_lut) + lut_full_offset(R, Qt, S2);
         q.full_bytes = (int)full_bytes;
         q.rb = (u32)full_lut_row_bytes(S2); q.W = (u32)full_lut_width(S2); q.ctx_off = 2u * q.W;
-        q.maxlen = S2; q.pairs = 0;
+        q.maxlen = S2; q.pairs = 0; q.seg = nullptr;
         q.out = d_out; q.status = c->d_status;
 #ifdef K2V3_PER_CU
         int per_cu = K2V3_PER_CU;
@@ -672,38 +672,38 @@ int kbbq_unpack_pairs_dev(kbbq_ctx* c, const uint8_t* d_pplane, int64_t npairs, 
     return KBBQ_OK;
 }
 
-int kbbq_accumulate_pairs_dev(kbbq_ctx* c, const uint8_t* d_pseq, const uint8_t* d_pcseq, const uint8_t* d_pqual,
-                              const uint32_t* d_pmeta, int64_t npairs, int R, int S2, int minscore,
-                              int dinuc_minscore, int64_t* d_tables)
+// K1 (table-driven kernel) on one-read-per-row or mate-pair rows, optionally grouped by read group
+static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
+                           const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
+                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables)
 {
-    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
-    int rc = check_pairs("kbbq_accumulate_pairs_dev", npairs, S2);
+    int rc = check_planes(who, nrows, pitch, d_seq, d_cseq, d_qual);
     if (rc) return rc;
-    const int pitch = pair_pitch(S2);
-    rc = check_planes("kbbq_accumulate_pairs_dev", npairs, pitch, d_pseq, d_pcseq, d_pqual);
-    if (rc) return rc;
-    if (R <= 0 || R > 32767) return fail(KBBQ_E_ARG, "kbbq_accumulate_pairs_dev: R out of range (%d)", R);
-    if (minscore < 0 || minscore > KQ - 1) return fail(KBBQ_E_ARG, "kbbq_accumulate_pairs_dev: minscore out of range (%d)", minscore);
-    if (dinuc_minscore < 0 || dinuc_minscore > 222) return fail(KBBQ_E_ARG, "kbbq_accumulate_pairs_dev: dinuc_minscore out of range (%d)", dinuc_minscore);
-    if (npairs == 0) return KBBQ_OK;
+    if (R <= 0 || R > 32767) return fail(KBBQ_E_ARG, "%s: R out of range (%d)", who, R);
+    if (S2 <= 0 || (S2 & 1) || S2 > 65534) return fail(KBBQ_E_ARG, "%s: S2 must be positive and even (%d)", who, S2);
+    if (minscore < 0 || minscore > KQ - 1) return fail(KBBQ_E_ARG, "%s: minscore out of range (%d)", who, minscore);
+    if (dinuc_minscore < 0 || dinuc_minscore > 222) return fail(KBBQ_E_ARG, "%s: dinuc_minscore out of range (%d)", who, dinuc_minscore);
+    if (pairs && pitch != pair_pitch(S2)) return fail(KBBQ_E_ARG, "%s: mate-pair rows of %d-base reads have pitch %d, not %d", who, S2 / 2, pair_pitch(S2), pitch);
+    if (nrows == 0) return KBBQ_OK;
     HIPCHK(hipSetDevice(c->device));
     const int S = S2 / 2;
     K1v3Params q;
-    q.seq = d_pseq; q.cseq = d_pcseq; q.qual = d_pqual; q.meta = d_pmeta;
-    q.nreads = npairs; q.pitch = pitch; q.cpr = pitch / 16; q.cpr_magic = magic_for(q.cpr);
+    q.seq = d_seq; q.cseq = d_cseq; q.qual = d_qual; q.meta = d_meta;
+    q.nreads = nrows; q.pitch = pitch; q.cpr = pitch / 16; q.cpr_magic = magic_for(q.cpr);
     q.R = R; q.S = S; q.minscore = minscore; q.type_minscore = dinuc_minscore;
     q.qlo_m1 = 32u + (u32)minscore; q.dlo = 33u + (u32)dinuc_minscore;
     q.nrows = KQ + 1 - minscore;
     q.row_bytes = (u32)((3 * S) | 1) * 4u;
     q.slack_bytes = (u32)(S + 32) * 4u;
-    q.maxlen = S2 + 1; q.gap = 1;
+    q.maxlen = pairs ? S2 + 1 : S; q.gap = pairs ? 1 : 0;
+    q.seg = reinterpret_cast<const long long*>(d_seg);
     q.tables = reinterpret_cast<u64*>(d_tables); q.status = c->d_status;
     q.dn_flush_iters = std::max(1, 65535 / ((K1V3_THREADS / K1V3_DNREP) * 16 * q.cpr));
     const size_t lds3 = (size_t)q.nrows * 128 * K1V3_DNREP + (size_t)q.nrows * q.row_bytes + q.slack_bytes;
     if (lds3 > (size_t)c->lds_bytes)
-        return fail(KBBQ_E_LUT, "kbbq_accumulate_pairs_dev: %d-base reads with minscore %d do not fit the LDS tables; use one read per row", S, minscore);
+        return fail(KBBQ_E_LUT, "%s: %d-base reads with minscore %d do not fit the LDS tables; use plain one-read-per-row planes", who, S, minscore);
     const bool split = dinuc_minscore > minscore;
-    const int64_t nblocks = (npairs + 63) / 64;
+    const int64_t nblocks = (nrows + 63) / 64;
     const int64_t iters = (nblocks + (K1V3_THREADS / 64) - 1) / (K1V3_THREADS / 64);
     int gx = (int)std::min<int64_t>(iters, std::max(1, c->cus / R));
     dim3 grid((unsigned)gx, (unsigned)R, 1), block(K1V3_THREADS, 1, 1);
@@ -714,6 +714,27 @@ int kbbq_accumulate_pairs_dev(kbbq_ctx* c, const uint8_t* d_pseq, const uint8_t*
     }
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
+}
+
+int kbbq_accumulate_pairs_dev(kbbq_ctx* c, const uint8_t* d_pseq, const uint8_t* d_pcseq, const uint8_t* d_pqual,
+                              const uint32_t* d_pmeta, int64_t npairs, int R, int S2, int minscore,
+                              int dinuc_minscore, int64_t* d_tables)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    int rc = check_pairs("kbbq_accumulate_pairs_dev", npairs, S2);
+    if (rc) return rc;
+    return accumulate_rows(c, "kbbq_accumulate_pairs_dev", d_pseq, d_pcseq, d_pqual, d_pmeta, npairs, pair_pitch(S2), 1,
+                           R, S2, minscore, dinuc_minscore, nullptr, d_tables);
+}
+
+int kbbq_accumulate_grouped_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
+                                const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
+                                int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (!d_seg) return fail(KBBQ_E_ARG, "kbbq_accumulate_grouped_dev: d_seg is NULL");
+    return accumulate_rows(c, "kbbq_accumulate_grouped_dev", d_seq, d_cseq, d_qual, d_meta, nrows, pitch, pairs ? 1 : 0,
+                           R, S2, minscore, dinuc_minscore, d_seg, d_tables);
 }
 
 int kbbq_pair_lut_dev(kbbq_ctx* c, const void* d_lut_blob, int R, int S2, int minscore, void* d_pair_lut)
@@ -732,6 +753,50 @@ int kbbq_pair_lut_dev(kbbq_ctx* c, const void* d_lut_blob, int R, int S2, int mi
     return KBBQ_OK;
 }
 
+// K2 (table-driven kernel) on one-read-per-row or mate-pair rows, optionally grouped by read group
+static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta,
+                      int64_t nrows, int pitch, int pairs, int R, int S2, int minscore, const void* d_lut_blob,
+                      const void* d_pair_lut, const int64_t* d_seg, uint8_t* d_out)
+{
+    int rc = check_planes(who, nrows, pitch, d_seq, d_qual, d_out);
+    if (rc) return rc;
+    if (R <= 0 || R > 32767 || !d_lut_blob || (pairs && (!d_pair_lut || ((uintptr_t)d_pair_lut & 15)))) return fail(KBBQ_E_ARG, "%s: bad argument", who);
+    if (S2 <= 0 || (S2 & 1) || S2 > 65534) return fail(KBBQ_E_ARG, "%s: S2 must be positive and even (%d)", who, S2);
+    if (minscore < 0 || minscore > 222) return fail(KBBQ_E_ARG, "%s: minscore out of range", who);
+    if (pairs && pitch != pair_pitch(S2)) return fail(KBBQ_E_ARG, "%s: mate-pair rows of %d-base reads have pitch %d, not %d", who, S2 / 2, pair_pitch(S2), pitch);
+    K2v3Params q;
+    q.rb = (u32)(pairs ? pair_lut_row_bytes(S2) : full_lut_row_bytes(S2));
+    const size_t rg_bytes = (size_t)(33 + KQ) * q.rb;
+    const size_t all_bytes = rg_bytes * (size_t)R;
+    const size_t lds = d_seg ? rg_bytes : all_bytes;
+    if (lds > (size_t)c->lds_bytes)
+        return fail(KBBQ_E_LUT, "%s: the apply LUT (%zu B) does not fit the LDS; group the rows by read group or use kbbq_apply_dev", who, lds);
+    if (nrows == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    q.seq = d_seq; q.qual = d_qual; q.meta = d_meta; q.nreads = nrows; q.pitch = pitch;
+    q.cpr = pitch / 16; q.cpr_magic = magic_for(q.cpr);
+    q.R = R; q.Qt = KQ; q.S2 = S2; q.minscore = minscore; q.qlo = 33u + (u32)minscore;
+    q.lut16 = reinterpret_cast<const int16_t*>(d_lut_blob); q.rs16 = lut_row_stride(S2);
+    q.full = pairs ? reinterpret_cast<const int8_t*>(d_pair_lut)
+                   : reinterpret_cast<const int8_t*>(d_lut_blob) + lut_full_offset(R, KQ, S2);
+    q.full_bytes = (int)all_bytes;
+    if (pairs) { q.W = 0u; q.ctx_off = (u32)pair_pitch(S2); q.maxlen = S2 + 1; }
+    else { q.W = (u32)full_lut_width(S2); q.ctx_off = 2u * q.W; q.maxlen = S2; }
+    q.pairs = pairs; q.seg = reinterpret_cast<const long long*>(d_seg);
+    q.out = d_out; q.status = c->d_status;
+    int per_cu = std::max(1, std::min<int>((int)(c->lds_bytes / lds), (K2V3_WAVES * 4 * 64) / K2V3_THREADS));
+    const int64_t nblocks = (nrows + 63) / 64;
+    const int64_t want = (nblocks + (K2V3_THREADS / 64) - 1) / (K2V3_THREADS / 64);
+    const int slices = d_seg ? R : 1;
+    int gx = (int)std::min<int64_t>(want, std::max<int64_t>(1, (int64_t)c->cus * per_cu / slices));
+    {
+        Timed t(c, 1);
+        hipLaunchKernelGGL(k2v3_apply, dim3((unsigned)std::max(gx, 1), (unsigned)slices, 1), dim3(K2V3_THREADS), lds, c->stream, q);
+    }
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
 int kbbq_apply_pairs_dev(kbbq_ctx* c, const uint8_t* d_pseq, const uint8_t* d_pqual, const uint32_t* d_pmeta,
                          int64_t npairs, int R, int S2, int minscore, const void* d_lut_blob, const void* d_pair_lut,
                          uint8_t* d_pout)
@@ -739,34 +804,18 @@ int kbbq_apply_pairs_dev(kbbq_ctx* c, const uint8_t* d_pseq, const uint8_t* d_pq
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
     int rc = check_pairs("kbbq_apply_pairs_dev", npairs, S2);
     if (rc) return rc;
-    const int pitch = pair_pitch(S2);
-    rc = check_planes("kbbq_apply_pairs_dev", npairs, pitch, d_pseq, d_pqual, d_pout);
-    if (rc) return rc;
-    if (R <= 0 || R > 32767 || !d_lut_blob || !d_pair_lut || ((uintptr_t)d_pair_lut & 15)) return fail(KBBQ_E_ARG, "kbbq_apply_pairs_dev: bad argument");
-    if (minscore < 0 || minscore > 222) return fail(KBBQ_E_ARG, "kbbq_apply_pairs_dev: minscore out of range");
-    const size_t bytes = kbbq_pair_lut_bytes(R, KQ, S2);
-    if (bytes > (size_t)c->lds_bytes) return fail(KBBQ_E_LUT, "kbbq_apply_pairs_dev: the pair LUT (%zu B) does not fit the LDS; use one read per row", bytes);
-    if (npairs == 0) return KBBQ_OK;
-    HIPCHK(hipSetDevice(c->device));
-    K2v3Params q;
-    q.seq = d_pseq; q.qual = d_pqual; q.meta = d_pmeta; q.nreads = npairs; q.pitch = pitch;
-    q.cpr = pitch / 16; q.cpr_magic = magic_for(q.cpr);
-    q.R = R; q.Qt = KQ; q.S2 = S2; q.minscore = minscore; q.qlo = 33u + (u32)minscore;
-    q.lut16 = reinterpret_cast<const int16_t*>(d_lut_blob); q.rs16 = lut_row_stride(S2);
-    q.full = reinterpret_cast<const int8_t*>(d_pair_lut); q.full_bytes = (int)bytes;
-    q.rb = (u32)pair_lut_row_bytes(S2); q.W = 0u; q.ctx_off = (u32)pair_pitch(S2);
-    q.maxlen = S2 + 1; q.pairs = 1;
-    q.out = d_pout; q.status = c->d_status;
-    int per_cu = std::max(1, std::min<int>((int)(c->lds_bytes / bytes), (K2V3_WAVES * 4 * 64) / K2V3_THREADS));
-    const int64_t nblocks = (npairs + 63) / 64;
-    const int64_t want = (nblocks + (K2V3_THREADS / 64) - 1) / (K2V3_THREADS / 64);
-    int gx = (int)std::min<int64_t>(want, (int64_t)c->cus * per_cu);
-    {
-        Timed t(c, 1);
-        hipLaunchKernelGGL(k2v3_apply, dim3((unsigned)std::max(gx, 1)), dim3(K2V3_THREADS), bytes, c->stream, q);
-    }
-    HIPCHK(hipGetLastError());
-    return KBBQ_OK;
+    return apply_rows(c, "kbbq_apply_pairs_dev", d_pseq, d_pqual, d_pmeta, npairs, pair_pitch(S2), 1, R, S2, minscore,
+                      d_lut_blob, d_pair_lut, nullptr, d_pout);
+}
+
+int kbbq_apply_grouped_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta,
+                           int64_t nrows, int pitch, int pairs, int R, int S2, int minscore, const void* d_lut_blob,
+                           const void* d_pair_lut, const int64_t* d_seg, uint8_t* d_out)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (!d_seg) return fail(KBBQ_E_ARG, "kbbq_apply_grouped_dev: d_seg is NULL");
+    return apply_rows(c, "kbbq_apply_grouped_dev", d_seq, d_qual, d_meta, nrows, pitch, pairs ? 1 : 0, R, S2, minscore,
+                      d_lut_blob, d_pair_lut, d_seg, d_out);
 }
 
 // ---- K4 / K5: benchmark path --------------------------------------------

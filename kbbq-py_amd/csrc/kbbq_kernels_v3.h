@@ -47,6 +47,7 @@ struct K1v3Params {
     int dn_flush_iters;         // workgroup iterations between flushes of the (16-bit packed) context table
     int maxlen;                 // longest row the tables take: S, or 2S + 1 for mate-pair rows
     int gap;                    // mate-pair rows: 1 (the separator byte between the mates), else 0
+    const long long* seg;       // rows grouped by read group: slice g owns rows [seg[g], seg[g + 1]); NULL: every slice scans all rows
     u64* tables; u64* status;
 };
 
@@ -88,7 +89,9 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block bases live in SGPRs
     const int nwaves = blockDim.x >> 6;
-    const long long nblocks = (p.nreads + 63) >> 6;
+    // rows grouped by read group: this slice's rows are contiguous (every lane useful, no compaction)
+    const long long seg_lo = p.seg ? p.seg[g] : 0ll, seg_hi = p.seg ? p.seg[g + 1] : p.nreads;
+    const long long nblocks = (seg_hi - seg_lo + 63) >> 6;
     const long long iters = (nblocks + nwaves - 1) / nwaves;
     const int S = p.S, S2 = 2 * p.S;
     const u32 row_bytes = p.row_bytes;
@@ -150,10 +153,10 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
     for (long long it = blockIdx.x; it < iters; it += gridDim.x) {
         const long long blk = it * nwaves + wave;
         if (blk < nblocks) {
-            const long long read0 = blk << 6;
+            const long long read0 = seg_lo + (blk << 6);
             const long long myread = read0 + lane;
-            const u32 m = myread < p.nreads ? p.meta[myread] : 0u;
-            const bool match = myread < p.nreads && (int)((m >> 16) & 0x7FFFu) == g && (m & 0xFFFFu) != 0u;
+            const u32 m = myread < seg_hi ? p.meta[myread] : 0u;
+            const bool match = myread < seg_hi && (int)((m >> 16) & 0x7FFFu) == g && (m & 0xFFFFu) != 0u;
             const u64 mask = __ballot(match);
             const int n = __popcll(mask);
             u32 cm = m, coff = (u32)lane;
@@ -328,24 +331,28 @@ struct K2v3Params {
     u32 ctx_off;               // offset of the context entries within a row
     int maxlen;                // longest row the LUT serves: S2 (H1: any single read), or S2 + 1 for mate-pair rows
     int pairs;                 // mate-pair rows: rows the fast path cannot serve are reported (KBBQ_E_LUT), not emulated
+    const long long* seg;      // rows grouped by read group: slice blockIdx.y stages only its group's LUT rows; NULL: all groups
     uint8_t* out; u64* status;
 };
 
 __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2V3_WAVES, 8))) void k2v3_apply(K2v3Params p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const u32 rb = p.rb;
+    const u32 rg_bytes = (u32)(33 + p.Qt) * rb;
+    const int g = blockIdx.y;                                   // grouped rows: the read group of this slice
     {
-        const u32* src = reinterpret_cast<const u32*>(p.full);
-        const int nw = p.full_bytes >> 2;
+        // grouped: only the rows of this slice's read group are staged (any number of groups at the LDS cost of one)
+        const u32* src = reinterpret_cast<const u32*>(p.full + (p.seg ? (size_t)g * rg_bytes : 0));
+        const int nw = (int)((p.seg ? rg_bytes : (u32)p.full_bytes) >> 2);
         for (int i = threadIdx.x; i < nw; i += blockDim.x) lds[i] = src[i];
         __syncthreads();
     }
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = blockDim.x >> 6;
-    const long long nblocks = (p.nreads + 63) >> 6;
-    const u32 rb = p.rb;
-    const u32 rg_bytes = (u32)(33 + p.Qt) * rb;
+    const long long seg_lo = p.seg ? p.seg[g] : 0ll, seg_hi = p.seg ? p.seg[g + 1] : p.nreads;
+    const long long nblocks = (seg_hi - seg_lo + 63) >> 6;
     const u32 hi_add = (u32)(0x80 - (p.Qt + 33)) * 0x01010101u;   // byte >= Qt+33 <=> bit 7 after the add
     const int lane_k0 = p.cpr == 1 ? lane : (int)__umulhi((u32)lane, p.cpr_magic);
     const int lane_j0 = lane - lane_k0 * p.cpr;
@@ -354,10 +361,10 @@ __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2
 
     for (long long blk = (long long)blockIdx.x * nwaves + wave; blk < nblocks;
          blk += (long long)gridDim.x * nwaves) {
-        const long long read0 = blk << 6;
+        const long long read0 = seg_lo + (blk << 6);
         const long long myread = read0 + lane;
-        const u32 m = myread < p.nreads ? p.meta[myread] : 0u;
-        const int n = (int)((p.nreads - read0) < 64 ? (p.nreads - read0) : 64);
+        const u32 m = myread < seg_hi ? p.meta[myread] : 0u;
+        const int n = (int)((seg_hi - read0) < 64 ? (seg_hi - read0) : 64);
         const int total = n * p.cpr;
         const uint8_t* bseq = p.seq + (size_t)read0 * p.pitch;
         const uint8_t* bqual = p.qual + (size_t)read0 * p.pitch;
@@ -429,8 +436,8 @@ __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2
                         d5[wd] = __builtin_amdgcn_alignbyte(code5[wd], pc5, 3) + code[wd];   // 5*prev + cur per byte
                         pc5 = code5[wd];
                     }
-                    const bool trouble = hiq != 0u || rg >= p.R || len > p.maxlen;
-                    if (trouble && p.pairs) {
+                    const bool trouble = hiq != 0u || rg >= p.R || len > p.maxlen || (p.seg && rg != g);
+                    if (trouble && (p.pairs || (p.seg && rg != g))) {
                         flag(p.status, ST_LUT, 0);                       // the caller re-runs on one-read-per-row planes
                     } else if (trouble) {
                         const uint4 e = chunk_apply_exact(p.lut16, p.rs16, p.R, p.Qt, p.S2, p.qlo, rg, second, pos0, nb,
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2
                                                           p.status, read);
                         o[0] = e.x; o[1] = e.y; o[2] = e.z; o[3] = e.w;
                     } else {
-                        const u32 rgb = (u32)rg * rg_bytes;
+                        const u32 rgb = p.seg ? 0u : (u32)rg * rg_bytes;
                         const u32 A = rgb + (second ? p.W : 0u) + (u32)pos0;
                         const u32 C = rgb + p.ctx_off;
 #pragma unroll

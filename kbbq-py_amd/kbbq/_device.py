@@ -181,12 +181,58 @@ class PairBatch:
         return out
 
 
+def group_by_rg(batch, R):
+    """The same rows ordered by read group (stable), with `seg` (int64 [R + 1] on the device: group g owns rows
+    [seg[g], seg[g + 1])) and `perm` (row i of the result is row perm[i] of `batch`).  accumulate() / apply()
+    then run every group at the single-group rate (include/kbbq_hip.h "rows grouped by read group");
+    ungroup() puts an output plane back into the original order.  Works on ReadBatch and PairBatch."""
+    import copy
+    torch = _torch()
+    n = batch.n
+    rg = (batch.meta[:n] >> 16) & 0x7FFF
+    if n and int(rg.max().item()) >= R:
+        raise ValueError('a row carries read group %d but R = %d' % (int(rg.max().item()), R))
+    perm = torch.argsort(rg, stable=True)
+    seg = torch.zeros(R + 1, dtype=torch.int64, device=batch.meta.device)
+    seg[1:] = torch.cumsum(torch.bincount(rg, minlength=R), 0)
+    g = copy.copy(batch)
+    for name in ('seq', 'cseq', 'qual'):
+        plane = getattr(batch, name)
+        if plane is not None:
+            setattr(g, name, plane[:n].index_select(0, perm).contiguous() if n else plane)
+    g.meta = batch.meta[:n].index_select(0, perm).contiguous() if n else batch.meta
+    g.seg, g.perm = seg, perm
+    return g
+
+
+def ungroup(batch, plane):
+    """An output plane of a grouped batch, rows back in the order before group_by_rg."""
+    torch = _torch()
+    n = batch.n
+    out = torch.empty_like(plane[:max(n, 1)])
+    if n:
+        out.index_copy_(0, batch.perm, plane[:n])
+    return out
+
+
 _pair_luts = {}
 
 
 def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None):
     """K1 over a device batch, adding into `tables` (recalibrate.py:57-119)."""
     ctx = context(batch.seq.device.index)
+    if getattr(batch, 'seg', None) is not None:
+        pairs = isinstance(batch, PairBatch)
+        if pairs and tables.S2 != 2 * batch.S:
+            raise ValueError('mate-pair rows of %d-base reads need tables with 2S = %d columns' % (batch.S, 2 * batch.S))
+        N.check(N.load().kbbq_accumulate_grouped_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual),
+                                                     N.ptr(batch.meta), batch.n, batch.pitch, 1 if pairs else 0,
+                                                     tables.R, tables.S2, minscore,
+                                                     minscore if dinuc_minscore is None else dinuc_minscore,
+                                                     N.ptr(batch.seg), N.ptr(tables.buf)))
+        if check:
+            ctx.status()
+        return
     if isinstance(batch, PairBatch):
         if tables.S2 != 2 * batch.S:
             raise ValueError('mate-pair rows of %d-base reads need tables with 2S = %d columns' % (batch.S, 2 * batch.S))
@@ -233,20 +279,30 @@ def apply(batch, lut_dev, shape, out=None, minscore=MINSCORE, check=True):
     ctx = context(batch.seq.device.index)
     if out is None:
         out = torch.empty_like(batch.qual)
-    if isinstance(batch, PairBatch):
-        # pair rows use their own layout of the table-driven LUT, derived on the device from the blob; rows it
-        # cannot serve (and a LUT that is not range-safe) surface as LutNeedsCheckedApply: unpack and re-run
-        if Qt != NQ or S2 != 2 * batch.S or mode != N.APPLY_FAST:
-            raise N.LutNeedsCheckedApply('mate-pair rows need the fast LUT of a %d-column model' % (2 * batch.S))
+    pairs = isinstance(batch, PairBatch)
+    grouped = getattr(batch, 'seg', None) is not None
+    if pairs or grouped:
+        # pair rows use their own layout of the table-driven LUT, derived on the device from the blob; rows the
+        # fast kernel cannot serve (and a LUT that is not range-safe) surface as LutNeedsCheckedApply: re-run on
+        # plain one-read-per-row planes
+        if Qt != NQ or mode != N.APPLY_FAST or (pairs and S2 != 2 * batch.S):
+            raise N.LutNeedsCheckedApply('this layout needs the fast LUT of a %d-column model' % S2)
         lib = N.load()
-        key = (batch.seq.device.index, R, S2)
-        plut = _pair_luts.get(key)
-        if plut is None:
-            plut = torch.empty(lib.kbbq_pair_lut_bytes(R, NQ, S2), dtype=torch.uint8, device=batch.seq.device)
-            _pair_luts[key] = plut
-        N.check(lib.kbbq_pair_lut_dev(ctx.handle, N.ptr(lut_dev), R, S2, minscore, N.ptr(plut)))
-        N.check(lib.kbbq_apply_pairs_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.qual), N.ptr(batch.meta), batch.n,
-                                         R, S2, minscore, N.ptr(lut_dev), N.ptr(plut), N.ptr(out)))
+        plut = None
+        if pairs:
+            key = (batch.seq.device.index, R, S2)
+            plut = _pair_luts.get(key)
+            if plut is None:
+                plut = torch.empty(lib.kbbq_pair_lut_bytes(R, NQ, S2), dtype=torch.uint8, device=batch.seq.device)
+                _pair_luts[key] = plut
+            N.check(lib.kbbq_pair_lut_dev(ctx.handle, N.ptr(lut_dev), R, S2, minscore, N.ptr(plut)))
+        if grouped:
+            N.check(lib.kbbq_apply_grouped_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.qual), N.ptr(batch.meta), batch.n,
+                                               batch.pitch, 1 if pairs else 0, R, S2, minscore, N.ptr(lut_dev),
+                                               N.ptr(plut), N.ptr(batch.seg), N.ptr(out)))
+        else:
+            N.check(lib.kbbq_apply_pairs_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.qual), N.ptr(batch.meta), batch.n,
+                                             R, S2, minscore, N.ptr(lut_dev), N.ptr(plut), N.ptr(out)))
         if check:
             ctx.status()
         return out

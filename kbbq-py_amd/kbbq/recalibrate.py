@@ -56,14 +56,21 @@ def _tally_local(packed, minscore, maxscore):
     batch = dev.ReadBatch.from_host(packed['seq'][:n], packed['qual'][:n], packed['meta'][:n],
                                     cseq=packed['cseq'][:n])
     packed['batch'] = batch                  # still resident: pass 2 re-uses it when it covers file A
-    if dev.PairBatch.worthwhile(S, batch.pitch):
+    # device layouts that move fewer bytes / keep every lane busy: mate-pair rows for uniform
+    # pairs, rows grouped by read group when there are several.  `packed['pairs']` names the laid-out batch.
+    try:
+        laid = dev.PairBatch.from_reads(batch) if dev.PairBatch.worthwhile(S, batch.pitch) else None
+    except ValueError:
+        laid = None                          # not uniform first/second pairs
+    if R > 1:
+        laid = dev.group_by_rg(laid if laid is not None else batch, R)
+    if laid is not None:
         try:
-            pairs = dev.PairBatch.from_reads(batch)
-            dev.accumulate(pairs, tables, minscore)
-            packed['pairs'] = pairs
+            dev.accumulate(laid, tables, minscore)
+            packed['pairs'] = laid
             return tables
-        except (ValueError, IndexError, TypeError, dev.N.LutNeedsCheckedApply):
-            tables.buf.zero_()               # not uniform pairs, or bad input: the row-per-read kernel decides
+        except (IndexError, TypeError, dev.N.LutNeedsCheckedApply):
+            tables.buf.zero_()               # bad input or an unsupported shape: the row-per-read kernel decides
     dev.accumulate(batch, tables, minscore)
     return tables
 
@@ -194,7 +201,11 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
         out = None
         if pairs is not None:
             try:
-                out = pairs.unpack(dev.apply(pairs, lut, shape))
+                out = dev.apply(pairs, lut, shape)
+                if getattr(pairs, 'seg', None) is not None:
+                    out = dev.ungroup(pairs, out)
+                if isinstance(pairs, dev.PairBatch):
+                    out = pairs.unpack(out)
             except dev.N.LutNeedsCheckedApply:
                 out = None                   # a LUT the fast kernel cannot serve: the checked row-per-read kernel
         if out is None and batch is not None:

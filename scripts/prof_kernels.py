@@ -22,6 +22,8 @@ from kbbq import _device as dev
 b = dev.ReadBatch.synthetic(0, args.reads, args.reads, seed=1, nrg=args.rgs, len_lo=args.len, len_hi=args.len)
 if args.pairs:
     b = dev.PairBatch.from_reads(b)
+if args.rgs > 1:
+    b = dev.group_by_rg(b, args.rgs)
 out = torch.empty_like(b.qual)
 t = dev.Tables(args.rgs, 2 * args.len)
 for _ in range(args.reps):

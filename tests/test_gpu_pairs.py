@@ -128,12 +128,19 @@ def test_product_fastq_path_takes_pair_rows_when_it_can(dev, oracle, tmp_path):
     from conftest import load_golden
     from kbbq import recalibrate
     from test_gpu_parity import VEC, _files
-    for name, expect_pairs in (('c1_10k_1rg', True), ('c3cut_2k_8rg', True), ('c5cut_2k_mixed', False)):
+    # c5cut: ragged lengths up to 300 bases (no pairs) and too long for the LDS tables of the table-driven K1:
+    # the first-generation kernel on plain rows takes over
+    for name, expect in (('c1_10k_1rg', ('pairs', False)), ('c3cut_2k_8rg', ('pairs', True)),
+                         ('c5cut_2k_mixed', None), ('q42_500_3rg', ('pairs', True))):
         info, gold = load_golden(name)
         d = tmp_path / name; d.mkdir()
         fa, fb = _files(oracle, info, d)
         packed, tables = recalibrate._pack_and_tally([fa, fb], info['case']['infer_rg'], 6, 42)
-        assert (packed['pairs'] is not None) == expect_pairs, name
+        laid = packed['pairs']
+        if expect is None:
+            assert laid is None, name
+        else:
+            assert isinstance(laid, dev.PairBatch) and (getattr(laid, 'seg', None) is not None) == expect[1], name
         got = recalibrate._vectors_from_tables(*tables.to_host(), 42)
         for k, v in zip(VEC, got):
             assert np.array_equal(v, gold[k]), (name, k)
@@ -179,3 +186,33 @@ def test_two_ranks_agree_on_the_first_error(dev, oracle, tmp_path):
     r = _run_ranks(2, ['recalibrate', '-f', fa, fb], timeout=200)
     assert r.returncode != 0 and r.stdout == b''
     assert r.stderr.decode().count('IndexError') >= 2
+
+
+@pytest.mark.parametrize('S,nrg,pairs', [(150, 8, False), (150, 8, True), (100, 3, True), (150, 1, True), (60, 16, False),
+                                         (150, 40, True)])
+def test_rows_grouped_by_read_group(dev, oracle, S, nrg, pairs):
+    """Rows ordered by read group + segment table: same tables, same qualities (after ungroup) as the plain path."""
+    import torch
+    n = 20000
+    b = dev.ReadBatch.synthetic(0, n, n, seed=11 + nrg, len_lo=S, len_hi=S, nrg=nrg)
+    t0 = dev.Tables(nrg, 2 * S); dev.accumulate(b, t0)
+    lut, shape, _, _ = dev.solve(t0)
+    want = dev.apply(b, lut, shape)
+    src = dev.PairBatch.from_reads(b) if pairs else b
+    g = dev.group_by_rg(src, nrg)
+    seg = g.seg.cpu().numpy()
+    assert seg[0] == 0 and seg[-1] == src.n and (np.diff(seg) >= 0).all()
+    rg = ((g.meta[:g.n].cpu().numpy().view(np.uint32) >> 16) & 0x7FFF)
+    assert (np.diff(rg.astype(np.int64)) >= 0).all()
+    t1 = dev.Tables(nrg, 2 * S); dev.accumulate(g, t1)
+    assert torch.equal(t0.buf, t1.buf)
+    out = dev.ungroup(g, dev.apply(g, lut, shape))
+    if pairs:
+        out = src.unpack(out)
+    assert torch.equal(out[:n], want[:n])
+    # a row outside its group's segment is reported, never silently mis-scored
+    if nrg > 1 and not pairs:
+        g.meta[0] = g.meta[0] ^ (1 << 16)
+        from kbbq import _native as N
+        with pytest.raises(N.LutNeedsCheckedApply):
+            dev.apply(g, lut, shape)
