@@ -287,6 +287,10 @@ int kbbq_accumulate_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq
                                   minscore, minscore, d_tables);
 }
 
+static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
+                           const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
+                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits);
+
 int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq,
                            const uint8_t* d_qual, const uint32_t* d_meta,
                            int64_t nreads, int pitch, int R, int S2, int minscore,
@@ -303,35 +307,13 @@ int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_c
     HIPCHK(hipSetDevice(c->device));
 
     const int64_t nblocks = (nreads + 63) / 64;
-    const int S = S2 / 2;
     const bool split = dinuc_minscore > minscore;
     const char* force = getenv("KBBQ_K1");              // "v1" forces the first kernel (A/B timing)
-    {
-        K1v3Params q;
-        q.seq = d_seq; q.cseq = d_cseq; q.qual = d_qual; q.meta = d_meta;
-        q.nreads = nreads; q.pitch = pitch; q.cpr = pitch / 16; q.cpr_magic = magic_for(q.cpr);
-        q.R = R; q.S = S; q.minscore = minscore; q.type_minscore = dinuc_minscore;
-        q.qlo_m1 = 32u + (u32)minscore; q.dlo = 33u + (u32)dinuc_minscore;
-        q.nrows = KQ + 1 - minscore;
-        q.row_bytes = (u32)((3 * S) | 1) * 4u;
-        q.slack_bytes = (u32)(S + 32) * 4u;              // x <= 4S + 12 for the padding of the shortest read
-        q.maxlen = S; q.gap = 0; q.seg = nullptr;
-        q.tables = reinterpret_cast<u64*>(d_tables); q.status = c->d_status;
-        q.dn_flush_iters = std::max(1, 65535 / ((K1V3_THREADS / K1V3_DNREP) * 16 * q.cpr));
-        const size_t lds3 = (size_t)q.nrows * 128 * K1V3_DNREP + (size_t)q.nrows * q.row_bytes + q.slack_bytes;
-        if (lds3 <= (size_t)c->lds_bytes && !(force && !strcmp(force, "v1"))) {
-            int per_cu = std::max(1, std::min<int>((int)(c->lds_bytes / lds3), 2048 / K1V3_THREADS));
-            const int64_t iters = (nblocks + (K1V3_THREADS / 64) - 1) / (K1V3_THREADS / 64);
-            int gx = (int)std::min<int64_t>(iters, std::max(1, c->cus * per_cu / R));
-            dim3 grid((unsigned)gx, (unsigned)R, 1), block(K1V3_THREADS, 1, 1);
-            {
-                Timed t(c, 0);
-                if (split) hipLaunchKernelGGL(k1v3_accumulate<true>, grid, block, lds3, c->stream, q);
-                else hipLaunchKernelGGL(k1v3_accumulate<false>, grid, block, lds3, c->stream, q);
-            }
-            HIPCHK(hipGetLastError());
-            return KBBQ_OK;
-        }
+    if (!(force && !strcmp(force, "v1"))) {
+        bool fits = false;
+        rc = accumulate_rows(c, "kbbq_accumulate_dev", d_seq, d_cseq, d_qual, d_meta, nreads, pitch, 0, R, S2, minscore,
+                             dinuc_minscore, nullptr, d_tables, &fits);
+        if (rc || fits) return rc;                      // launched (or a real error); otherwise the tables do not fit the LDS
     }
     K1Params p;
     p.seq = d_seq; p.cseq = d_cseq; p.qual = d_qual; p.meta = d_meta;
@@ -675,8 +657,9 @@ int kbbq_unpack_pairs_dev(kbbq_ctx* c, const uint8_t* d_pplane, int64_t npairs, 
 // K1 (table-driven kernel) on one-read-per-row or mate-pair rows, optionally grouped by read group
 static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                            const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
-                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables)
+                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits)
 {
+    if (fits) *fits = true;
     int rc = check_planes(who, nrows, pitch, d_seq, d_cseq, d_qual);
     if (rc) return rc;
     if (R <= 0 || R > 32767) return fail(KBBQ_E_ARG, "%s: R out of range (%d)", who, R);
@@ -700,8 +683,10 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     q.tables = reinterpret_cast<u64*>(d_tables); q.status = c->d_status;
     q.dn_flush_iters = std::max(1, 65535 / ((K1V3_THREADS / K1V3_DNREP) * 16 * q.cpr));
     const size_t lds3 = (size_t)q.nrows * 128 * K1V3_DNREP + (size_t)q.nrows * q.row_bytes + q.slack_bytes;
-    if (lds3 > (size_t)c->lds_bytes)
+    if (lds3 > (size_t)c->lds_bytes) {
+        if (fits) { *fits = false; return KBBQ_OK; }     // the caller has another kernel for this shape
         return fail(KBBQ_E_LUT, "%s: %d-base reads with minscore %d do not fit the LDS tables; use plain one-read-per-row planes", who, S, minscore);
+    }
     const bool split = dinuc_minscore > minscore;
     const int64_t nblocks = (nrows + 63) / 64;
     const int64_t iters = (nblocks + (K1V3_THREADS / 64) - 1) / (K1V3_THREADS / 64);
@@ -724,7 +709,7 @@ int kbbq_accumulate_pairs_dev(kbbq_ctx* c, const uint8_t* d_pseq, const uint8_t*
     int rc = check_pairs("kbbq_accumulate_pairs_dev", npairs, S2);
     if (rc) return rc;
     return accumulate_rows(c, "kbbq_accumulate_pairs_dev", d_pseq, d_pcseq, d_pqual, d_pmeta, npairs, pair_pitch(S2), 1,
-                           R, S2, minscore, dinuc_minscore, nullptr, d_tables);
+                           R, S2, minscore, dinuc_minscore, nullptr, d_tables, nullptr);
 }
 
 int kbbq_accumulate_grouped_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
@@ -734,7 +719,7 @@ int kbbq_accumulate_grouped_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
     if (!d_seg) return fail(KBBQ_E_ARG, "kbbq_accumulate_grouped_dev: d_seg is NULL");
     return accumulate_rows(c, "kbbq_accumulate_grouped_dev", d_seq, d_cseq, d_qual, d_meta, nrows, pitch, pairs ? 1 : 0,
-                           R, S2, minscore, dinuc_minscore, d_seg, d_tables);
+                           R, S2, minscore, dinuc_minscore, d_seg, d_tables, nullptr);
 }
 
 int kbbq_pair_lut_dev(kbbq_ctx* c, const void* d_lut_blob, int R, int S2, int minscore, void* d_pair_lut)
