@@ -216,3 +216,28 @@ def test_rows_grouped_by_read_group(dev, oracle, S, nrg, pairs):
         from kbbq import _native as N
         with pytest.raises(N.LutNeedsCheckedApply):
             dev.apply(g, lut, shape)
+
+
+def test_grouped_rows_with_empty_groups_and_tiny_batches(dev):
+    """Read groups without rows (empty segments) and batches smaller than one wave."""
+    import torch
+    S = 50
+    for n, R, keep in ((2, 1, None), (64, 6, (0, 3)), (130, 4, (1,)), (4000, 9, (2, 5, 8))):
+        b = dev.ReadBatch.synthetic(0, n, n, seed=n, len_lo=S, len_hi=S, nrg=R)
+        if keep is not None:
+            # rewrite the read groups so that only `keep` occur (pairs still share theirs)
+            meta = b.meta[:n].cpu().numpy().view(np.uint32)
+            pair = np.arange(n) >> 1
+            rg = np.array(keep, dtype=np.uint32)[pair % len(keep)]
+            b.meta[:n] = torch.from_numpy(((meta & 0x8000FFFF) | (rg << 16)).view(np.int32)).cuda()
+        t0 = dev.Tables(R, 2 * S); dev.accumulate(b, t0)
+        lut, shape, _, _ = dev.solve(t0)
+        want = dev.apply(b, lut, shape)
+        for src in (b, dev.PairBatch.from_reads(b)):
+            g = dev.group_by_rg(src, R)
+            t1 = dev.Tables(R, 2 * S); dev.accumulate(g, t1)
+            assert torch.equal(t0.buf, t1.buf), (n, R)
+            out = dev.ungroup(g, dev.apply(g, lut, shape))
+            if src is not b:
+                out = src.unpack(out)
+            assert torch.equal(out[:n], want[:n]), (n, R)
