@@ -20,6 +20,7 @@
 // layouts do not fit in LDS (very long reads, many read groups).
 #pragma once
 #include "kbbq_kernels.h"
+#include <type_traits>
 
 #define K1V3_THREADS 1024        // one workgroup per CU: the replicated context table needs ~150 KB of LDS
 #define K1V3_DNREP 16            // copies of the context-total table (copy = lane & 15)
@@ -61,6 +62,22 @@ __device__ __forceinline__ void decode4x(u32 w, u32& code, u32& code5, u32& expe
     expect = __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, h);
 }
 
+// increment of both count tables for base B of a word: errs << 16 | total = (seq byte != cseq byte) ? 0x10001 : 1.
+// One sub-dword compare on byte B of xw = seq ^ cseq and one select (the compiler's own sequence masks the
+// byte out first: three instructions).
+template <int B>
+__device__ __forceinline__ u32 k1_increment(u32 xw, u32 zero, u32 both)
+{
+    u32 inc;
+    if (B == 0)      asm("v_cmp_ne_u32_sdwa vcc, %1, %2 src0_sel:BYTE_0 src1_sel:DWORD\n\tv_cndmask_b32_e32 %0, 1, %3, vcc" : "=v"(inc) : "v"(xw), "v"(zero), "v"(both) : "vcc");
+    else if (B == 1) asm("v_cmp_ne_u32_sdwa vcc, %1, %2 src0_sel:BYTE_1 src1_sel:DWORD\n\tv_cndmask_b32_e32 %0, 1, %3, vcc" : "=v"(inc) : "v"(xw), "v"(zero), "v"(both) : "vcc");
+    else if (B == 2) asm("v_cmp_ne_u32_sdwa vcc, %1, %2 src0_sel:BYTE_2 src1_sel:DWORD\n\tv_cndmask_b32_e32 %0, 1, %3, vcc" : "=v"(inc) : "v"(xw), "v"(zero), "v"(both) : "vcc");
+    else             asm("v_cmp_ne_u32_sdwa vcc, %1, %2 src0_sel:BYTE_3 src1_sel:DWORD\n\tv_cndmask_b32_e32 %0, 1, %3, vcc" : "=v"(inc) : "v"(xw), "v"(zero), "v"(both) : "vcc");
+    return inc;
+}
+
+typedef __attribute__((address_space(3))) u32 lds_u32;
+
 struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int k; int j; int nb; };
 
 // LDS: dn [nrows][32][16] u32 context counts (errs << 16 | total), 16 copies (copy = lane & 15:
@@ -98,7 +115,8 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
     const u32 tclamp = 255u - p.qlo_m1;                                // inverted bytes >= this are uncounted
     const u32 pos_base = (u32)dn_words * 4u - 180u * row_bytes;        // 180 = 255 - 'K': inverted byte of q = 42 is row 0
     const u32 dnt_row = 128u * K1V3_DNREP;                             // bytes per row of the replicated totals
-    const u32 dnt_base = 0u - 180u * dnt_row + 4u * (u32)(lane_id() & (K1V3_DNREP - 1));
+    // LDS byte address (the low half of the flat address is the LDS offset) of this lane's copy, less the row bias
+    const u32 dnt_base = (u32)reinterpret_cast<size_t>(lds) - 180u * dnt_row + 4u * (u32)(lane_id() & (K1V3_DNREP - 1));
     int since_flush = 0, since_dn_flush = 0;
     // work item of this lane at step 0 and the per-step advances (64 / 128 items)
     const int lane_k0 = p.cpr == 1 ? lane : (int)__umulhi((u32)lane, p.cpr_magic);
@@ -243,12 +261,16 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                             pc5 = code5[wd];
                             const u32 xw = ch.s[wd] ^ ch.c[wd];
                             const u32 qn = ~ch.q[wd];
-#pragma unroll
-                            for (int b = 0; b < 4; ++b) {
+                            const u32 zero = 0u, both = 0x10001u;
+                            auto one_base = [&](auto bsel) {
+                                constexpr int b = decltype(bsel)::value;
                                 const u32 qi = (qn >> (8 * b)) & 0xFFu;                 // 255 - quality byte
                                 const u32 tq = qi < tclamp ? qi : tclamp;              // below minscore (and padding): trash row
-                                const bool err = ((xw >> (8 * b)) & 0xFFu) != 0u;      // recalibrate.py:13-20
-                                const u32 inc = err ? 0x10001u : 1u;                   // errs << 16 | total, both tables
+#ifndef KBBQ_K1_PLAIN_INC
+                                const u32 inc = k1_increment<b>(xw, zero, both);       // recalibrate.py:13-20: errs << 16 | total
+#else
+                                const u32 inc = ((xw >> (8 * b)) & 0xFFu) != 0u ? 0x10001u : 1u;
+#endif
                                 const u32 a = __umul24(tq, row_bytes) + A + (u32)(4 * (4 * wd + b));
 #ifndef KBBQ_ABL_NOPOS
                                 atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + a), inc);   // recalibrate.py:116-117
@@ -257,13 +279,17 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
 #endif
                                 u32 slot = (d5 >> (8 * b)) & 0xFFu;
                                 if (SPLIT) slot = qi <= 255u - p.dlo ? slot : 24u;             // context needs q >= its own threshold
-                                const u32 ad = slot * (4u * K1V3_DNREP) + tq * dnt_row + dnt_base;     // constant powers of two: shifts
+                                const u32 trow = tq * dnt_row + dnt_base;                      // constant powers of two: two shift-adds,
+                                const u32 ad = slot * (4u * K1V3_DNREP) + trow;                // the LDS base is inside dnt_base
 #ifndef KBBQ_ABL_NODN
-                                atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + ad), inc); // recalibrate.py:118-119
+                                __hip_atomic_fetch_add(reinterpret_cast<lds_u32*>(ad), inc, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);          // recalibrate.py:118-119
 #else
                                 asm volatile("" :: "v"(ad), "v"(inc));
 #endif
-                            }
+                            };
+                            one_base(std::integral_constant<int, 0>{}); one_base(std::integral_constant<int, 1>{});
+                            one_base(std::integral_constant<int, 2>{}); one_base(std::integral_constant<int, 3>{});
                         }
                     }
                 }
