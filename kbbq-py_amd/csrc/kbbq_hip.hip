@@ -443,7 +443,7 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
         q.full = reinterpret_cast<const int8_t*>(d_lut) + lut_full_offset(R, Qt, S2);
         q.full_bytes = (int)full_bytes;
         q.rb = (u32)full_lut_row_bytes(S2); q.W = (u32)full_lut_width(S2); q.ctx_off = 2u * q.W;
-        q.maxlen = S2; q.pairs = 0; q.seg = nullptr;
+        q.maxlen = S2; q.pairs = 0; q.seg = nullptr; q.rpb = 64;
         q.out = d_out; q.status = c->d_status;
 #ifdef K2V3_PER_CU
         int per_cu = K2V3_PER_CU;
@@ -770,10 +770,12 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
     q.pairs = pairs; q.seg = reinterpret_cast<const long long*>(d_seg);
     q.out = d_out; q.status = c->d_status;
     int per_cu = std::max(1, std::min<int>((int)(c->lds_bytes / lds), (K2V3_WAVES * 4 * 64) / K2V3_THREADS));
-    const int64_t nblocks = (nrows + 63) / 64;
+    q.rpb = 64;      // smaller wave blocks / short-lived workgroups were measured slower (profiles/r01_traversal_microbench.md)
+    const int64_t nblocks = (nrows + q.rpb - 1) / q.rpb;
     const int64_t want = (nblocks + (K2V3_THREADS / 64) - 1) / (K2V3_THREADS / 64);
     const int slices = d_seg ? R : 1;
     int gx = (int)std::min<int64_t>(want, std::max<int64_t>(1, (int64_t)c->cus * per_cu / slices));
+
     {
         Timed t(c, 1);
         hipLaunchKernelGGL(k2v3_apply, dim3((unsigned)std::max(gx, 1), (unsigned)slices, 1), dim3(K2V3_THREADS), lds, c->stream, q);

@@ -358,6 +358,7 @@ struct K2v3Params {
     int maxlen;                // longest row the LUT serves: S2 (H1: any single read), or S2 + 1 for mate-pair rows
     int pairs;                 // mate-pair rows: rows the fast path cannot serve are reported (KBBQ_E_LUT), not emulated
     const long long* seg;      // rows grouped by read group: slice blockIdx.y stages only its group's LUT rows; NULL: all groups
+    int rpb;                   // rows per wave block (<= 64): a wave's contiguous footprint is rpb * pitch bytes per plane
     uint8_t* out; u64* status;
 };
 
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = blockDim.x >> 6;
     const long long seg_lo = p.seg ? p.seg[g] : 0ll, seg_hi = p.seg ? p.seg[g + 1] : p.nreads;
-    const long long nblocks = (seg_hi - seg_lo + 63) >> 6;
+    const long long nblocks = (seg_hi - seg_lo + p.rpb - 1) / p.rpb;
     const u32 hi_add = (u32)(0x80 - (p.Qt + 33)) * 0x01010101u;   // byte >= Qt+33 <=> bit 7 after the add
     const int lane_k0 = p.cpr == 1 ? lane : (int)__umulhi((u32)lane, p.cpr_magic);
     const int lane_j0 = lane - lane_k0 * p.cpr;
@@ -387,10 +388,10 @@ __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2
 
     for (long long blk = (long long)blockIdx.x * nwaves + wave; blk < nblocks;
          blk += (long long)gridDim.x * nwaves) {
-        const long long read0 = seg_lo + (blk << 6);
+        const long long read0 = seg_lo + blk * p.rpb;
         const long long myread = read0 + lane;
-        const u32 m = myread < seg_hi ? p.meta[myread] : 0u;
-        const int n = (int)((seg_hi - read0) < 64 ? (seg_hi - read0) : 64);
+        const int n = (int)((seg_hi - read0) < p.rpb ? (seg_hi - read0) : p.rpb);
+        const u32 m = lane < n ? p.meta[myread] : 0u;
         const int total = n * p.cpr;
         const uint8_t* bseq = p.seq + (size_t)read0 * p.pitch;
         const uint8_t* bqual = p.qual + (size_t)read0 * p.pitch;
