@@ -241,3 +241,45 @@ def test_grouped_rows_with_empty_groups_and_tiny_batches(dev):
             if src is not b:
                 out = src.unpack(out)
             assert torch.equal(out[:n], want[:n]), (n, R)
+
+
+def test_randomised_layout_sweep_against_the_oracle(dev, oracle):
+    """Seeded sweep over read lengths (around the 16-byte chunk and pitch boundaries), read-group counts and
+    thresholds: every layout (rows, mate-pair rows, each grouped by read group) gives the oracle's tables and
+    qualities."""
+    import torch
+    rng = np.random.default_rng(2024)
+    lengths = [15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 100, 127, 128, 129, 150, 151, 199, 200]
+    for S in lengths:
+        nrg = int(rng.integers(1, 7))
+        minscore = int(rng.choice([6, 6, 6, 10, 15]))
+        n = int(rng.integers(300, 1500)) * 2
+        b = dev.ReadBatch.synthetic(0, n, n, seed=S, len_lo=S, len_hi=S, nrg=nrg, qlo=int(rng.integers(0, 8)), qhi=int(rng.integers(30, 43)))
+        meta = b.meta[:n].cpu().numpy().view(np.uint32)
+        host = [x.cpu().numpy() for x in (b.seq[:n], b.cseq[:n], b.qual[:n])]
+        want = oracle.accumulate(host[0], host[1], host[2], meta, nrg, S, minscore=minscore)
+        dqs = oracle.get_delta_qs(*want)
+        want_q = oracle.apply(host[0], host[2], meta, want[0], *dqs, minscore=minscore)
+        layouts = [('rows', b)]
+        if dev.PairBatch.worthwhile(S, b.pitch) or S in (16, 64, 128):
+            layouts.append(('pairs', dev.PairBatch.from_reads(b)))
+        for name, src in list(layouts):
+            layouts.append((name + '+grouped', dev.group_by_rg(src, nrg)))
+        for name, lay in layouts:
+            t = dev.Tables(nrg, 2 * S)
+            try:
+                dev.accumulate(lay, t, minscore)
+            except dev.N.LutNeedsCheckedApply:
+                assert S >= 199 and name != 'rows', (S, name)      # longer than the table-driven K1 holds: only the plain rows have a fallback
+                continue
+            for got, w in zip(t.to_host(), want[5:9]):
+                assert np.array_equal(got, w), (S, nrg, name)
+            lut, shape, _, _ = dev.solve(t, minscore=minscore)
+            out = dev.apply(lay, lut, shape, minscore=minscore)
+            if getattr(lay, 'seg', None) is not None:
+                out = dev.ungroup(lay, out)
+            if isinstance(lay, dev.PairBatch):
+                out = lay.unpack(out, b.pitch)
+            got_q = out[:n].cpu().numpy()
+            assert np.array_equal(got_q[:, :S].astype(np.int32) - 33, want_q[:, :S]), (S, nrg, name)   # the oracle returns raw qualities
+            assert not got_q[:, S:].any()
