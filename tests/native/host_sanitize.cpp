@@ -1,0 +1,64 @@
+// AddressSanitizer / UBSan harness for the host C++ of libkbbq_hip (fastq_host.cpp, solve_host.cpp):
+// g++ -fsanitize=address,undefined ... (tests/test_host_sanitizers.py).  GPU code cannot run under a
+// sanitizer on this pool; the host side can, and it is the part that parses untrusted text.
+#include "../../include/kbbq_hip.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static std::string g_err;
+int kbbq_set_error_(int code, const char* msg) { g_err = msg ? msg : ""; return code; }
+extern "C" const char* kbbq_last_error(void) { return g_err.c_str(); }
+
+static int run_pair(const char* pa, const char* pb, int infer)
+{
+    kbbq_fastq *a = nullptr, *b = nullptr;
+    int rc = kbbq_fastq_open(pa, &a);
+    if (rc) { printf("open A rc=%d (%s)\n", rc, g_err.c_str()); return 0; }
+    if (pb) { rc = kbbq_fastq_open(pb, &b); if (rc) { printf("open B rc=%d (%s)\n", rc, g_err.c_str()); kbbq_fastq_close(a); return 0; } }
+    int64_t info[5] = {0, 0, 0, 0, 0};
+    rc = kbbq_fastq_scan(a, b, infer, info);
+    printf("scan rc=%d n=%lld S=%lld R=%lld kind=%lld idx=%lld\n", rc, (long long)info[0], (long long)info[1],
+           (long long)info[2], (long long)info[3], (long long)info[4]);
+    const int64_t n = info[0];
+    const int pitch = (int)((info[1] + 15) / 16 * 16 > 0 ? (info[1] + 15) / 16 * 16 : 16);
+    std::vector<uint8_t> seq((size_t)n * pitch + 1), cseq((size_t)n * pitch + 1), qual((size_t)n * pitch + 1);
+    std::vector<uint32_t> meta((size_t)n + 1);
+    rc = kbbq_fastq_fill(a, b, infer, n, pitch, seq.data(), b ? cseq.data() : nullptr, qual.data(), meta.data());
+    printf("fill rc=%d\n", rc);
+    for (int64_t first : {(int64_t)0, n / 3}) {          // ranged fill + format of a shard
+        const int64_t m = n - first;
+        rc = kbbq_fastq_fill_range(a, b, infer, first, m, pitch, seq.data(), b ? cseq.data() : nullptr, qual.data(), meta.data());
+        const int64_t need = -kbbq_fastq_format(a, first, m, pitch, qual.data(), nullptr, 0);
+        std::vector<char> out((size_t)need + 1);
+        const int64_t got = kbbq_fastq_format(a, first, m, pitch, qual.data(), out.data(), need);
+        printf("range first=%lld rc=%d bytes=%lld/%lld\n", (long long)first, rc, (long long)got, (long long)need);
+    }
+    for (int i = 0; i < kbbq_fastq_rg_count(a); ++i) printf("rg %d = %s\n", i, kbbq_fastq_rg_name(a, i));
+    const char* nm; int nl;
+    if (kbbq_fastq_count(a) > 0 && kbbq_fastq_name(a, kbbq_fastq_count(a) - 1, &nm, &nl) == 0) printf("last name %.*s\n", nl, nm);
+    kbbq_fastq_close(a);
+    if (b) kbbq_fastq_close(b);
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) return 2;
+    if (!strcmp(argv[1], "pair")) return run_pair(argv[2], argc > 3 && strcmp(argv[3], "-") ? argv[3] : nullptr, argc > 4 ? atoi(argv[4]) : 0);
+    if (!strcmp(argv[1], "combiln")) {
+        const int64_t n = 50000;
+        std::vector<int64_t> e((size_t)n), t((size_t)n);
+        for (int64_t i = 0; i < n; ++i) { e[(size_t)i] = (i * 7919) % 1000003 - 5; t[(size_t)i] = e[(size_t)i] + (i * 104729) % 9999991 - 3; }
+        std::vector<double> out((size_t)n);
+        for (int th : {1, 3, 8, 3}) { int rc = kbbq_combiln_host(e.data(), t.data(), n, out.data(), th); printf("combiln threads=%d rc=%d %.6f\n", th, rc, out[123]); }
+        std::vector<double> x = {0.5, 1, 2, 12.5, 13, 999, 1e8, 1e300, -1, 0};
+        std::vector<double> g(x.size());
+        printf("gammaln rc=%d %.6f\n", kbbq_gammaln_host(x.data(), (int64_t)x.size(), g.data()), g[3]);
+        return 0;
+    }
+    return 2;
+}

@@ -70,7 +70,7 @@ def test_logpmf_decomposition_is_bit_identical():
 @pytest.fixture(scope='module')
 def solver(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp('native') / 'solve_check')
-    subprocess.check_call(['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-o', exe,
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-fsanitize=undefined', '-fno-sanitize-recover=undefined', '-o', exe,
                            os.path.join(ROOT, 'tests', 'native', 'solve_check.cpp')])
 
     def run(prior_q, errs, total):

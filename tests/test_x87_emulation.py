@@ -17,7 +17,7 @@ from conftest import ROOT
 def test_x87_add_matches_native_long_double(tmp_path):
     exe = str(tmp_path / 'x87_check')
     src = os.path.join(ROOT, 'tests', 'native', 'x87_check.cpp')
-    subprocess.check_call(['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-o', exe, src])
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-fsanitize=undefined', '-fno-sanitize-recover=undefined', '-o', exe, src])
     out = subprocess.run([exe, '1500000'], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.startswith('OK')
