@@ -282,6 +282,30 @@ int    kbbq_apply_grouped_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t
                               int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
                               const void* d_lut_blob, const void* d_pair_lut, const int64_t* d_seg, uint8_t* d_out);
 
+/* ---- host SAM text reader (no GPU) -----------------------------------------------------------
+ * Replaces, for the truth-set benchmark and the BAM-sourced tally, what the reference gets from
+ * pysam.AlignmentFile / AlignedSegment (benchmark.py:57-74,102-143; gatk/bqsr.py:23-123): per alignment
+ * the flag, contig, position, CIGAR, mate position, template length, sequence, qualities and the RG / OQ
+ * tags, as arrays (the kernels take whole batches).  SAM text only; mapped, indexed and parsed in parallel.
+ * kbbq_sam_info: { alignments, CIGAR operations, longest SEQ, contigs seen, @RG lines, header lines }.
+ * kbbq_sam_fields (any pointer may be NULL): flag; contig = index into the first-appearance list of RNAME;
+ * pos / pnext 0-based; tlen; qlen = len(SEQ) (0 for '*'); ref_span = reference_end - reference_start;
+ * clip = query_alignment_start | query_alignment_end << 16; cig_off / cig_n into kbbq_sam_cigar's array
+ * (length << 4 | BAM op code, unknown letter = 15); rg = index of the RG:Z tag among the header's @RG IDs
+ * (-1 no tag, -2 not in the header); has_qual_oq = len(QUAL) (0 for '*') | len(OQ:Z) << 16 (-1 << 16 when absent).
+ * kbbq_sam_fill: plane rows [0, n) <- SEQ (0) / QUAL (1) / OQ (2) of alignments [first, first + n), zero padded.
+ * kbbq_sam_text: 0 QNAME, 1 whole alignment line, 2 header line, 3 contig name, 4 @RG ID (not NUL-terminated).  */
+typedef struct kbbq_sam kbbq_sam;
+int kbbq_sam_open(const char* path, kbbq_sam** out);
+int kbbq_sam_close(kbbq_sam* f);
+int kbbq_sam_info(const kbbq_sam* f, int64_t* info6);
+int kbbq_sam_fields(const kbbq_sam* f, int32_t* flag, int32_t* contig, int64_t* pos, int64_t* pnext, int64_t* tlen,
+                    int32_t* qlen, int32_t* ref_span, uint32_t* clip, uint32_t* cig_off, uint32_t* cig_n, int32_t* rg,
+                    int32_t* has_qual_oq);
+int kbbq_sam_cigar(const kbbq_sam* f, uint32_t* ops);
+int kbbq_sam_fill(const kbbq_sam* f, int64_t first, int64_t n, int pitch, int which, uint8_t* plane);
+int kbbq_sam_text(const kbbq_sam* f, int what, int64_t i, const char** p, int64_t* len);
+
 /* ---- host FASTQ ingest / egress (no GPU) ----------------------------------
  * Replaces, for this path, pysam.FastxFile iteration (recalibrate.py:56-57,141-142),
  * the name parsing of compare_reads.py:304-318 / recalibrate.py:59-64 and the print()

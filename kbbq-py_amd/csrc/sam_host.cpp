@@ -1,0 +1,369 @@
+// sam_host.cpp -- host-side SAM text reader for the truth-set benchmark and the BAM-sourced tally (no GPU code).
+//
+// Replaces, for those paths, what the reference gets from pysam.AlignmentFile / AlignedSegment
+// (benchmark.py:57-74,102-143; gatk/bqsr.py:23-123): per alignment the flag, contig, position, CIGAR,
+// mate position, template length, sequence, qualities and the RG / OQ tags -- as ARRAYS, because the
+// kernels (K4 find_errors, K6 canonical reads) take whole batches.  SAM text only (binary BAM needs
+// htslib); the file is mapped, lines are indexed and parsed in parallel.
+//
+// Field semantics follow the SAM specification and pysam's attribute definitions:
+//   reference_start = POS - 1; next_reference_start = PNEXT - 1; reference_end = start + sum of M/D/N/=/X;
+//   query_alignment_start / _end = leading / trailing soft clip (hard clips outside them are ignored).
+// CIGAR operations are stored as (length << 4 | op) with BAM op codes MIDNSHP=X = 0..8; an unknown
+// operation letter is stored as op 15 and rejected by K4 (ValueError, like the reference's walk).
+#include "../../include/kbbq_hip.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+int kbbq_set_error_(int code, const char* msg);      // defined in kbbq_hip.hip
+
+struct kbbq_sam {
+    const uint8_t* buf = nullptr; size_t size = 0;
+    std::vector<uint64_t> hdr0; std::vector<uint32_t> hdrlen;      // header lines ('@...')
+    std::vector<uint64_t> line0; std::vector<uint32_t> linelen;    // alignment lines
+    // per alignment
+    std::vector<uint32_t> name_len, seq_len, qual_len, oq_len, rgtag_len, cig_n, clip;
+    std::vector<uint64_t> seq0, qual0, oq0, rgtag0, cig_off;
+    std::vector<int32_t> flag, contig, ref_span, rg;
+    std::vector<int64_t> pos, pnext, tlen;
+    std::vector<uint32_t> cigar;
+    std::vector<std::string> contigs;          // first-appearance order of RNAME
+    std::vector<std::string> rg_ids;           // @RG ID in header order
+    ~kbbq_sam() { if (buf) munmap((void*)buf, size); }
+};
+
+namespace {
+
+unsigned threads_for(size_t work)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 4;
+    const char* e = getenv("KBBQ_HOST_THREADS");
+    if (e && atoi(e) > 0) hw = (unsigned)atoi(e);
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(hw, work / (1 << 20) + 1));
+}
+
+template <typename F> void par_for(int64_t n, unsigned nt, F f)
+{
+    if (nt <= 1 || n < 4096) { f(0, n); return; }
+    std::vector<std::thread> th;
+    const int64_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const int64_t lo = std::min<int64_t>(n, t * per), hi = std::min<int64_t>(n, lo + per);
+        if (lo < hi) th.emplace_back([=]() { f(lo, hi); });
+    }
+    for (auto& t : th) t.join();
+}
+
+bool parse_int(const uint8_t* p, const uint8_t* e, int64_t& out)
+{
+    if (p >= e) return false;
+    bool neg = false;
+    if (*p == '-' || *p == '+') { neg = *p == '-'; ++p; if (p >= e) return false; }
+    int64_t v = 0;
+    for (; p < e; ++p) {
+        if (*p < '0' || *p > '9') return false;
+        if (v > (INT64_MAX - 9) / 10) return false;
+        v = v * 10 + (*p - '0');
+    }
+    out = neg ? -v : v;
+    return true;
+}
+
+int cigar_code(uint8_t c)
+{
+    switch (c) {
+        case 'M': return 0; case 'I': return 1; case 'D': return 2; case 'N': return 3; case 'S': return 4;
+        case 'H': return 5; case 'P': return 6; case '=': return 7; case 'X': return 8; default: return 15;
+    }
+}
+
+// one pass over a CIGAR string: count the operations (ops == nullptr) or write them
+int64_t walk_cigar(const uint8_t* p, const uint8_t* e, uint32_t* ops, bool& bad)
+{
+    if (e - p == 1 && *p == '*') return 0;
+    int64_t n = 0; uint64_t len = 0; bool have = false;
+    for (; p < e; ++p) {
+        if (*p >= '0' && *p <= '9') { len = len * 10 + (uint64_t)(*p - '0'); have = true; if (len > 0x0FFFFFFFull) bad = true; }
+        else {
+            if (!have) bad = true;
+            if (ops) ops[n] = (uint32_t)(len << 4) | (uint32_t)cigar_code(*p);
+            ++n; len = 0; have = false;
+        }
+    }
+    if (have) bad = true;                       // trailing digits without an operation
+    return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kbbq_sam_open(const char* path, kbbq_sam** out)
+{
+    if (!path || !out) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_sam_open: NULL argument");
+    *out = nullptr;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return kbbq_set_error_(KBBQ_E_ARG, (std::string("cannot open ") + path).c_str());
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return kbbq_set_error_(KBBQ_E_ARG, "fstat failed"); }
+    kbbq_sam* f = new kbbq_sam();
+    f->size = (size_t)st.st_size;
+    if (f->size) {
+        void* m = mmap(nullptr, f->size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); f->size = 0; delete f; return kbbq_set_error_(KBBQ_E_ARG, "mmap failed"); }
+        f->buf = (const uint8_t*)m;
+        madvise(m, f->size, MADV_SEQUENTIAL);
+    }
+    close(fd);
+    if (f->size >= 4 && (!memcmp(f->buf, "BAM\1", 4) || !memcmp(f->buf, "\x1f\x8b\x08\x04", 4))) {
+        delete f;
+        return kbbq_set_error_(KBBQ_E_NAME, "binary BAM needs htslib; convert with `samtools view -h`");
+    }
+    // line ends, in parallel
+    const unsigned nt = threads_for(f->size);
+    std::vector<std::vector<uint64_t>> parts(nt);
+    {
+        std::vector<std::thread> th;
+        const size_t per = (f->size + nt - 1) / nt;
+        for (unsigned t = 0; t < nt; ++t) {
+            const size_t lo = std::min(f->size, t * per), hi = std::min(f->size, lo + per);
+            th.emplace_back([f, lo, hi, &parts, t]() {
+                const uint8_t* p = f->buf + lo; const uint8_t* e = f->buf + hi;
+                while (p < e) {
+                    const uint8_t* nl = (const uint8_t*)memchr(p, '\n', (size_t)(e - p));
+                    if (!nl) break;
+                    parts[t].push_back((uint64_t)(nl - f->buf));
+                    p = nl + 1;
+                }
+            });
+        }
+        for (auto& t : th) t.join();
+    }
+    std::vector<uint64_t> nl;
+    for (auto& v : parts) nl.insert(nl.end(), v.begin(), v.end());
+    if (f->size && (nl.empty() || nl.back() != f->size - 1)) nl.push_back(f->size);
+    uint64_t start = 0;
+    for (uint64_t end : nl) {
+        uint64_t e = end;
+        if (e > start && f->buf[e - 1] == '\r') --e;
+        bool blank = true;
+        for (uint64_t k = start; k < e; ++k) if (f->buf[k] != ' ' && f->buf[k] != '\t') { blank = false; break; }
+        if (!blank) {
+            if (f->buf[start] == '@') { f->hdr0.push_back(start); f->hdrlen.push_back((uint32_t)(e - start)); }
+            else { f->line0.push_back(start); f->linelen.push_back((uint32_t)(e - start)); }
+        }
+        start = end + 1;
+    }
+    // @RG IDs in header order
+    for (size_t h = 0; h < f->hdr0.size(); ++h) {
+        const uint8_t* p = f->buf + f->hdr0[h]; const uint8_t* e = p + f->hdrlen[h];
+        if (e - p < 3 || memcmp(p, "@RG", 3) != 0) continue;
+        std::string id;
+        const uint8_t* q = p;
+        while (q < e) {
+            const uint8_t* t = (const uint8_t*)memchr(q, '\t', (size_t)(e - q));
+            const uint8_t* fe = t ? t : e;
+            if (fe - q > 3 && q[0] == 'I' && q[1] == 'D' && q[2] == ':') id.assign((const char*)q + 3, (size_t)(fe - q - 3));
+            q = fe + 1;
+        }
+        f->rg_ids.push_back(id);
+    }
+    std::unordered_map<std::string, int> rgmap;
+    for (size_t i = 0; i < f->rg_ids.size(); ++i) rgmap.emplace(f->rg_ids[i], (int)i);
+
+    const int64_t n = (int64_t)f->line0.size();
+    f->name_len.assign(n, 0); f->seq_len.assign(n, 0); f->qual_len.assign(n, 0); f->oq_len.assign(n, 0); f->rgtag_len.assign(n, 0);
+    f->cig_n.assign(n, 0); f->clip.assign(n, 0); f->seq0.assign(n, 0); f->qual0.assign(n, 0); f->oq0.assign(n, 0); f->rgtag0.assign(n, 0);
+    f->cig_off.assign(n + 1, 0); f->flag.assign(n, 0); f->contig.assign(n, -1); f->ref_span.assign(n, 0); f->rg.assign(n, -1);
+    f->pos.assign(n, 0); f->pnext.assign(n, 0); f->tlen.assign(n, 0);
+    std::vector<uint64_t> rname0(n, 0), cig0(n, 0); std::vector<uint32_t> rname_len(n, 0), cig_len(n, 0);
+    std::atomic<int64_t> badline(-1);
+    auto flagbad = [&](int64_t i) { int64_t cur = badline.load(); while ((cur < 0 || i < cur) && !badline.compare_exchange_weak(cur, i)) {} };
+    // pass 1: split fields, numbers, tags, count CIGAR operations
+    par_for(n, nt, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const uint8_t* p = f->buf + f->line0[i]; const uint8_t* e = p + f->linelen[i];
+            const uint8_t* fs[12]; const uint8_t* fe[12]; int nf = 0;
+            const uint8_t* q = p;
+            while (nf < 11 && q <= e) {
+                const uint8_t* t = (const uint8_t*)memchr(q, '\t', (size_t)(e - q));
+                fs[nf] = q; fe[nf] = t ? t : e; ++nf;
+                if (!t) { q = e + 1; break; }
+                q = t + 1;
+            }
+            if (nf < 11) { flagbad(i); continue; }
+            int64_t v;
+            f->name_len[i] = (uint32_t)(fe[0] - fs[0]);
+            if (!parse_int(fs[1], fe[1], v)) { flagbad(i); continue; }
+            f->flag[i] = (int32_t)v;
+            rname0[i] = (uint64_t)(fs[2] - f->buf); rname_len[i] = (uint32_t)(fe[2] - fs[2]);
+            if (!parse_int(fs[3], fe[3], v)) { flagbad(i); continue; }
+            f->pos[i] = v - 1;
+            cig0[i] = (uint64_t)(fs[5] - f->buf); cig_len[i] = (uint32_t)(fe[5] - fs[5]);
+            if (!parse_int(fs[7], fe[7], v)) { flagbad(i); continue; }
+            f->pnext[i] = v - 1;
+            if (!parse_int(fs[8], fe[8], v)) { flagbad(i); continue; }
+            f->tlen[i] = v;
+            f->seq0[i] = (uint64_t)(fs[9] - f->buf); f->seq_len[i] = (uint32_t)(fe[9] - fs[9]);
+            f->qual0[i] = (uint64_t)(fs[10] - f->buf); f->qual_len[i] = (uint32_t)(fe[10] - fs[10]);
+            if (f->seq_len[i] > 65535) { flagbad(i); continue; }
+            bool bad = false;
+            f->cig_n[i] = (uint32_t)walk_cigar(fs[5], fe[5], nullptr, bad);
+            if (bad) { flagbad(i); continue; }
+            // tags
+            while (q < e) {
+                const uint8_t* t = (const uint8_t*)memchr(q, '\t', (size_t)(e - q));
+                const uint8_t* te = t ? t : e;
+                if (te - q >= 5 && q[2] == ':' && q[4] == ':') {
+                    if (q[0] == 'R' && q[1] == 'G' && q[3] == 'Z') { f->rgtag0[i] = (uint64_t)(q + 5 - f->buf); f->rgtag_len[i] = (uint32_t)(te - q - 5) + 1; }
+                    else if (q[0] == 'O' && q[1] == 'Q' && q[3] == 'Z') { f->oq0[i] = (uint64_t)(q + 5 - f->buf); f->oq_len[i] = (uint32_t)(te - q - 5) + 1; }
+                }
+                q = te + 1;
+            }
+            if (f->rgtag_len[i]) {
+                auto it = rgmap.find(std::string((const char*)f->buf + f->rgtag0[i], f->rgtag_len[i] - 1));
+                f->rg[i] = it == rgmap.end() ? -2 : it->second;          // -2: tag names a group the header lacks
+            }
+        }
+    });
+    if (badline.load() >= 0) {
+        const int64_t b = badline.load();
+        const std::string head((const char*)f->buf + f->line0[b], std::min<size_t>(60, f->linelen[b]));
+        delete f;
+        return kbbq_set_error_(KBBQ_E_RANGE, ("not a SAM alignment line: " + head).c_str());
+    }
+    // contigs in first-appearance order (serial: the order matters)
+    std::unordered_map<std::string, int> cmap;
+    for (int64_t i = 0; i < n; ++i) {
+        std::string name((const char*)f->buf + rname0[i], rname_len[i]);
+        auto it = cmap.find(name);
+        if (it == cmap.end()) { it = cmap.emplace(name, (int)f->contigs.size()).first; f->contigs.push_back(name); }
+        f->contig[i] = it->second;
+        f->cig_off[i + 1] = f->cig_off[i] + f->cig_n[i];
+    }
+    f->cigar.assign(f->cig_off[n], 0);
+    // pass 2: CIGAR operations, reference span, soft clips
+    par_for(n, nt, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            bool bad = false;
+            uint32_t* ops = f->cigar.data() + f->cig_off[i];
+            const int64_t m = walk_cigar(f->buf + cig0[i], f->buf + cig0[i] + cig_len[i], ops, bad);
+            int64_t span = 0;
+            for (int64_t k = 0; k < m; ++k) { const uint32_t op = ops[k] & 15u; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += ops[k] >> 4; }
+            f->ref_span[i] = (int32_t)std::min<int64_t>(span, INT32_MAX);
+            int64_t lead = 0, tail = 0;
+            for (int64_t k = 0; k < m; ++k) { const uint32_t op = ops[k] & 15u; if (op == 4) lead += ops[k] >> 4; else if (op != 5) break; }
+            for (int64_t k = m - 1; k >= 0; --k) { const uint32_t op = ops[k] & 15u; if (op == 4) tail += ops[k] >> 4; else if (op != 5) break; }
+            const int64_t L = (f->seq_len[i] == 1 && f->buf[f->seq0[i]] == '*') ? 0 : f->seq_len[i];
+            const int64_t qs = std::min<int64_t>(lead, 65535), qe = std::max<int64_t>(0, std::min<int64_t>(L - tail, 65535));
+            f->clip[i] = (uint32_t)qs | ((uint32_t)qe << 16);
+        }
+    });
+    *out = f;
+    return KBBQ_OK;
+}
+
+int kbbq_sam_close(kbbq_sam* f) { delete f; return KBBQ_OK; }
+
+// info = { alignments, CIGAR operations in total, longest SEQ, contigs seen, @RG lines, header lines }
+int kbbq_sam_info(const kbbq_sam* f, int64_t* info6)
+{
+    if (!f || !info6) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_sam_info: NULL argument");
+    const int64_t n = (int64_t)f->line0.size();
+    int64_t maxlen = 0;
+    for (int64_t i = 0; i < n; ++i) maxlen = std::max<int64_t>(maxlen, f->seq_len[i]);
+    info6[0] = n; info6[1] = (int64_t)f->cigar.size(); info6[2] = maxlen; info6[3] = (int64_t)f->contigs.size();
+    info6[4] = (int64_t)f->rg_ids.size(); info6[5] = (int64_t)f->hdr0.size();
+    return KBBQ_OK;
+}
+
+// any output pointer may be NULL
+int kbbq_sam_fields(const kbbq_sam* f, int32_t* flag, int32_t* contig, int64_t* pos, int64_t* pnext, int64_t* tlen,
+                    int32_t* qlen, int32_t* ref_span, uint32_t* clip, uint32_t* cig_off, uint32_t* cig_n, int32_t* rg,
+                    int32_t* has_qual_oq)
+{
+    if (!f) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_sam_fields: NULL handle");
+    const int64_t n = (int64_t)f->line0.size();
+    for (int64_t i = 0; i < n; ++i) {
+        if (flag) flag[i] = f->flag[i];
+        if (contig) contig[i] = f->contig[i];
+        if (pos) pos[i] = f->pos[i];
+        if (pnext) pnext[i] = f->pnext[i];
+        if (tlen) tlen[i] = f->tlen[i];
+        if (qlen) qlen[i] = (f->seq_len[i] == 1 && f->buf[f->seq0[i]] == '*') ? 0 : (int32_t)f->seq_len[i];
+        if (ref_span) ref_span[i] = f->ref_span[i];
+        if (clip) clip[i] = f->clip[i];
+        if (cig_off) cig_off[i] = (uint32_t)f->cig_off[i];
+        if (cig_n) cig_n[i] = f->cig_n[i];
+        if (rg) rg[i] = f->rg[i];
+        if (has_qual_oq) {
+            const bool noqual = f->qual_len[i] == 1 && f->buf[f->qual0[i]] == '*';
+            has_qual_oq[i] = (noqual ? 0 : (int32_t)f->qual_len[i]) | (f->oq_len[i] ? (int32_t)(f->oq_len[i] - 1) << 16 : -65536);
+        }
+    }
+    return KBBQ_OK;
+}
+
+int kbbq_sam_cigar(const kbbq_sam* f, uint32_t* ops)
+{
+    if (!f || (!ops && !f->cigar.empty())) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_sam_cigar: NULL argument");
+    if (!f->cigar.empty()) memcpy(ops, f->cigar.data(), f->cigar.size() * sizeof(uint32_t));
+    return KBBQ_OK;
+}
+
+// which: 0 SEQ, 1 QUAL, 2 OQ tag; rows [0, n) <- alignments [first, first + n), zero padded; a missing / '*' field
+// leaves its row zero
+int kbbq_sam_fill(const kbbq_sam* f, int64_t first, int64_t n, int pitch, int which, uint8_t* plane)
+{
+    if (!f || (n > 0 && !plane)) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_sam_fill: NULL argument");
+    if (first < 0 || n < 0 || first + n > (int64_t)f->line0.size() || pitch <= 0 || which < 0 || which > 2)
+        return kbbq_set_error_(KBBQ_E_ARG, "kbbq_sam_fill: bad range / pitch / plane");
+    par_for(n, threads_for((size_t)n * (size_t)pitch), [&](int64_t lo, int64_t hi) {
+        for (int64_t r = lo; r < hi; ++r) {
+            const int64_t i = first + r;
+            uint64_t off; uint32_t len;
+            if (which == 0) { off = f->seq0[i]; len = f->seq_len[i]; }
+            else if (which == 1) { off = f->qual0[i]; len = f->qual_len[i]; }
+            else { off = f->oq0[i]; len = f->oq_len[i] ? f->oq_len[i] - 1 : 0; }
+            if (len == 1 && which != 2 && f->buf[off] == '*') len = 0;
+            len = std::min<uint32_t>(len, (uint32_t)pitch);
+            uint8_t* row = plane + (size_t)r * pitch;
+            if (len) memcpy(row, f->buf + off, len);
+            memset(row + len, 0, (size_t)pitch - len);
+        }
+    });
+    return KBBQ_OK;
+}
+
+// what: 0 QNAME of alignment i, 1 whole alignment line i, 2 header line i, 3 contig name i, 4 @RG ID i
+int kbbq_sam_text(const kbbq_sam* f, int what, int64_t i, const char** p, int64_t* len)
+{
+    if (!f || !p || !len) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_sam_text: NULL argument");
+    const int64_t lim = what <= 1 ? (int64_t)f->line0.size() : what == 2 ? (int64_t)f->hdr0.size()
+                      : what == 3 ? (int64_t)f->contigs.size() : what == 4 ? (int64_t)f->rg_ids.size() : -1;
+    if (i < 0 || i >= lim) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_sam_text: index out of range");
+    switch (what) {
+        case 0: *p = (const char*)f->buf + f->line0[i]; *len = f->name_len[i]; break;
+        case 1: *p = (const char*)f->buf + f->line0[i]; *len = f->linelen[i]; break;
+        case 2: *p = (const char*)f->buf + f->hdr0[i]; *len = f->hdrlen[i]; break;
+        case 3: *p = f->contigs[i].data(); *len = (int64_t)f->contigs[i].size(); break;
+        default: *p = f->rg_ids[i].data(); *len = (int64_t)f->rg_ids[i].size(); break;
+    }
+    return KBBQ_OK;
+}
+
+}  // extern "C"

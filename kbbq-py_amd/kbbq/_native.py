@@ -75,6 +75,13 @@ PROTOTYPES = {
     'kbbq_apply_pairs_dev': (_i, [_vp] * 4 + [_i64, _i, _i, _i] + [_vp] * 3),
     'kbbq_accumulate_grouped_dev': (_i, [_vp] * 5 + [_i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'kbbq_apply_grouped_dev': (_i, [_vp] * 4 + [_i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'kbbq_sam_open': (_i, [_c.c_char_p, _vp]),
+    'kbbq_sam_close': (_i, [_vp]),
+    'kbbq_sam_info': (_i, [_vp, _vp]),
+    'kbbq_sam_fields': (_i, [_vp] * 13),
+    'kbbq_sam_cigar': (_i, [_vp, _vp]),
+    'kbbq_sam_fill': (_i, [_vp, _i64, _i64, _i, _i, _vp]),
+    'kbbq_sam_text': (_i, [_vp, _i, _i64, _vp, _vp]),
     'kbbq_canonical_reads_dev': (_i, [_vp] * 9 + [_i64, _i, _i, _i, _i] + [_vp] * 4),
     'kbbq_fastq_open': (_i, [_c.c_char_p, _c.POINTER(_vp)]),
     'kbbq_fastq_close': (_i, [_vp]),

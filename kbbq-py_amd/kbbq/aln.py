@@ -145,32 +145,122 @@ class SamHeader(list):
         return out
 
 
+class _SamHandle:
+    """Owns the native reader's handle; shared by an AlignmentFile and its SamBatch so that either keeps the
+    mapped file alive."""
+
+    def __init__(self, path):
+        from . import _native as N
+        import ctypes
+        self.h = ctypes.c_void_p()
+        N.check(N.load().kbbq_sam_open(str(path).encode(), ctypes.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                from . import _native as N
+                N.load().kbbq_sam_close(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class SamBatch:
+    """Every alignment of a SAM file as arrays (the native reader, csrc/sam_host.cpp)."""
+
+    def __init__(self, handle):
+        from . import _native as N
+        import ctypes
+        lib = N.load()
+        self._handle = handle                 # keeps the mapping alive for plane() / names()
+        native = handle.h
+        info = np.zeros(6, dtype=np.int64)
+        N.check(lib.kbbq_sam_info(native, N.ptr(info)))
+        self.n, ncig, self.maxlen, ncontigs, nrg, _ = (int(x) for x in info)
+        n = max(self.n, 1)
+        self.flag = np.zeros(n, np.int32); self.contig = np.zeros(n, np.int32)
+        self.pos = np.zeros(n, np.int64); self.pnext = np.zeros(n, np.int64); self.tlen = np.zeros(n, np.int64)
+        self.qlen = np.zeros(n, np.int32); self.ref_span = np.zeros(n, np.int32); self.clip = np.zeros(n, np.uint32)
+        self.cig_off = np.zeros(n, np.uint32); self.cig_n = np.zeros(n, np.uint32); self.rg = np.zeros(n, np.int32)
+        hq = np.zeros(n, np.int32)
+        N.check(lib.kbbq_sam_fields(native, *[N.ptr(a) for a in (self.flag, self.contig, self.pos, self.pnext, self.tlen,
+                                                                self.qlen, self.ref_span, self.clip, self.cig_off,
+                                                                self.cig_n, self.rg, hq)]))
+        for name in ('flag', 'contig', 'pos', 'pnext', 'tlen', 'qlen', 'ref_span', 'clip', 'cig_off', 'cig_n', 'rg'):
+            setattr(self, name, getattr(self, name)[:self.n])
+        hq = hq[:self.n]
+        self.qual_len = hq & 0xFFFF                       # 0: QUAL is '*'
+        self.oq_len = hq >> 16                            # -1: no OQ tag
+        self.cigar = np.zeros(max(ncig, 1), np.uint32)
+        N.check(lib.kbbq_sam_cigar(native, N.ptr(self.cigar)))
+        self.cigar = self.cigar[:ncig]
+        self._native = native
+
+        def text(what, i):
+            p, ln = ctypes.c_char_p(), ctypes.c_int64(0)
+            N.check(lib.kbbq_sam_text(native, what, i, ctypes.byref(p), ctypes.byref(ln)))
+            return ctypes.string_at(p, ln.value).decode('latin-1')
+        self._text = text
+        self.contig_names = [text(3, i) for i in range(ncontigs)]
+        self.rg_ids = [text(4, i) for i in range(nrg)]
+
+    def plane(self, which, pitch, first=0, n=None):
+        """uint8 [n, pitch]: SEQ (0), QUAL (1) or the OQ tag (2) characters, zero padded."""
+        from . import _native as N
+        n = self.n - first if n is None else n
+        out = np.empty((max(n, 1), pitch), dtype=np.uint8)
+        if n == 0:
+            out[:] = 0
+        N.check(N.load().kbbq_sam_fill(self._native, first, n, pitch, which, N.ptr(out)))
+        return out
+
+    def names(self):
+        return [self._text(0, i) for i in range(self.n)]
+
+    def line(self, i):
+        return self._text(1, i)
+
+
 class AlignmentFile:
-    """Iterable of AlignedRead from a SAM text file (mode is accepted and ignored)."""
+    """A SAM text file (mode is accepted and ignored): parsed once by the native reader (csrc/sam_host.cpp) into
+    arrays -- `batch()`, what the kernels consume -- and, for code written against pysam, an iterable of
+    AlignedRead objects built on demand from the same lines."""
 
     def __init__(self, path, mode='r'):
         with open(path, 'rb') as fh:
             if fh.read(4) in (b'BAM\x01', b'\x1f\x8b\x08\x04'):
                 raise NotImplementedError('binary BAM needs htslib; convert with `samtools view -h`')
-        self.header = SamHeader()
-        self._reads = []
-        with _open(path) as fh:
-            for line in fh:
-                if line.startswith('@'):
-                    self.header.append(line.rstrip('\n'))
-                elif line.strip():
-                    self._reads.append(AlignedRead(line))
+        if str(path).endswith('.gz'):
+            raise NotImplementedError('compressed SAM is not read here; decompress it first')
+        from . import _native as N
+        self._handle = _SamHandle(path)
+        self._batch = SamBatch(self._handle)
+        info = np.zeros(6, dtype=np.int64)
+        N.check(N.load().kbbq_sam_info(self._handle.h, N.ptr(info)))
+        self.header = SamHeader(self._batch._text(2, i) for i in range(int(info[5])))
+        self._reads = None
+
+    def batch(self):
+        return self._batch
+
+    def _objects(self):
+        if self._reads is None:
+            self._reads = [AlignedRead(self._batch.line(i)) for i in range(self._batch.n)]
+        return self._reads
 
     def __iter__(self):
-        return iter(self._reads)
+        return iter(self._objects())
 
     def __next__(self):
         if not hasattr(self, '_it'):
-            self._it = iter(self._reads)
+            self._it = iter(self._objects())
         return next(self._it)
 
     def __len__(self):
-        return len(self._reads)
+        return self._batch.n
+
+    def close(self):
+        """pysam compatibility; the mapping is released when the last user of the handle goes away."""
 
 
 class FastaFile:

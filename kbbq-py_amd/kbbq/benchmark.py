@@ -74,19 +74,31 @@ class _Genome:
         self.sizes = {c: len(a) for c, a in refdict.items()}
 
 
-def _flag_batch(reads, genome, flip_reverse, keep=None):
-    """K4 over a list of aligned reads -> (err, skip) device planes [n, pitch], lens
-    (host).  `keep`, a dict, receives the device seq plane for callers that go on to K6."""
-    from . import _device as dev
-    from . import _native as N
-    torch = dev._torch()
+def _read_arrays(reads, genome, flip_reverse):
+    """Host arrays K4 needs, from an aln.AlignmentFile (native reader: vectorised) or from a list of
+    pysam-like read objects (one Python pass; the form the reference's own tests use)."""
+    if isinstance(reads, aln.AlignmentFile):
+        b = reads.batch()
+        n = b.n
+        lens = b.qlen.astype(np.uint32)
+        pitch = fastx.pitch_for(int(lens.max()) if n else 1)
+        seq = b.plane(0, pitch)
+        sizes = np.array([genome.sizes[c] for c in b.contig_names] + [0], dtype=np.int64)      # KeyError: unknown contig
+        offs = np.array([genome.offset[c] for c in b.contig_names] + [0], dtype=np.int64)
+        size = sizes[b.contig] if n else np.zeros(0, np.int64)
+        start = np.minimum(np.maximum(b.pos, 0), size)               # Python slice clamping of the reference window
+        end = np.minimum(np.maximum(b.pos + b.ref_span, start), size)
+        ref_start = (offs[b.contig] if n else np.zeros(0, np.int64)) + start
+        ref_len = (end - start).astype(np.int32)
+        flip = ((b.flag & 16) != 0).astype(np.uint8) if flip_reverse else np.zeros(n, dtype=np.uint8)
+        return n, lens, pitch, seq, ref_start, ref_len, b.cig_off, b.cig_n, b.cigar, flip
     n = len(reads)
     lens = np.array([len(r.query_sequence) for r in reads], dtype=np.uint32)
     pitch = fastx.pitch_for(int(lens.max()) if n else 1)
     seq = np.zeros((max(n, 1), pitch), dtype=np.uint8)
-    ref_start = np.zeros(max(n, 1), dtype=np.int64); ref_len = np.zeros(max(n, 1), dtype=np.int32)
-    cig_off = np.zeros(max(n, 1), dtype=np.uint32); cig_n = np.zeros(max(n, 1), dtype=np.uint32)
-    flip = np.zeros(max(n, 1), dtype=np.uint8)
+    ref_start = np.zeros(n, dtype=np.int64); ref_len = np.zeros(n, dtype=np.int32)
+    cig_off = np.zeros(n, dtype=np.uint32); cig_n = np.zeros(n, dtype=np.uint32)
+    flip = np.zeros(n, dtype=np.uint8)
     cigar = []
     for i, r in enumerate(reads):
         seq[i, :lens[i]] = aln.codes(r.query_sequence)
@@ -100,23 +112,43 @@ def _flag_batch(reads, genome, flip_reverse, keep=None):
             code = op if isinstance(op, (int, np.integer)) and 0 <= op <= 8 else 15   # 15: unrecognised -> ValueError
             cigar.append((int(l) << 4) | int(code))
         flip[i] = 1 if (flip_reverse and r.is_reverse) else 0
+    return n, lens, pitch, seq, ref_start, ref_len, cig_off, cig_n, np.array(cigar, dtype=np.uint32), flip
+
+
+def _flag_batch(reads, genome, flip_reverse, keep=None):
+    """K4 over aligned reads (an aln.AlignmentFile or a list of read objects) -> (err, skip) device planes
+    [n, pitch], lens (host).  `keep`, a dict, receives the device seq plane for callers that go on to K6."""
+    from . import _device as dev
+    from . import _native as N
+    torch = dev._torch()
+    n, lens, pitch, seq, ref_start, ref_len, cig_off, cig_n, cigar, flip = _read_arrays(reads, genome, flip_reverse)
+    pad = lambda a, dt: np.ascontiguousarray(a if len(a) else np.zeros(1), dtype=dt)
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    d_seq, d_len = up(seq), up(lens.view(np.int32) if n else np.zeros(1, np.int32))
-    d_cigar = up(np.array(cigar if cigar else [0], dtype=np.uint32).view(np.int32))
+    d_seq, d_len = up(seq), up(pad(lens, np.uint32).view(np.int32))
+    d_cigar = up(pad(cigar, np.uint32).view(np.int32))
     err = torch.zeros((max(n, 1), pitch), dtype=torch.uint8, device='cuda')
     skip = torch.zeros((max(n, 1), pitch), dtype=torch.uint8, device='cuda')
     if keep is not None:
         keep['seq'] = d_seq
     ctx = dev.context()
     # keep every device tensor referenced until the kernel has run (N.ptr only takes the address)
-    d_rs, d_rl, d_flip = up(ref_start), up(ref_len), up(flip)
-    d_co, d_cn = up(cig_off.view(np.int32)), up(cig_n.view(np.int32))
+    d_rs, d_rl, d_flip = up(pad(ref_start, np.int64)), up(pad(ref_len, np.int32)), up(pad(flip, np.uint8))
+    d_co, d_cn = up(pad(cig_off, np.uint32).view(np.int32)), up(pad(cig_n, np.uint32).view(np.int32))
     N.check(N.load().kbbq_find_errors_dev(ctx.handle, N.ptr(d_seq), N.ptr(d_len), n, pitch,
                                           N.ptr(d_rs), N.ptr(d_rl), N.ptr(d_co), N.ptr(d_cn),
                                           N.ptr(d_cigar), N.ptr(genome.genome), N.ptr(genome.mask), genome.length,
                                           N.ptr(d_flip), N.ptr(err), N.ptr(skip)))
     ctx.status()
     return err, skip, lens, pitch
+
+
+def _bam_names(reads):
+    """Canonical read names (benchmark.py:41-48): QNAME + /1 or /2."""
+    if isinstance(reads, aln.AlignmentFile):
+        b = reads.batch()
+        second = (b.flag & 128) != 0
+        return [nm + ('/2' if s else '/1') for nm, s in zip(b.names(), second)]
+    return [get_bam_readname(r) for r in reads]
 
 
 def _count_q(qual, err, skip, lens, pitch, qoffset):
@@ -150,11 +182,11 @@ def _actual_q(numerrs, numtotal):
 def get_error_dict(bamfile, refdict, fullskips):
     """{canonical read name: (errors, skips)} -- flags of reverse-strand reads flipped, because a
     FASTQ made from the BAM holds them reverse-complemented."""
-    reads = list(bamfile)
+    reads = bamfile if isinstance(bamfile, aln.AlignmentFile) else list(bamfile)
     genome = _Genome(refdict, fullskips)
     err, skip, lens, _ = _flag_batch(reads, genome, flip_reverse=True)
     e, s = err.cpu().numpy().astype(bool), skip.cpu().numpy().astype(bool)
-    return {get_bam_readname(r): (e[i, :lens[i]].copy(), s[i, :lens[i]].copy()) for i, r in enumerate(reads)}
+    return {name: (e[i, :lens[i]].copy(), s[i, :lens[i]].copy()) for i, name in enumerate(_bam_names(reads))}
 
 
 def calculate_q(errors, quals):
@@ -188,6 +220,21 @@ def get_bamread_quals(read, use_oq=False):
 
 
 def _qual_plane(reads, lens, pitch, use_oq):
+    """uint8 plane of phred values (not characters) per read."""
+    if isinstance(reads, aln.AlignmentFile):
+        b = reads.batch()
+        have = b.oq_len if use_oq else b.qual_len
+        if use_oq and b.n and int(have.min()) < 0:
+            raise KeyError("tag 'OQ' not present")
+        if b.n and np.any(have != lens):
+            i = int(np.flatnonzero(have != lens)[0])
+            raise IndexError('boolean index did not match indexed array: read %d has %d qualities for %d bases'
+                             % (i, int(have[i]), int(lens[i])))
+        chars = b.plane(2 if use_oq else 1, pitch)
+        inside = np.arange(pitch)[None, :] < np.asarray(lens)[:, None] if b.n else np.zeros((1, pitch), dtype=bool)
+        if b.n and int(chars[:b.n][inside].min(initial=255)) < 33:
+            raise ValueError('qualities must lie in 0..255')
+        return np.where(inside, chars[:max(b.n, 1)] - 33, 0).astype(np.uint8)
     q = np.zeros((max(len(reads), 1), pitch), dtype=np.uint8)
     for i, r in enumerate(reads):
         v = get_bamread_quals(r, use_oq)
@@ -204,7 +251,7 @@ def benchmark_bam(bamfile, ref, var_sites, use_oq=False, bedfh=None):
     from . import _device as dev
     torch = dev._torch()
     fullskips = get_full_skips(ref, var_sites, bedfh)
-    reads = list(bamfile)
+    reads = bamfile if isinstance(bamfile, aln.AlignmentFile) else list(bamfile)
     err, skip, lens, pitch = _flag_batch(reads, _Genome(ref, fullskips), flip_reverse=False)
     qual = torch.from_numpy(_qual_plane(reads, lens, pitch, use_oq)).cuda()
     return _actual_q(*_count_q(qual, err, skip, lens, pitch, 0))
@@ -214,11 +261,11 @@ def benchmark_fastq(fqfile, bamfile, ref, var_sites, bedfh=None):
     from . import _device as dev
     torch = dev._torch()
     fullskips = get_full_skips(ref, var_sites, bedfh)
-    reads = list(bamfile)
+    reads = bamfile if isinstance(bamfile, aln.AlignmentFile) else list(bamfile)
     err, skip, lens, pitch = _flag_batch(reads, _Genome(ref, fullskips), flip_reverse=True)
     row = {}
-    for i, r in enumerate(reads):
-        row[get_bam_readname(r)] = i                                 # later reads replace earlier ones (dict)
+    for i, name in enumerate(_bam_names(reads)):
+        row[name] = i                                                # later reads replace earlier ones (dict)
     fq = fastx.NativeFastq(fqfile)
     idx = np.array([row[fq.name(i).split('_')[0]] for i in range(fq.n)], dtype=np.int64)   # KeyError if absent
     n, S, _, kind, bad = fq.scan(None, False)

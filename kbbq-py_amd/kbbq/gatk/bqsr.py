@@ -63,6 +63,14 @@ def bamread_adaptor_boundary(read):
 _UNSET = object()
 
 
+class _CigarView:
+    """The few attributes _trim_range reads, for alignments that only exist as arrays."""
+
+    def __init__(self, ops, start, end, reverse, nqual):
+        self.cigartuples, self.reference_start, self.reference_end = ops, start, end
+        self.is_reverse, self.query_qualities = reverse, range(nqual)
+
+
 def _trim_range(read, boundary=_UNSET):
     """(lo, hi): query positions [lo, hi) lie past the adaptor boundary (reference
     bqsr.py:158-206), found by one pass over the CIGAR instead of get_aligned_pairs()."""
@@ -144,28 +152,58 @@ def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxsc
     for chrom in ref:
         fullskips[chrom] = np.zeros(len(ref[chrom]), dtype=bool)
         fullskips[chrom][np.array(var_pos[chrom], dtype=np.int_)] = True      # KeyError: a contig without sites
-    reads = list(bamfileobj)
-    if not reads:
-        raise StopIteration                                                    # next(bamfileobj) at :71
-    S = len(reads[0].query_qualities)
+    native = isinstance(bamfileobj, aln.AlignmentFile)
+    reads = bamfileobj if native else list(bamfileobj)
     n = len(reads)
+    if n == 0:
+        raise StopIteration                                                    # next(bamfileobj) at :71
     genome = benchmark._Genome(ref, fullskips)
     kept = {}
     err, skip, lens, pitch = benchmark._flag_batch(reads, genome, flip_reverse=False, keep=kept)
-    oq = np.zeros((n, pitch), dtype=np.uint8)
-    clip = np.zeros(n, dtype=np.uint32); trim = np.zeros(n, dtype=np.uint32); flags = np.zeros(n, dtype=np.uint32)
     bad_length = None
-    for i, r in enumerate(reads):
-        rg = rg_to_int[r.get_tag('RG')]
-        q = aln.codes(r.get_tag('OQ'))
-        if (len(q) != S or lens[i] != S) and bad_length is None:
-            bad_length = i
-        m = min(len(q), pitch)
-        oq[i, :m] = q[:m]
-        clip[i] = r.query_alignment_start | (r.query_alignment_end << 16)
-        lo, hi = _trim_range(r)
-        trim[i] = lo | (hi << 16)
-        flags[i] = (1 if r.is_reverse else 0) | (2 if r.is_read2 else 0) | (rg << 16)
+    if native:
+        # arrays straight from the SAM reader; only reads whose adaptor boundary falls inside them need a CIGAR pass
+        b = reads.batch()
+        S = int(b.qual_len[0]) if b.qual_len[0] else int(b.qlen[0])            # len(read.query_qualities) of the first read
+        if int(b.rg.min()) < 0:
+            i = int(np.flatnonzero(b.rg < 0)[0])
+            raise KeyError("tag 'RG' not present" if b.rg[i] == -1 else b._text(1, i).split('RG:Z:')[1].split('\t')[0])
+        if int(b.oq_len.min()) < 0:
+            raise KeyError("tag 'OQ' not present")
+        oq = b.plane(2, pitch)
+        wrong = np.flatnonzero((b.oq_len != S) | (lens != S))
+        if wrong.size:
+            bad_length = int(wrong[0])
+        clip = b.clip.copy()
+        rev, mate_rev = (b.flag & 16) != 0, (b.flag & 32) != 0
+        ref_end = b.pos + b.ref_span
+        usable = (b.tlen != 0) & ((b.flag & 1) != 0) & ((b.flag & 4) == 0) & ((b.flag & 8) == 0) & (rev != mate_rev)
+        bnd_rev = b.pnext - 1
+        cand_rev = usable & rev & ((ref_end - 1) > b.pnext) & (bnd_rev >= b.pos)
+        bnd_fwd = b.pos + np.abs(b.tlen)
+        cand_fwd = usable & ~rev & (b.pos <= b.pnext + b.tlen) & (bnd_fwd <= ref_end - 1)
+        trim = np.zeros(n, dtype=np.uint32)
+        for i in np.flatnonzero(cand_rev | cand_fwd):
+            ops = [(int(x) & 15, int(x) >> 4) for x in b.cigar[b.cig_off[i]:b.cig_off[i] + b.cig_n[i]]]
+            shim = _CigarView(ops, int(b.pos[i]), int(ref_end[i]), bool(rev[i]), int(b.qual_len[i]))
+            lo, hi = _trim_range(shim, int(bnd_rev[i]) if rev[i] else int(bnd_fwd[i]))
+            trim[i] = lo | (hi << 16)
+        flags = (rev.astype(np.uint32) | (((b.flag & 128) != 0).astype(np.uint32) << 1) | (b.rg.astype(np.uint32) << 16))
+    else:
+        S = len(reads[0].query_qualities)
+        oq = np.zeros((n, pitch), dtype=np.uint8)
+        clip = np.zeros(n, dtype=np.uint32); trim = np.zeros(n, dtype=np.uint32); flags = np.zeros(n, dtype=np.uint32)
+        for i, r in enumerate(reads):
+            rg = rg_to_int[r.get_tag('RG')]
+            q = aln.codes(r.get_tag('OQ'))
+            if (len(q) != S or lens[i] != S) and bad_length is None:
+                bad_length = i
+            m = min(len(q), pitch)
+            oq[i, :m] = q[:m]
+            clip[i] = r.query_alignment_start | (r.query_alignment_end << 16)
+            lo, hi = _trim_range(r)
+            trim[i] = lo | (hi << 16)
+            flags[i] = (1 if r.is_reverse else 0) | (2 if r.is_read2 else 0) | (rg << 16)
     upto = n if bad_length is None else bad_length       # reads before the offending one are still examined
     tables = dev.Tables(max(R, 1), 2 * S)
     if upto:

@@ -45,9 +45,39 @@ static int run_pair(const char* pa, const char* pb, int infer)
     return 0;
 }
 
+static int run_sam(const char* path)
+{
+    kbbq_sam* f = nullptr;
+    int rc = kbbq_sam_open(path, &f);
+    if (rc) { printf("sam open rc=%d (%s)\n", rc, g_err.c_str()); return 0; }
+    int64_t info[6];
+    kbbq_sam_info(f, info);
+    printf("sam n=%lld cigar=%lld maxlen=%lld contigs=%lld rgs=%lld header=%lld\n", (long long)info[0], (long long)info[1],
+           (long long)info[2], (long long)info[3], (long long)info[4], (long long)info[5]);
+    const size_t n = (size_t)info[0] + 1;
+    std::vector<int32_t> flag(n), contig(n), qlen(n), span(n), rg(n), hq(n);
+    std::vector<int64_t> pos(n), pnext(n), tlen(n);
+    std::vector<uint32_t> clip(n), co(n), cn(n), ops((size_t)info[1] + 1);
+    kbbq_sam_fields(f, flag.data(), contig.data(), pos.data(), pnext.data(), tlen.data(), qlen.data(), span.data(), clip.data(),
+                    co.data(), cn.data(), rg.data(), hq.data());
+    kbbq_sam_fields(f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    kbbq_sam_cigar(f, ops.data());
+    const int pitch = (int)((info[2] + 15) / 16 * 16 > 0 ? (info[2] + 15) / 16 * 16 : 16);
+    std::vector<uint8_t> plane((size_t)info[0] * pitch + 1);
+    for (int which = 0; which < 3; ++which) printf("fill %d rc=%d\n", which, kbbq_sam_fill(f, 0, info[0], pitch, which, plane.data()));
+    if (info[0] > 2) kbbq_sam_fill(f, 1, info[0] - 2, 16, 0, plane.data());          // a narrower pitch truncates
+    const char* p; int64_t len; long long total = 0;
+    for (int what = 0; what < 5; ++what)
+        for (int64_t i = 0; i < 3; ++i) if (kbbq_sam_text(f, what, i, &p, &len) == 0) total += len + (len ? p[len - 1] : 0);
+    printf("text %lld\n", total);
+    kbbq_sam_close(f);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) return 2;
+    if (!strcmp(argv[1], "sam")) return run_sam(argv[2]);
     if (!strcmp(argv[1], "pair")) return run_pair(argv[2], argc > 3 && strcmp(argv[3], "-") ? argv[3] : nullptr, argc > 4 ? atoi(argv[4]) : 0);
     if (!strcmp(argv[1], "combiln")) {
         const int64_t n = 50000;

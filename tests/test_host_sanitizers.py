@@ -17,7 +17,7 @@ def harness(tmp_path_factory):
     csrc = os.path.join(ROOT, 'kbbq-py_amd', 'csrc')
     cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-pthread',
            '-o', exe, os.path.join(ROOT, 'tests', 'native', 'host_sanitize.cpp'),
-           os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'solve_host.cpp')]
+           os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'solve_host.cpp'), os.path.join(csrc, 'sam_host.cpp')]
     subprocess.check_call(cmd)
 
     def run(*args):
@@ -78,3 +78,26 @@ def test_malformed_inputs_do_not_touch_memory_they_do_not_own(harness, tmp_path)
 def test_gammaln_pool(harness):
     out = harness('combiln')
     assert out.count('rc=0') == 5
+
+
+def test_sam_reader(harness, oracle, tmp_path):
+    import oracle_bqsr as OQ
+    paths = OQ.synth_bqsr_set(str(tmp_path), seed=3, npairs=400, S=60)
+    out = harness('sam', paths['sam'])
+    assert 'sam n=800' in out and out.count('rc=0') == 3
+    hdr = '@HD\tVN:1.6\n@SQ\tSN:c\tLN:100\n@RG\tID:a\tPU:u\n@RG\tPU:noid\n@CO\tfree text\n'
+    ok = 'r1\t99\tc\t5\t60\t4M\t=\t20\t30\tACGT\tIIII\tRG:Z:a\tOQ:Z:JJJJ\n'
+    cases = {
+        'empty': '', 'header_only': hdr, 'good': hdr + ok, 'no_newline': hdr + ok.rstrip('\n'), 'crlf': (hdr + ok).replace('\n', '\r\n'),
+        'few_fields': hdr + 'r1\t99\tc\t5\n', 'bad_flag': hdr + ok.replace('\t99\t', '\tx9\t'), 'bad_pos': hdr + ok.replace('\t5\t60', '\t-\t60'),
+        'huge_pos': hdr + ok.replace('\t5\t60', '\t99999999999999999999\t60'), 'star_fields': hdr + 'r1\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*\n',
+        'bad_cigar': hdr + ok.replace('4M', '4'), 'cigar_no_len': hdr + ok.replace('4M', 'M'), 'odd_op': hdr + ok.replace('4M', '2M2Z'),
+        'huge_cigar_len': hdr + ok.replace('4M', '99999999999M'), 'many_ops': hdr + ok.replace('4M', '1M1I' * 5000),
+        'empty_tags': hdr + 'r1\t0\tc\t1\t0\t1M\t*\t0\t0\tA\tI\tRG:Z:\tOQ:Z:\tXX\t\t\n', 'unknown_rg': hdr + ok.replace('RG:Z:a', 'RG:Z:zz'),
+        'blank_lines': hdr + '\n\n' + ok + '\n   \n', 'binary': hdr + 'r\x00\t1\tc\x01\t1\t0\t1M\t*\t0\t0\t\xff\t\xfe\n',
+        'long_seq': hdr + 'r1\t0\tc\t1\t0\t70000M\t*\t0\t0\t' + 'A' * 70000 + '\t' + 'I' * 70000 + '\n',
+        'bam_magic': 'BAM\x01rest', 'tabs_only': '\t\t\t\t\t\t\t\t\t\t\t\n',
+    }
+    for name, text in cases.items():
+        harness('sam', _write(tmp_path / (name + '.sam'), text.encode('latin-1'), 'wb'))
+    harness('sam', str(tmp_path / 'missing.sam'))

@@ -205,3 +205,40 @@ def test_product_per_read_covariates_match_reference(oracle, name, tmp_path):
     reads = list(aln.AlignmentFile(paths['sam']))
     assert np.array_equal(np.concatenate([bqsr.bamread_bqsr_cycle(r) for r in reads]), gold['cycle'])
     assert np.array_equal(np.concatenate([bqsr.bamread_bqsr_dinuc(r) for r in reads]), gold['dinuc'])
+
+
+def test_native_sam_arrays_match_stand_ins(oracle, tmp_path):
+    """aln.AlignmentFile.batch(): the native SAM reader's arrays against the independent stand-in reader."""
+    import _shim
+    from kbbq import aln
+    for name in ('bqsr_a', 'bqsr_b'):
+        _, _, paths = _inputs(name, tmp_path, oracle)
+        ref = list(_shim.AlignmentFile(paths['sam']))
+        b = aln.AlignmentFile(paths['sam']).batch()
+        assert b.n == len(ref)
+        assert np.array_equal(b.flag, [r.flag for r in ref]) and np.array_equal(b.pos, [r.reference_start for r in ref])
+        assert np.array_equal(b.pnext, [r.next_reference_start for r in ref]) and np.array_equal(b.tlen, [r.tlen for r in ref])
+        assert np.array_equal(b.qlen, [r.query_length for r in ref])
+        assert np.array_equal(b.ref_span, [r.reference_end - r.reference_start for r in ref])
+        assert np.array_equal(b.clip & 0xFFFF, [r.query_alignment_start for r in ref])
+        assert np.array_equal(b.clip >> 16, [r.query_alignment_end for r in ref])
+        assert [b.contig_names[c] for c in b.contig] == [r.reference_name for r in ref]
+        assert [b.rg_ids[g] for g in b.rg] == [r.get_tag('RG') for r in ref]
+        ops = [[(int(x) & 15, int(x) >> 4) for x in b.cigar[o:o + m]] for o, m in zip(b.cig_off, b.cig_n)]
+        assert ops == [list(r.cigartuples) for r in ref]
+        S = int(b.qlen[0])
+        pitch = (S + 15) // 16 * 16
+        for which, get in ((0, lambda r: r.query_sequence), (2, lambda r: r.get_tag('OQ'))):
+            plane = b.plane(which, pitch)
+            assert all(bytes(plane[i, :S]).decode() == get(ref[i]) for i in range(b.n)) and not plane[:, S:].any()
+        assert np.array_equal(b.qual_len, b.qlen) and np.array_equal(b.oq_len, b.qlen)
+        assert b.names() == [r.query_name for r in ref]
+    # malformed lines are a ValueError, as for the object reader; binary BAM is refused
+    bad = tmp_path / 'bad.sam'
+    bad.write_text('@HD\tVN:1.6\nr1\t0\tc\t1\n')
+    with pytest.raises(ValueError):
+        aln.AlignmentFile(str(bad))
+    bam = tmp_path / 'x.bam'
+    bam.write_bytes(b'BAM\x01....')
+    with pytest.raises(NotImplementedError):
+        aln.AlignmentFile(str(bam))
