@@ -26,6 +26,32 @@ __global__ __launch_bounds__(512) void blocked(const uint4* a, const uint4* b, u
     }
 }
 
+// the blocked traversal with non-temporal (streaming) loads and / or stores
+template <bool NTL, bool NTS>
+__global__ __launch_bounds__(512) void blocked_nt(const uint4* a, const uint4* b, uint4* c, long long nkib, int blk)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const long long nblocks = nkib / blk;
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    auto ld = [](const uint4* p) {
+        if (!NTL) return *p;
+        const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    for (long long B = (long long)blockIdx.x * nw + wave; B < nblocks; B += (long long)gridDim.x * nw) {
+        const long long base = B * blk * 64 + lane;
+        uint4 x = ld(a + base), y = ld(b + base);
+        for (int s = 0; s < blk; ++s) {
+            uint4 nx = x, ny = y;
+            if (s + 1 < blk) { nx = ld(a + base + (s + 1) * 64); ny = ld(b + base + (s + 1) * 64); }
+            const uint4 r = make_uint4(x.x ^ y.x, x.y ^ y.y, x.z ^ y.z, x.w ^ y.w);
+            if (NTS) { v4u v; v.x = r.x; v.y = r.y; v.z = r.z; v.w = r.w; __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(c + base + s * 64)); }
+            else c[base + s * 64] = r;
+            x = nx; y = ny;
+        }
+    }
+}
+
 __global__ __launch_bounds__(512) void flat(const uint4* a, const uint4* b, uint4* c, long long nkib, int)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -116,6 +142,34 @@ __global__ __launch_bounds__(512) void flat_sync(const uint4* a, const uint4* b,
     }
 }
 
+// non-persistent: one wave per `parts` KiB taken far apart (B, B + n/parts, ...): several loop iterations per
+// wave but no contiguous footprint beyond 1 KiB
+__global__ __launch_bounds__(256) void tile_far(const uint4* a, const uint4* b, uint4* c, long long nkib, int parts)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const long long per = nkib / parts;
+    const long long B = (long long)blockIdx.x * nw + wave;
+    if (B >= per) return;
+    for (int s = 0; s < parts; ++s) {
+        const long long base = (B + s * per) * 64 + lane;
+        const uint4 x = a[base], y = b[base];
+        c[base] = make_uint4(x.x ^ y.x, x.y ^ y.y, x.z ^ y.z, x.w ^ y.w);
+    }
+}
+
+// non-persistent, one wave per `blk` contiguous KiB, one KiB at a time (load, load, store; no loads up front)
+__global__ __launch_bounds__(256) void tile_seq(const uint4* a, const uint4* b, uint4* c, long long nkib, int blk)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const long long B = (long long)blockIdx.x * nw + wave;
+    if (B * blk >= nkib) return;
+    for (int s = 0; s < blk; ++s) {
+        const long long base = (B * blk + s) * 64 + lane;
+        const uint4 x = a[base], y = b[base];
+        c[base] = make_uint4(x.x ^ y.x, x.y ^ y.y, x.z ^ y.z, x.w ^ y.w);
+    }
+}
+
 int main(int argc, char** argv)
 {
     const long long nkib = 20000000LL * 160 / 1024 / 80 * 80;       // the 20 M x 160 B planes of scripts/time_kernels.py
@@ -138,6 +192,10 @@ int main(int argc, char** argv)
         snprintf(nm, sizeof nm, "blocked blk=%d KiB, %d x 512 thr per CU", blk, per_cu);
         run(nm, [&] { hipLaunchKernelGGL(blocked, dim3(cus * per_cu), dim3(512), 0, 0, a, b, c, nkib, blk); });
     }
+    run("blocked blk=10, non-temporal loads", [&] { hipLaunchKernelGGL((blocked_nt<true, false>), dim3(cus * 2), dim3(512), 0, 0, a, b, c, nkib, 10); });
+    run("blocked blk=10, non-temporal stores", [&] { hipLaunchKernelGGL((blocked_nt<false, true>), dim3(cus * 2), dim3(512), 0, 0, a, b, c, nkib, 10); });
+    run("blocked blk=10, non-temporal loads + stores", [&] { hipLaunchKernelGGL((blocked_nt<true, true>), dim3(cus * 2), dim3(512), 0, 0, a, b, c, nkib, 10); });
+    run("blocked blk=10, plain (same template)", [&] { hipLaunchKernelGGL((blocked_nt<false, false>), dim3(cus * 2), dim3(512), 0, 0, a, b, c, nkib, 10); });
     // the same kernel launched NON-persistently: one wave per block, grid covers everything
     for (int thr : {256, 512}) for (int blk : {2, 10}) {
         snprintf(nm, sizeof nm, "blocked blk=%d KiB, non-persistent grid, %d thr", blk, thr);
@@ -168,6 +226,14 @@ int main(int argc, char** argv)
     for (int per_cu : {2, 4}) {
         snprintf(nm, sizeof nm, "flat + barrier per step, %d x 512 thr per CU", per_cu);
         run(nm, [&] { hipLaunchKernelGGL(flat_sync, dim3(cus * per_cu), dim3(512), 0, 0, a, b, c, nkib, 0); });
+    }
+    for (int parts : {2, 4, 8}) {
+        snprintf(nm, sizeof nm, "tile: wave takes %d far-apart KiB", parts);
+        run(nm, [&] { hipLaunchKernelGGL(tile_far, dim3((unsigned)((nkib / parts + 3) / 4)), dim3(256), 0, 0, a, b, c, nkib, parts); });
+    }
+    for (int blk : {2, 4, 8}) {
+        snprintf(nm, sizeof nm, "tile: wave per %d contiguous KiB, one at a time", blk);
+        run(nm, [&] { hipLaunchKernelGGL(tile_seq, dim3((unsigned)((nkib / blk + 3) / 4)), dim3(256), 0, 0, a, b, c, nkib, blk); });
     }
     for (int blk : {1, 2, 4, 8}) {
         snprintf(nm, sizeof nm, "tile: wave per %d KiB, non-persistent", blk);
