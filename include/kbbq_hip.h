@@ -306,6 +306,7 @@ int kbbq_sam_cigar(const kbbq_sam* f, uint32_t* ops);
 int kbbq_sam_fill(const kbbq_sam* f, int64_t first, int64_t n, int pitch, int which, uint8_t* plane);
 int kbbq_sam_text(const kbbq_sam* f, int what, int64_t i, const char** p, int64_t* len);
 
+
 /* ---- host FASTQ ingest / egress (no GPU) ----------------------------------
  * Replaces, for this path, pysam.FastxFile iteration (recalibrate.py:56-57,141-142),
  * the name parsing of compare_reads.py:304-318 / recalibrate.py:59-64 and the print()
@@ -330,6 +331,9 @@ int         kbbq_fastq_fill(const kbbq_fastq* a, const kbbq_fastq* b, int infer_
 /* the same for reads [first, first + n) -> rows [0, n): one rank's shard; read-group ids are those of the scan */
 int kbbq_fastq_fill_range(const kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t first, int64_t n, int pitch,
                           uint8_t* seq, uint8_t* cseq, uint8_t* qual, uint32_t* meta);
+/* benchmark.py:102-124: idx[i] = the alignment whose QNAME + "/1"|"/2" equals the name of FASTQ read i up to its
+ * first '_' (the last such alignment), -1 if none.                                                   */
+int         kbbq_sam_match_fastq(const kbbq_sam* f, const kbbq_fastq* fq, int64_t* idx);
 int64_t     kbbq_fastq_format(const kbbq_fastq* a, int64_t first, int64_t n, int pitch,
                               const uint8_t* newqual, char* out, int64_t cap);
 

@@ -366,4 +366,33 @@ int kbbq_sam_text(const kbbq_sam* f, int what, int64_t i, const char** p, int64_
     return KBBQ_OK;
 }
 
+// benchmark.py:102-124: FASTQ reads are matched to alignments by name -- the FASTQ name up to its first '_'
+// against QNAME + "/1" | "/2" (second-in-pair flag); of several alignments with one name the LAST wins (a dict
+// in the reference).  idx[i] = alignment of FASTQ read i, or -1 (the reference's KeyError).
+int kbbq_sam_match_fastq(const kbbq_sam* f, const kbbq_fastq* fq, int64_t* idx)
+{
+    if (!f || !fq) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_sam_match_fastq: NULL argument");
+    const int64_t n = kbbq_fastq_count(fq);
+    if (n > 0 && !idx) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_sam_match_fastq: NULL argument");
+    std::unordered_map<std::string, int64_t> row;
+    const int64_t na = (int64_t)f->line0.size();
+    row.reserve((size_t)na * 2);
+    for (int64_t i = 0; i < na; ++i) {
+        std::string key((const char*)f->buf + f->line0[i], f->name_len[i]);
+        key += (f->flag[i] & 128) ? "/2" : "/1";
+        row[key] = i;
+    }
+    par_for(n, threads_for((size_t)n * 64), [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const char* p = nullptr; int len = 0;
+            if (kbbq_fastq_name(fq, i, &p, &len) != KBBQ_OK) { idx[i] = -1; continue; }
+            const void* us = memchr(p, '_', (size_t)len);
+            if (us) len = (int)((const char*)us - p);
+            auto it = row.find(std::string(p, (size_t)len));
+            idx[i] = it == row.end() ? -1 : it->second;
+        }
+    });
+    return KBBQ_OK;
+}
+
 }  // extern "C"

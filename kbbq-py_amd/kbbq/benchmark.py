@@ -142,6 +142,18 @@ def _flag_batch(reads, genome, flip_reverse, keep=None):
     return err, skip, lens, pitch
 
 
+def _match_native(bam, fq):
+    """Row of the alignment for every FASTQ read (benchmark.py:102-124), matched in C++."""
+    from . import _native as N
+    n = fq.n
+    idx = np.zeros(max(n, 1), dtype=np.int64)
+    N.check(N.load().kbbq_sam_match_fastq(bam.batch()._handle.h, fq._h, N.ptr(idx)))
+    idx = idx[:n]
+    if n and int(idx.min()) < 0:
+        raise KeyError(fq.name(int(np.flatnonzero(idx < 0)[0])).split('_')[0])
+    return idx
+
+
 def _bam_names(reads):
     """Canonical read names (benchmark.py:41-48): QNAME + /1 or /2."""
     if isinstance(reads, aln.AlignmentFile):
@@ -263,11 +275,14 @@ def benchmark_fastq(fqfile, bamfile, ref, var_sites, bedfh=None):
     fullskips = get_full_skips(ref, var_sites, bedfh)
     reads = bamfile if isinstance(bamfile, aln.AlignmentFile) else list(bamfile)
     err, skip, lens, pitch = _flag_batch(reads, _Genome(ref, fullskips), flip_reverse=True)
-    row = {}
-    for i, name in enumerate(_bam_names(reads)):
-        row[name] = i                                                # later reads replace earlier ones (dict)
     fq = fastx.NativeFastq(fqfile)
-    idx = np.array([row[fq.name(i).split('_')[0]] for i in range(fq.n)], dtype=np.int64)   # KeyError if absent
+    if isinstance(reads, aln.AlignmentFile):
+        idx = _match_native(reads, fq)                               # both sides native: no Python object per read
+    else:
+        row = {}
+        for i, name in enumerate(_bam_names(reads)):
+            row[name] = i                                            # later reads replace earlier ones (dict)
+        idx = np.array([row[fq.name(i).split('_')[0]] for i in range(fq.n)], dtype=np.int64)   # KeyError if absent
     n, S, _, kind, bad = fq.scan(None, False)
     _, _, fqual, fmeta = fq.fill(None, False, fq.n, max(pitch, fastx.pitch_for(S)))
     flens = (fmeta & 0xFFFF).astype(np.uint32)
