@@ -27,6 +27,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 extern "C" const char* kbbq_last_error(void);
 int kbbq_set_error_(int code, const char* msg);      // defined in kbbq_hip.hip
@@ -72,13 +73,34 @@ int kbbq_fastq_open(const char* path, kbbq_fastq** out)
     if (fstat(fd, &st) != 0) { close(fd); return kbbq_set_error_(KBBQ_E_ARG, "fstat failed"); }
     kbbq_fastq* f = new kbbq_fastq();
     f->size = (size_t)st.st_size;
-    if (f->size) {
-        void* m = mmap(nullptr, f->size, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (m == MAP_FAILED) { close(fd); delete f; return kbbq_set_error_(KBBQ_E_ARG, "mmap failed"); }
-        f->buf = (const uint8_t*)m; f->mapped = true;
-        madvise(m, f->size, MADV_SEQUENTIAL);
+    unsigned char magic[2] = {0, 0};
+    const bool gz = f->size >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    if (gz) {
+        // gzip / bgzip (what pysam.FastxFile reads transparently): inflate all members into memory
+        gzFile g = gzdopen(fd, "rb");
+        if (!g) { close(fd); delete f; return kbbq_set_error_(KBBQ_E_ARG, "gzdopen failed"); }
+        gzbuffer(g, 1 << 20);
+        size_t cap = std::max<size_t>(f->size * 4, 1 << 20), used = 0;
+        uint8_t* mem = (uint8_t*)malloc(cap);
+        for (;;) {
+            if (!mem) { gzclose(g); delete f; return kbbq_set_error_(KBBQ_E_ARG, "out of memory while inflating"); }
+            const int got = gzread(g, mem + used, (unsigned)std::min<size_t>(cap - used, 1u << 30));
+            if (got < 0) { free(mem); gzclose(g); f->size = 0; delete f; return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": corrupt gzip stream").c_str()); }
+            if (got == 0) break;
+            used += (size_t)got;
+            if (used == cap) { cap *= 2; mem = (uint8_t*)realloc(mem, cap); }
+        }
+        gzclose(g);                                  // closes fd
+        f->buf = mem; f->size = used; f->mapped = false;
+    } else {
+        if (f->size) {
+            void* m = mmap(nullptr, f->size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { close(fd); delete f; return kbbq_set_error_(KBBQ_E_ARG, "mmap failed"); }
+            f->buf = (const uint8_t*)m; f->mapped = true;
+            madvise(m, f->size, MADV_SEQUENTIAL);
+        }
+        close(fd);
     }
-    close(fd);
     // line starts, in parallel: each thread scans a byte range for '\n'
     const unsigned nt = nthreads_for(f->size);
     std::vector<std::vector<uint64_t>> parts(nt);

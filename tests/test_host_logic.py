@@ -383,3 +383,24 @@ def test_sharded_packing_concatenates_to_the_whole(oracle, tmp_path):
                    for p in parts)
         singles = [fastx.pack_single(whole['text'], True, shard=(r, world)) for r in range(world)]
         assert np.array_equal(np.concatenate([p['qual'] for p in singles]), whole['qual'])
+
+
+def test_gzip_fastq_is_read_like_plain_text(oracle, tmp_path):
+    """pysam.FastxFile reads .gz transparently; so does the native reader (zlib, all gzip members)."""
+    import gzip
+    n = 400
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 8, 20, 90, 2)
+    names = oracle.synth_names(0, n, 2, with_rg=True)
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, names, cseq, qual, meta)
+    want = fastx.pack_pair(fa, fb, True)
+    for p in (fa, fb):
+        data = open(p, 'rb').read()
+        with open(p + '.gz', 'wb') as fh:                     # two concatenated members, as bgzip-style writers produce
+            fh.write(gzip.compress(data[:len(data) // 2]) + gzip.compress(data[len(data) // 2:]))
+    got = fastx.pack_pair(fa + '.gz', fb + '.gz', True)
+    assert got['n'] == want['n'] == n and got['rg_to_int'] == want['rg_to_int']
+    for k in ('seq', 'cseq', 'qual', 'meta'):
+        assert np.array_equal(got[k], want[k]), k
+    assert got['text'].format(0, n, got['qual']) == open(fa, 'rb').read()

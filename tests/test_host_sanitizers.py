@@ -17,7 +17,7 @@ def harness(tmp_path_factory):
     csrc = os.path.join(ROOT, 'kbbq-py_amd', 'csrc')
     cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-pthread',
            '-o', exe, os.path.join(ROOT, 'tests', 'native', 'host_sanitize.cpp'),
-           os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'solve_host.cpp'), os.path.join(csrc, 'sam_host.cpp')]
+           os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'solve_host.cpp'), os.path.join(csrc, 'sam_host.cpp'), '-lz']
     subprocess.check_call(cmd)
 
     def run(*args):
@@ -73,6 +73,16 @@ def test_malformed_inputs_do_not_touch_memory_they_do_not_own(harness, tmp_path)
             harness('pair', p, good, infer)
             harness('pair', good, p, infer)
     harness('pair', str(tmp_path / 'does_not_exist.fq'), '-', '0')
+    # gzip input, intact / truncated / garbage after the magic
+    import gzip
+    good_text = open(good, 'rb').read() * 500
+    gz = tmp_path / 'good.fq.gz'
+    with gzip.open(gz, 'wb') as fh:
+        fh.write(good_text)
+    assert 'scan rc=0 n=1000' in harness('pair', str(gz), str(gz), '1')
+    raw = open(gz, 'rb').read()
+    harness('pair', _write(tmp_path / 'cut.fq.gz', raw[:len(raw) // 2], 'wb'), '-', '0')
+    harness('pair', _write(tmp_path / 'junk.fq.gz', b'\x1f\x8b' + b'\x00' * 50, 'wb'), '-', '0')
 
 
 def test_gammaln_pool(harness):
