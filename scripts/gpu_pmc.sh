@@ -1,5 +1,5 @@
-# usage (on the GPU box): bash scripts/gpu_pmc.sh TAG  -- PMC passes for K1/K2 (counters in their own runs)
-TAG=${1:-pmc}
+# usage (on the GPU box): bash scripts/gpu_pmc.sh TAG [--pairs] -- PMC passes for K1/K2 (counters in their own runs)
+TAG=${1:-pmc}; shift
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
@@ -11,7 +11,7 @@ for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $SET -d $OUT/p$i -o p$i --output-format csv -- python $R/scripts/prof_kernels.py --reads 20000000 --reps 2 > $OUT/p$i.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $SET -d $OUT/p$i -o p$i --output-format csv -- python $R/scripts/prof_kernels.py --reads 20000000 --reps 2 "$@" > $OUT/p$i.log 2>&1
   echo "pass $i ($SET) rc=$?"
 done
-ls $OUT/*/ | head -40
+python $R/scripts/pmc_summary.py $OUT
