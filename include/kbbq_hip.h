@@ -113,6 +113,13 @@ int kbbq_accumulate_ex_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d
                            const uint8_t* d_qual, const uint32_t* d_meta,
                            int64_t nreads, int pitch, int R, int S2, int minscore,
                            int dinuc_minscore, int64_t* d_tables);
+/* The same for ONE LENGTH BAND of a mixed-length input: S2 sizes the (global) count tables as before, S_band >= the
+ * longest read of THIS batch (0 = S2 / 2) sizes the kernel's LDS tables, so that short reads packed at a narrow pitch
+ * use the table-driven kernel even when the input's longest read would not fit it.  Counts land in the same cells
+ * (a second-in-pair column 2*len - 1 - i does not depend on the table width).                                     */
+int kbbq_accumulate_band_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
+                             const uint32_t* d_meta, int64_t nreads, int pitch, int R, int S2, int S_band,
+                             int minscore, int dinuc_minscore, int64_t* d_tables);
 int kbbq_accumulate(kbbq_ctx* ctx, const uint8_t* seq, const uint8_t* cseq,
                     const uint8_t* qual, const uint32_t* meta,
                     int64_t nreads, int pitch, int R, int S2, int minscore,
@@ -277,7 +284,8 @@ int    kbbq_apply_pairs_dev(kbbq_ctx* ctx, const uint8_t* d_pseq, const uint8_t*
  * The fast apply LUT must be range-safe (blob flags 0); rows it cannot serve are reported (KBBQ_E_LUT).  */
 int    kbbq_accumulate_grouped_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                                    const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2,
-                                   int minscore, int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables);
+                                   int S_band, int minscore, int dinuc_minscore, const int64_t* d_seg,
+                                   int64_t* d_tables);      /* S_band as in kbbq_accumulate_band_dev (0 with pairs) */
 int    kbbq_apply_grouped_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta,
                               int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
                               const void* d_lut_blob, const void* d_pair_lut, const int64_t* d_seg, uint8_t* d_out);

@@ -289,12 +289,20 @@ int kbbq_accumulate_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq
 
 static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                            const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
-                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits);
+                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band = 0);
 
 int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq,
                            const uint8_t* d_qual, const uint32_t* d_meta,
                            int64_t nreads, int pitch, int R, int S2, int minscore,
                            int dinuc_minscore, int64_t* d_tables)
+{
+    return kbbq_accumulate_band_dev(c, d_seq, d_cseq, d_qual, d_meta, nreads, pitch, R, S2, 0, minscore, dinuc_minscore, d_tables);
+}
+
+int kbbq_accumulate_band_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq,
+                             const uint8_t* d_qual, const uint32_t* d_meta,
+                             int64_t nreads, int pitch, int R, int S2, int S_band, int minscore,
+                             int dinuc_minscore, int64_t* d_tables)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
     int rc = check_planes("kbbq_accumulate_dev", nreads, pitch, d_seq, d_cseq, d_qual);
@@ -312,7 +320,7 @@ int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_c
     if (!(force && !strcmp(force, "v1"))) {
         bool fits = false;
         rc = accumulate_rows(c, "kbbq_accumulate_dev", d_seq, d_cseq, d_qual, d_meta, nreads, pitch, 0, R, S2, minscore,
-                             dinuc_minscore, nullptr, d_tables, &fits);
+                             dinuc_minscore, nullptr, d_tables, &fits, S_band);
         if (rc || fits) return rc;                      // launched (or a real error); otherwise the tables do not fit the LDS
     }
     K1Params p;
@@ -657,9 +665,10 @@ int kbbq_unpack_pairs_dev(kbbq_ctx* c, const uint8_t* d_pplane, int64_t npairs, 
 // K1 (table-driven kernel) on one-read-per-row or mate-pair rows, optionally grouped by read group
 static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                            const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
-                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits)
+                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band)
 {
     if (fits) *fits = true;
+    if (S_band < 0 || S_band > S2 / 2 || (pairs && S_band)) return fail(KBBQ_E_ARG, "%s: S_band out of range (%d)", who, S_band);
     int rc = check_planes(who, nrows, pitch, d_seq, d_cseq, d_qual);
     if (rc) return rc;
     if (R <= 0 || R > 32767) return fail(KBBQ_E_ARG, "%s: R out of range (%d)", who, R);
@@ -669,11 +678,11 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     if (pairs && pitch != pair_pitch(S2)) return fail(KBBQ_E_ARG, "%s: mate-pair rows of %d-base reads have pitch %d, not %d", who, S2 / 2, pair_pitch(S2), pitch);
     if (nrows == 0) return KBBQ_OK;
     HIPCHK(hipSetDevice(c->device));
-    const int S = S2 / 2;
+    const int S = S_band ? S_band : S2 / 2;          // the LDS tables are laid out for the longest read of THIS batch
     K1v3Params q;
     q.seq = d_seq; q.cseq = d_cseq; q.qual = d_qual; q.meta = d_meta;
     q.nreads = nrows; q.pitch = pitch; q.cpr = pitch / 16; q.cpr_magic = magic_for(q.cpr);
-    q.R = R; q.S = S; q.minscore = minscore; q.type_minscore = dinuc_minscore;
+    q.R = R; q.S = S; q.gS2 = S2; q.minscore = minscore; q.type_minscore = dinuc_minscore;
     q.qlo_m1 = 32u + (u32)minscore; q.dlo = 33u + (u32)dinuc_minscore;
     q.nrows = KQ + 1 - minscore;
     q.row_bytes = (u32)((3 * S) | 1) * 4u;
@@ -713,13 +722,13 @@ int kbbq_accumulate_pairs_dev(kbbq_ctx* c, const uint8_t* d_pseq, const uint8_t*
 }
 
 int kbbq_accumulate_grouped_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
-                                const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
-                                int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables)
+                                const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int S_band,
+                                int minscore, int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
     if (!d_seg) return fail(KBBQ_E_ARG, "kbbq_accumulate_grouped_dev: d_seg is NULL");
     return accumulate_rows(c, "kbbq_accumulate_grouped_dev", d_seq, d_cseq, d_qual, d_meta, nrows, pitch, pairs ? 1 : 0,
-                           R, S2, minscore, dinuc_minscore, d_seg, d_tables, nullptr);
+                           R, S2, minscore, dinuc_minscore, d_seg, d_tables, nullptr, S_band);
 }
 
 int kbbq_pair_lut_dev(kbbq_ctx* c, const void* d_lut_blob, int R, int S2, int minscore, void* d_pair_lut)

@@ -48,6 +48,9 @@ struct K1v3Params {
     int dn_flush_iters;         // workgroup iterations between flushes of the (16-bit packed) context table
     int maxlen;                 // longest row the tables take: S, or 2S + 1 for mate-pair rows
     int gap;                    // mate-pair rows: 1 (the separator byte between the mates), else 0
+    int gS2;                    // columns of the GLOBAL cycle tables (2 x the longest read of the whole input); S may be
+                                // smaller -- the longest read of THIS batch -- because a second-in-pair column
+                                // 2*len-1-i does not depend on the S the LDS table is laid out for
     const long long* seg;       // rows grouped by read group: slice g owns rows [seg[g], seg[g + 1]); NULL: every slice scans all rows
     u64* tables; u64* status;
 };
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
     const int dk2 = 128 / p.cpr, dj2 = 128 - dk2 * p.cpr;
 
     u64* pos_errs = p.tables;
-    u64* pos_total = p.tables + (size_t)p.R * KQ * S2;
-    u64* dn_errs = p.tables + 2 * (size_t)p.R * KQ * S2;
+    u64* pos_total = p.tables + (size_t)p.R * KQ * p.gS2;
+    u64* dn_errs = p.tables + 2 * (size_t)p.R * KQ * p.gS2;
     u64* dn_total = dn_errs + (size_t)p.R * KQ * KND;
 
     auto flush_dn = [&]() {
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
     auto flush_pos = [&]() {
         for (int r = wave; r < p.nrows - 1; r += nwaves) {
             const int q = KQ - 1 - r;
-            const size_t grow = ((size_t)g * KQ + q) * S2;
+            const size_t grow = ((size_t)g * KQ + q) * p.gS2;
             u32* prow = pos + (size_t)r * (row_bytes >> 2);
             for (int x = lane; x < 3 * S; x += 64) {
                 const u32 v = prow[x];

@@ -218,8 +218,10 @@ def ungroup(batch, plane):
 _pair_luts = {}
 
 
-def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None):
-    """K1 over a device batch, adding into `tables` (recalibrate.py:57-119)."""
+def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None, s_band=0):
+    """K1 over a device batch, adding into `tables` (recalibrate.py:57-119).  s_band: the longest read of THIS batch
+    when it is one length band of a mixed-length input (its rows packed at a narrower pitch than the tables' S):
+    the kernel's LDS tables are then laid out for s_band instead of tables.S2 / 2."""
     ctx = context(batch.seq.device.index)
     if getattr(batch, 'seg', None) is not None:
         pairs = isinstance(batch, PairBatch)
@@ -227,7 +229,7 @@ def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None
             raise ValueError('mate-pair rows of %d-base reads need tables with 2S = %d columns' % (batch.S, 2 * batch.S))
         N.check(N.load().kbbq_accumulate_grouped_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual),
                                                      N.ptr(batch.meta), batch.n, batch.pitch, 1 if pairs else 0,
-                                                     tables.R, tables.S2, minscore,
+                                                     tables.R, tables.S2, 0 if pairs else int(s_band), minscore,
                                                      minscore if dinuc_minscore is None else dinuc_minscore,
                                                      N.ptr(batch.seg), N.ptr(tables.buf)))
         if check:
@@ -243,9 +245,9 @@ def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None
         if check:
             ctx.status()
         return
-    N.check(N.load().kbbq_accumulate_ex_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq),
+    N.check(N.load().kbbq_accumulate_band_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq),
                                             N.ptr(batch.qual), N.ptr(batch.meta), batch.n, batch.pitch,
-                                            tables.R, tables.S2, minscore,
+                                            tables.R, tables.S2, int(s_band), minscore,
                                             minscore if dinuc_minscore is None else dinuc_minscore,
                                             N.ptr(tables.buf)))
     if check:

@@ -283,3 +283,52 @@ def test_randomised_layout_sweep_against_the_oracle(dev, oracle):
             got_q = out[:n].cpu().numpy()
             assert np.array_equal(got_q[:, :S].astype(np.int32) - 33, want_q[:, :S]), (S, nrg, name)   # the oracle returns raw qualities
             assert not got_q[:, S:].any()
+
+
+def test_length_bands_of_a_mixed_length_input(dev, oracle):
+    """Reads of 36..300 bases in ascending order (the only order the reference accepts), tallied and
+    applied band by band at each band's own pitch -- the table-driven K1 laid out for the band's longest read --
+    give the tables and qualities of the whole batch at the widest pitch."""
+    import torch
+    n, nrg = 6000, 2
+    b = dev.ReadBatch.synthetic(0, n, n, seed=5, len_lo=36, len_hi=300, nrg=nrg)
+    S = 300
+    meta = b.meta[:n].cpu().numpy().view(np.uint32)
+    lens = (meta & 0xFFFF).astype(np.int64)
+    assert (np.diff(lens) >= 0).all() and lens.max() == S
+    whole = dev.Tables(nrg, 2 * S); dev.accumulate(b, whole)
+    lut, shape, _, _ = dev.solve(whole)
+    want = dev.apply(b, lut, shape)[:n].cpu().numpy()
+    host = [x[:n].cpu().numpy() for x in (b.seq, b.cseq, b.qual)]
+    banded = dev.Tables(nrg, 2 * S)
+    outs = []
+    edges = [0] + [int(np.searchsorted(lens, c, side='right')) for c in (48, 64, 96, 128, 160, 208, 256)] + [n]
+    used = 0
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        if hi <= lo:
+            continue
+        smax = int(lens[lo:hi].max())
+        pitch = (smax + 15) // 16 * 16
+        band = dev.ReadBatch.from_host(np.ascontiguousarray(host[0][lo:hi, :pitch]), np.ascontiguousarray(host[2][lo:hi, :pitch]),
+                                       meta[lo:hi], cseq=np.ascontiguousarray(host[1][lo:hi, :pitch]))
+        for lay in (band, dev.group_by_rg(band, nrg)):
+            t = dev.Tables(nrg, 2 * S)
+            try:
+                dev.accumulate(lay, t, s_band=smax)
+            except dev.N.LutNeedsCheckedApply:
+                assert smax > 200 and lay is not band        # grouped rows have no first-generation fallback
+                continue
+            ref = dev.Tables(nrg, 2 * S)
+            dev.accumulate(band, ref)                         # the same band without the hint: first-generation kernel
+            assert torch.equal(t.buf, ref.buf), (lo, hi)
+        dev.accumulate(band, banded, s_band=smax)
+        out = dev.apply(band, lut, shape)[:hi - lo].cpu().numpy()
+        assert np.array_equal(out, want[lo:hi, :pitch]) and not want[lo:hi, pitch:].any()
+        used += 1
+    assert used >= 6 and torch.equal(banded.buf, whole.buf)
+    # a read longer than the band it was put in is reported, not mis-binned
+    t = dev.Tables(nrg, 2 * S)
+    short = dev.ReadBatch.from_host(np.ascontiguousarray(host[0][-8:, :304]), np.ascontiguousarray(host[2][-8:, :304]),
+                                    meta[-8:], cseq=np.ascontiguousarray(host[1][-8:, :304]))
+    with pytest.raises(IndexError):
+        dev.accumulate(short, t, s_band=150)
