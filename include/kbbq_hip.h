@@ -334,6 +334,7 @@ int         kbbq_fastq_name(const kbbq_fastq* f, int64_t i, const char** name, i
 int         kbbq_fastq_rg_count(const kbbq_fastq* f);
 const char* kbbq_fastq_rg_name(const kbbq_fastq* f, int i);
 int         kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* info5);
+int         kbbq_fastq_lengths(const kbbq_fastq* f, int64_t first, int64_t n, uint32_t* out);   /* sequence lengths */
 int         kbbq_fastq_fill(const kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t n, int pitch,
                             uint8_t* seq, uint8_t* cseq, uint8_t* qual, uint32_t* meta);
 /* the same for reads [first, first + n) -> rows [0, n): one rank's shard; read-group ids are those of the scan */

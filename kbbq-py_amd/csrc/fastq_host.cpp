@@ -257,6 +257,15 @@ int kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* i
 // Fill the padded planes for reads [0, n): seq / qual from `a`, cseq from `b` (b, cseq may be NULL).
 // Padding: 'N' in seq / cseq, 0 in qual (include/kbbq_hip.h).  Call kbbq_fastq_scan first (it
 // builds the read-group table used here).
+// sequence lengths of reads [first, first + n)
+int kbbq_fastq_lengths(const kbbq_fastq* f, int64_t first, int64_t n, uint32_t* out)
+{
+    if (!f || (n > 0 && !out) || first < 0 || n < 0 || first + n > (int64_t)f->h0.size())
+        return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_lengths: bad argument");
+    for (int64_t i = 0; i < n; ++i) out[i] = f->slen[first + i];
+    return KBBQ_OK;
+}
+
 int kbbq_fastq_fill(const kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t n, int pitch,
                     uint8_t* seq, uint8_t* cseq, uint8_t* qual, uint32_t* meta)
 {

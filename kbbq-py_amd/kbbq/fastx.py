@@ -280,6 +280,12 @@ class NativeFastq:
                                            1 if infer_rg_flag else 0, _N.ptr(info)))
         return [int(x) for x in info]
 
+    def lengths(self, first=0, n=None):
+        n = self.n - first if n is None else n
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        _N.check(_N.load().kbbq_fastq_lengths(self._h, first, n, _N.ptr(out)))
+        return out[:n]
+
     def fill(self, other, infer_rg_flag, n, pitch, first=0):
         """Planes and sidecar of reads [first, first + n) (rows 0..n-1)."""
         seq = np.empty((n, pitch), dtype=np.uint8)
@@ -319,6 +325,38 @@ _SCAN_ERRORS = {
 }
 
 
+# Row widths offered to the length bands of a mixed-length input: a read goes into the narrowest class that holds
+# it, so the bytes moved per read follow its own length instead of the longest read's (a 50-base read in a
+# 304-byte row costs 6x).  Few classes: every band is one kernel launch.
+BAND_CLASSES = (32, 48, 64, 96, 128, 160, 208, 256, 320, 400, 512, 768, 1024, 2048, 4096, 16384, 65536)
+
+
+def length_bands(lens, max_bands=16):
+    """[(lo, hi, longest)] -- maximal runs of reads whose lengths fall into one BAND_CLASSES class.  Valid inputs
+    have non-decreasing lengths, i.e. at most one run per class; anything with more than max_bands
+    runs is kept as one band."""
+    lens = np.asarray(lens, dtype=np.int64)
+    n = len(lens)
+    if n == 0:
+        return []
+    cls = np.searchsorted(np.asarray(BAND_CLASSES), np.maximum(lens, 1), side='left')
+    cuts = np.flatnonzero(np.diff(cls)) + 1
+    if len(cuts) + 1 > max_bands:
+        return [(0, n, int(lens.max()))]
+    edges = [0] + cuts.tolist() + [n]
+    return [(lo, hi, int(lens[lo:hi].max())) for lo, hi in zip(edges[:-1], edges[1:])]
+
+
+def _fill_bands(A, B, infer_rg_flag, lo, hi):
+    """Reads [lo, hi) packed band by band: [dict(first, n, S, pitch, seq, cseq, qual, meta)], `first` counted from lo."""
+    out = []
+    for b_lo, b_hi, longest in length_bands(A.lengths(lo, hi - lo)):
+        pitch = pitch_for(longest)
+        seq, cseq, qual, meta = A.fill(B, infer_rg_flag, b_hi - b_lo, pitch, first=lo + b_lo)
+        out.append(dict(first=b_lo, n=b_hi - b_lo, S=longest, pitch=pitch, seq=seq, cseq=cseq, qual=qual, meta=meta))
+    return out
+
+
 def _shard(n, shard):
     """Records [lo, hi) of this rank among n (pairs stay together), or everything."""
     if shard is None:
@@ -327,25 +365,29 @@ def _shard(n, shard):
     return shard_range(n, shard[0], shard[1])
 
 
-def pack_pair(path_a, path_b, infer_rg_flag, shard=None):
+def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False):
     """Pass-1 input (recalibrate.py:56-57) through the C++ packer; same dictionary as pack_pair_py
     except that `text` is the NativeFastq of file A and `names` is filled lazily by callers.
     shard = (rank, world): every rank scans the whole pair (so read-group ids, the longest read and
     the first host-detectable error are global) and packs only its own records [first, first + n);
-    `total` is the global number of usable reads."""
+    `total` is the global number of usable reads.  bands=True: instead of one set of planes at the widest pitch,
+    `bands` holds the reads packed by length band (length_bands), each at its own pitch."""
     A, B = NativeFastq(path_a), NativeFastq(path_b)
     total, S, R, kind, idx = A.scan(B, infer_rg_flag)
     pending = (idx, _SCAN_ERRORS[kind](idx), kind == 5) if kind else None
     pitch = pitch_for(S)
     lo, hi = _shard(total, shard)
-    seq, cseq, qual, meta = A.fill(B, infer_rg_flag, hi - lo, pitch, first=lo)
     rgs = A.rg_names()
-    return dict(seq=seq, cseq=cseq, qual=qual, meta=meta, n=hi - lo, first=lo, total=total, pitch=pitch, S=S, R=R,
-                rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)},
-                text=A, pending_error=pending)
+    common = dict(n=hi - lo, first=lo, total=total, pitch=pitch, S=S, R=R,
+                  rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)},
+                  text=A, pending_error=pending)
+    if bands:
+        return dict(common, bands=_fill_bands(A, B, infer_rg_flag, lo, hi))
+    seq, cseq, qual, meta = A.fill(B, infer_rg_flag, hi - lo, pitch, first=lo)
+    return dict(common, seq=seq, cseq=cseq, qual=qual, meta=meta)
 
 
-def pack_single(text, infer_rg_flag, shard=None):
+def pack_single(text, infer_rg_flag, shard=None, bands=False):
     """Pass-2 input: every read of file A with its own first-appearance RG map
     (recalibrate.py:141-148); shard = (rank, world) as in pack_pair."""
     total, S, R, kind, idx = text.scan(None, infer_rg_flag)
@@ -353,7 +395,10 @@ def pack_single(text, infer_rg_flag, shard=None):
         raise _SCAN_ERRORS[kind](idx)
     pitch = pitch_for(S)
     lo, hi = _shard(total, shard)
-    seq, _, qual, meta = text.fill(None, infer_rg_flag, hi - lo, pitch, first=lo)
     rgs = text.rg_names()
-    return dict(seq=seq, qual=qual, meta=meta, n=hi - lo, first=lo, total=total, pitch=pitch, S=S, R=R,
-                rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)})
+    common = dict(n=hi - lo, first=lo, total=total, pitch=pitch, S=S, R=R,
+                  rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)})
+    if bands:
+        return dict(common, bands=_fill_bands(text, None, infer_rg_flag, lo, hi))
+    seq, _, qual, meta = text.fill(None, infer_rg_flag, hi - lo, pitch, first=lo)
+    return dict(common, seq=seq, qual=qual, meta=meta)

@@ -38,40 +38,49 @@ def _vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore)
     return _solve.vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore)
 
 
-def _tally_local(packed, minscore, maxscore):
-    """K1 over this rank's packed reads -> device Tables (zero tables when the rank has no reads).
-    Uniform first/second pairs are tallied on mate-pair rows (5 % fewer bytes through HBM, identical
-    counts); anything that path reports is redone one read per row, which carries the reference's
-    exact error semantics."""
-    if maxscore != 42:
-        raise ValueError('the Q axis of the device tables is fixed at 43 (maxscore = 42)')
-    n = packed['n']
-    R, S = max(packed['R'], 0), packed['S']
-    packed['batch'] = packed['pairs'] = None
-    if R == 0 or S == 0:
-        return None
-    tables = dev.Tables(R, 2 * S)
-    if n == 0:
-        return tables
-    batch = dev.ReadBatch.from_host(packed['seq'][:n], packed['qual'][:n], packed['meta'][:n],
-                                    cseq=packed['cseq'][:n])
-    packed['batch'] = batch                  # still resident: pass 2 re-uses it when it covers file A
-    # device layouts that move fewer bytes / keep every lane busy (DESIGN.md section 2): mate-pair rows for uniform
-    # pairs, rows grouped by read group when there are several.  `packed['pairs']` names the laid-out batch.
+def _lay_out(batch, R, S):
+    """The device layout that moves the fewest bytes / keeps every lane busy for this batch:
+    mate-pair rows for uniform first/second pairs, rows grouped by read group when there are several.  None: the
+    batch stays as it is."""
     try:
         laid = dev.PairBatch.from_reads(batch) if dev.PairBatch.worthwhile(S, batch.pitch) else None
     except ValueError:
         laid = None                          # not uniform first/second pairs
     if R > 1:
         laid = dev.group_by_rg(laid if laid is not None else batch, R)
-    if laid is not None:
+    return laid
+
+
+def _tally_local(packed, minscore, maxscore):
+    """K1 over this rank's packed reads, length band by length band -> device Tables (zero tables when the rank has
+    no reads).  Each band is tallied in the layout _lay_out picks; whatever that path reports (bad input, a shape it
+    does not serve) is redone one read per row, which carries the reference's exact error semantics.  The read index
+    of a kernel-reported error is made relative to the rank's first read."""
+    if maxscore != 42:
+        raise ValueError('the Q axis of the device tables is fixed at 43 (maxscore = 42)')
+    R, S = max(packed['R'], 0), packed['S']
+    if R == 0 or S == 0:
+        return None
+    tables = dev.Tables(R, 2 * S)
+    for band in packed['bands']:
+        batch = dev.ReadBatch.from_host(band['seq'], band['qual'], band['meta'], cseq=band['cseq'])
+        band['batch'], band['laid'] = batch, None      # still resident: pass 2 re-uses them when it covers file A
+        laid = _lay_out(batch, R, band['S'])
         try:
-            dev.accumulate(laid, tables, minscore)
-            packed['pairs'] = laid
-            return tables
-        except (IndexError, TypeError, dev.N.LutNeedsCheckedApply):
-            tables.buf.zero_()               # bad input or an unsupported shape: the row-per-read kernel decides
-    dev.accumulate(batch, tables, minscore)
+            if laid is not None:
+                part = dev.Tables(R, 2 * S)
+                try:
+                    dev.accumulate(laid, part, minscore, s_band=band['S'])
+                    tables.buf += part.buf
+                    band['laid'] = laid
+                    continue
+                except (IndexError, TypeError, dev.N.LutNeedsCheckedApply):
+                    pass                     # bad input or an unsupported shape: the row-per-read kernel decides
+            dev.accumulate(batch, tables, minscore, s_band=band['S'])
+        except (IndexError, TypeError) as e:
+            if hasattr(e, 'read_index'):
+                e.read_index = band['first'] + max(e.read_index, 0)
+            raise
     return tables
 
 
@@ -93,7 +102,7 @@ def _tally(packed, minscore, maxscore):
 
 def _pack_and_tally(fastq, infer_rg, minscore, maxscore):
     world, rank = parallel.world_rank()
-    packed = fastx.pack_pair(fastq[0], fastq[1], infer_rg, shard=(rank, world) if world > 1 else None)
+    packed = fastx.pack_pair(fastq[0], fastq[1], infer_rg, shard=(rank, world) if world > 1 else None, bands=True)
     err = packed.get('pending_error')
     if err is not None:
         # the reference fails at the FIRST offending read: let the kernel look at the reads
@@ -171,7 +180,7 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
         text = fastx.NativeFastq(fastq[0])
         if text.n == 0:
             return
-        single = fastx.pack_single(text, infer_rg, shard)
+        single = fastx.pack_single(text, infer_rg, shard, bands=True)
         tables = load_model(gatkreport, single['rg_to_int'])
     else:
         packed, tables = _pack_and_tally(fastq, infer_rg, 6, 42)
@@ -185,33 +194,46 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
                 save_model(tables, packed['rg_to_int'], gatkreport)
             parallel.barrier()
     lut, shape, _, _ = dev.solve(tables)
-    pairs = None
+    R = shape[0]
     if packed is not None and packed['total'] == text.n:
         # pass 2 walks the same reads with the same first-appearance read groups (:141-148):
         # the planes of pass 1 are still on the device
-        batch, single, pairs = packed['batch'], packed, packed['pairs']
+        single = packed
     else:
         # file B was shorter (zip truncation), or the model came from a report: pass 2 covers
         # all of file A with its own first-appearance read groups
         if single is None:
-            single = fastx.pack_single(text, infer_rg, shard)
-        batch = dev.ReadBatch.from_host(single['seq'], single['qual'], single['meta']) if single['n'] else None
+            single = fastx.pack_single(text, infer_rg, shard, bands=True)
+        for band in single['bands']:
+            band['batch'] = dev.ReadBatch.from_host(band['seq'], band['qual'], band['meta'])
+            band['laid'] = _lay_out(band['batch'], R, band['S'])
 
-    def apply_shard():
-        out = None
-        if pairs is not None:
+    def apply_band(band):
+        laid, out = band.get('laid'), None
+        if laid is not None:
             try:
-                out = dev.apply(pairs, lut, shape)
-                if getattr(pairs, 'seg', None) is not None:
-                    out = dev.ungroup(pairs, out)
-                if isinstance(pairs, dev.PairBatch):
-                    out = pairs.unpack(out)
+                out = dev.apply(laid, lut, shape)
+                if getattr(laid, 'seg', None) is not None:
+                    out = dev.ungroup(laid, out)
+                if isinstance(laid, dev.PairBatch):
+                    out = laid.unpack(out)
             except dev.N.LutNeedsCheckedApply:
                 out = None                   # a LUT the fast kernel cannot serve: the checked row-per-read kernel
-        if out is None and batch is not None:
-            out = dev.apply(batch, lut, shape)
+        if out is None:
+            out = dev.apply(band['batch'], lut, shape)
         return out
-    out = _collective(apply_shard, single['first'])
+
+    def apply_shard():
+        outs = []
+        for band in single['bands']:
+            try:
+                outs.append(apply_band(band))
+            except (IndexError, TypeError, ValueError) as e:
+                if hasattr(e, 'read_index'):
+                    e.read_index = band['first'] + max(e.read_index, 0)
+                raise
+        return outs
+    outs = _collective(apply_shard, single['first'])
 
     # recalibrate.py:153-156: '@' + name, sequence, '+', qualities -- rendered by the C++ writer in
     # slabs, written through print() like the reference
@@ -219,15 +241,16 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
         import sys
         raw = getattr(sys.stdout, 'buffer', None)      # a text-only stdout (StringIO) gets print(), like the reference
         step = 1 << 20
-        for first in range(0, single['n'], step):
-            m = min(step, single['n'] - first)
-            newq = out[first:first + m].cpu().numpy()
-            rendered = text.format_array(single['first'] + first, m, newq)
-            if raw is not None:
-                sys.stdout.flush()
-                raw.write(memoryview(rendered))
-            else:
-                print(rendered.tobytes().decode('latin-1'), end='')
+        for band, out in zip(single['bands'], outs):
+            for first in range(0, band['n'], step):
+                m = min(step, band['n'] - first)
+                newq = out[first:first + m].cpu().numpy()
+                rendered = text.format_array(single['first'] + band['first'] + first, m, newq)
+                if raw is not None:
+                    sys.stdout.flush()
+                    raw.write(memoryview(rendered))
+                else:
+                    print(rendered.tobytes().decode('latin-1'), end='')
         sys.stdout.flush()
     parallel.in_rank_order(emit)
 

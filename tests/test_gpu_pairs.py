@@ -128,18 +128,23 @@ def test_product_fastq_path_takes_pair_rows_when_it_can(dev, oracle, tmp_path):
     from conftest import load_golden
     from kbbq import recalibrate
     from test_gpu_parity import VEC, _files
-    # c5cut: ragged lengths up to 300 bases (no pairs) and too long for the LDS tables of the table-driven K1:
-    # the first-generation kernel on plain rows takes over
+    # c5cut: ragged lengths 36..300 in ascending order: several length bands, each at its own pitch; no pairs; the
+    # bands up to 200 bases run the table-driven K1 (grouped by read group), the longest the first-generation kernel
     for name, expect in (('c1_10k_1rg', ('pairs', False)), ('c3cut_2k_8rg', ('pairs', True)),
                          ('c5cut_2k_mixed', None), ('q42_500_3rg', ('pairs', True))):
         info, gold = load_golden(name)
         d = tmp_path / name; d.mkdir()
         fa, fb = _files(oracle, info, d)
         packed, tables = recalibrate._pack_and_tally([fa, fb], info['case']['infer_rg'], 6, 42)
-        laid = packed['pairs']
+        bands = packed['bands']
         if expect is None:
-            assert laid is None, name
+            assert len(bands) >= 6 and [b['pitch'] for b in bands] == sorted(b['pitch'] for b in bands)
+            assert bands[0]['pitch'] <= 48 and bands[-1]['pitch'] == 304 and sum(b['n'] for b in bands) == packed['n']
+            assert all(not isinstance(b['laid'], dev.PairBatch) for b in bands)
+            assert all((b['laid'] is not None) == (b['S'] <= 200) for b in bands), [(b['S'], b['laid']) for b in bands]
         else:
+            assert len(bands) == 1
+            laid = bands[0]['laid']
             assert isinstance(laid, dev.PairBatch) and (getattr(laid, 'seg', None) is not None) == expect[1], name
         got = recalibrate._vectors_from_tables(*tables.to_host(), 42)
         for k, v in zip(VEC, got):
