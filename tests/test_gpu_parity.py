@@ -463,3 +463,59 @@ def test_large_batch_properties(dev):
     low = (b.qual < 39) | (b.qual == 0)
     assert torch.equal(out[low], b.qual[low])
     assert torch.equal(out[~low], b.qual[~low] + 5)
+
+
+def test_full_size_properties(dev):
+    """BASELINE config 2 in full (50 M x 2x150 bp, 7.5 G bases): size-independent properties of the tally and the
+    apply -- totals and per-quality / per-cycle marginals against independent torch reductions, the two device
+    layouts against each other, linearity over a split, the apply's pass-through and padding invariants."""
+    import torch
+    n, S = 50_000_000, 150
+    b = dev.ReadBatch.synthetic(0, n, n, seed=1, nrg=1)
+    t = dev.Tables(1, 2 * S)
+    dev.accumulate(b, t)
+    pe, pt, de, dt = t.views()
+    tot_valid = tot_err = 0
+    qhist = torch.zeros(43, dtype=torch.int64, device='cuda')
+    cyc1 = torch.zeros(S, dtype=torch.int64, device='cuda'); cyc2 = torch.zeros(S, dtype=torch.int64, device='cuda')
+    step = 2_000_000
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        q = b.qual[lo:hi, :S]
+        valid = q >= 33 + 6
+        err = (b.seq[lo:hi, :S] != b.cseq[lo:hi, :S]) & valid
+        tot_valid += int(valid.sum()); tot_err += int(err.sum())
+        qhist += torch.bincount((q[valid].to(torch.int64) - 33), minlength=43)
+        second = b.meta[lo:hi] < 0
+        cyc1 += valid[~second].sum(dim=0); cyc2 += valid[second].sum(dim=0)
+        del q, valid, err
+    assert int(pt.sum()) == tot_valid and int(pe.sum()) == tot_err and tot_err > 0
+    assert torch.equal(pt.sum(dim=(0, 2)), qhist)
+    assert torch.equal(pt[0].sum(dim=0)[:S], cyc1) and torch.equal(pt[0].sum(dim=0)[S:], cyc2.flip(0))
+    assert int(dt.sum()) <= tot_valid and int(de.sum()) <= tot_err
+    # linearity: two uneven parts add up to the whole
+    t2 = dev.Tables(1, 2 * S)
+    for lo, hi in ((0, 17_000_002), (17_000_002, n)):
+        part = dev.ReadBatch(hi - lo, b.pitch)
+        part.seq, part.cseq, part.qual, part.meta = b.seq[lo:hi], b.cseq[lo:hi], b.qual[lo:hi], b.meta[lo:hi]
+        dev.accumulate(part, t2)
+    assert torch.equal(t.buf, t2.buf)
+    # mate-pair rows: the same tables; the same new qualities
+    pb = dev.PairBatch.from_reads(b)
+    t3 = dev.Tables(1, 2 * S)
+    dev.accumulate(pb, t3)
+    assert torch.equal(t.buf, t3.buf)
+    lut, shape, _, _ = dev.solve(t)
+    out = dev.apply(b, lut, shape)
+    # bases below the threshold pass through, padding stays zero, everything else is a valid quality character
+    for lo in range(0, n, 5_000_000):
+        hi = min(n, lo + 5_000_000)
+        q, o = b.qual[lo:hi], out[lo:hi]
+        low = (q[:, :S] < 33 + 6)
+        assert torch.equal(o[:, :S][low], q[:, :S][low]) and not bool(o[:, S:].any())
+        assert int(o[:, :S].min()) >= 33 and int(o[:, :S].max()) <= 33 + 93
+        del q, o, low
+    del b
+    torch.cuda.empty_cache()
+    out_pairs = pb.unpack(dev.apply(pb, lut, shape))
+    assert torch.equal(out_pairs[:n], out[:n])
