@@ -52,7 +52,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--reads', type=int, default=50_000_000, help='reads per GPU')
     ap.add_argument('--rgs', type=int, default=1)
-    ap.add_argument('--cpu-sample', type=int, default=2_000_000, help='reads in the CPU baseline sample (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=6_000_000, help='reads in the CPU baseline sample (0 = skip)')
     ap.add_argument('--layout', choices=('pairs', 'reads'), default='pairs',
                     help='device layout of the resident batch: mate-pair rows (304 B per 2 x 150 bp) or one read per row (2 x 160 B)')
     args = ap.parse_args()
