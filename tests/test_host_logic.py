@@ -404,3 +404,24 @@ def test_gzip_fastq_is_read_like_plain_text(oracle, tmp_path):
     for k in ('seq', 'cseq', 'qual', 'meta'):
         assert np.array_equal(got[k], want[k]), k
     assert got['text'].format(0, n, got['qual']) == open(fa, 'rb').read()
+
+
+def test_cli_without_arguments_and_version(monkeypatch, capfd):
+    """reference tests/test_main.py:5-17: no sub-command behaves like the bare program name with anything appended
+    (no error, same output); --version prints and exits."""
+    import sys
+    from kbbq import main
+    monkeypatch.setattr(sys, 'argv', ['kbbq'])
+    main.main()
+    first = capfd.readouterr()
+    monkeypatch.setattr(sys, 'argv', ['kbbq-h'])
+    main.main()
+    assert capfd.readouterr() == first
+    monkeypatch.setattr(sys, 'argv', ['kbbq', '--version'])
+    with pytest.raises(SystemExit) as e:
+        main.main()
+    assert e.value.code == 0 and kbbq.__version__ in capfd.readouterr().out
+    monkeypatch.setattr(sys, 'argv', ['kbbq', 'recalibrate'])
+    with pytest.raises(SystemExit) as e:                     # -b / -f is required
+        main.main()
+    assert e.value.code == 2
