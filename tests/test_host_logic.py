@@ -425,3 +425,49 @@ def test_cli_without_arguments_and_version(monkeypatch, capfd):
     with pytest.raises(SystemExit) as e:                     # -b / -f is required
         main.main()
     assert e.value.code == 2
+
+
+def test_native_packer_agrees_with_numpy_twin_on_random_inputs(tmp_path):
+    """Differential test: the C++ packer (pack_pair) against the readable NumPy statement of the rules (pack_pair_py)
+    on random FASTQ pairs with random defects -- same usable reads, same first offending read and exception class,
+    same planes, sidecars and read-group order."""
+    rng = np.random.default_rng(77)
+    acgt = np.array(list('ACGTN'))
+    for case in range(120):
+        n = int(rng.integers(0, 40))
+        infer = bool(rng.integers(0, 2))
+        base_len = int(rng.integers(1, 40))
+        lens = np.sort(rng.integers(max(1, base_len - 3), base_len + 4, n)) if rng.random() < 0.7 else rng.integers(1, base_len + 4, n)
+        recs_a, recs_b = [], []
+        for i in range(n):
+            L = int(lens[i])
+            seq = ''.join(rng.choice(acgt, L, p=[.24, .24, .24, .24, .04]))
+            cseq = ''.join(c if rng.random() > 0.05 else str(rng.choice(acgt[:4])) for c in seq)
+            qual = ''.join(chr(33 + int(q)) for q in rng.integers(0, 42, L))
+            name = 'r%d/%d' % (i // 2, 1 + (i & 1))
+            if infer or rng.random() < 0.3:
+                name += '_RG:Z:g%d' % ((i // 2) % 3)
+            name_b = name
+            defect = rng.random()
+            if defect < 0.03:
+                name_b = 'x' + name                                   # corrected name does not start with the name
+            elif defect < 0.06:
+                cseq = cseq[:-1] if L > 1 else cseq + 'A'             # length mismatch between the files
+            elif defect < 0.09 and infer:
+                name = name_b = name.split('_')[0]                    # no read-group field
+            elif defect < 0.12 and infer:
+                name = name_b = name.replace('_RG:', '_XG:')          # second field is not an RG tag
+            recs_a.append((name, seq, qual)); recs_b.append((name_b, cseq, qual[:len(cseq)].ljust(len(cseq), 'I')))
+        if rng.random() < 0.15 and n > 2:
+            recs_b = recs_b[:int(rng.integers(1, n))]                 # zip() truncation
+        d = tmp_path / ('c%d' % case); d.mkdir()
+        fa, fb = _write(d, 'a.fq', recs_a), _write(d, 'b.fq', recs_b)
+        got, want = fastx.pack_pair(fa, fb, infer), fastx.pack_pair_py(fa, fb, infer)
+        assert (got['n'], got['S'], got['R'], got['pitch']) == (want['n'], want['S'], want['R'], want['pitch']), case
+        ge, we = got['pending_error'], want['pending_error']
+        assert (ge is None) == (we is None), case
+        if ge is not None:
+            assert ge[0] == we[0] and type(ge[1]) is type(we[1]) and ge[2] == we[2], (case, ge, we)
+        for k in ('seq', 'cseq', 'qual', 'meta'):
+            assert np.array_equal(got[k], want[k]), (case, k)
+        assert list(got['rg_to_int'])[:len(want['rg_to_int'])] == list(want['rg_to_int']), case
