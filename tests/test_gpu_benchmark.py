@@ -137,3 +137,32 @@ def test_python_index_wraps_and_errors(bm, OB):
         compare_reads.find_read_errors(aln.AlignedRead('e\t0\tc\t18\t60\t6M\t*\t0\t0\tCGTACG\tIIIIII'), ref, full)
     with pytest.raises(ValueError):
         bm.calculate_q(np.array([True]), np.array([-1]))
+
+
+@pytest.mark.parametrize('case', [dict(seed=101, npairs=700), dict(seed=102, npairs=500, readlen=(10, 40)),
+                                  dict(seed=103, npairs=400, readlen=(140, 160), contigs=(('a', 4000), ('b', 2500), ('c', 2600)))])
+def test_random_truth_sets_against_the_oracle(bm, OB, case, tmp_path):
+    """More random truth sets (substitutions, indels, N-skips, clips, both strands): K4 flags and K5 counts against the
+    oracle's scalar walk, through the native SAM reader and through pysam-style read objects."""
+    import _shim
+    from kbbq import aln
+    paths = OB.synth_truthset(str(tmp_path), **case)
+    ref, var = bm.get_ref_dict(paths['fa']), bm.get_var_sites(paths['vcf'])
+    with open(paths['bed']) as fh:
+        full = bm.get_full_skips(ref, var, fh)
+    oref = OB.get_ref_dict(paths['fa'])
+    want = OB.get_error_dict(list(_shim.AlignmentFile(paths['sam'])), oref, full)
+    for source in (aln.AlignmentFile(paths['sam']), list(aln.AlignmentFile(paths['sam']))):
+        got = bm.get_error_dict(source, ref, full)
+        assert list(got) == list(want)
+        for k in want:
+            assert np.array_equal(got[k][0], want[k][0]) and np.array_equal(got[k][1], want[k][1]), k
+    for use_oq in (False, True):
+        a, t = bm.benchmark_bam(aln.AlignmentFile(paths['sam']), ref, var, use_oq=use_oq, bedfh=open(paths['bed']))
+        oa, ot = OB.benchmark_bam(list(_shim.AlignmentFile(paths['sam'])), oref, OB.get_var_sites(paths['vcf']), use_oq=use_oq,
+                                  bed_path=paths['bed'])
+        assert np.array_equal(a, oa) and np.array_equal(t, ot)
+    a, t = bm.benchmark_fastq(paths['fq'], aln.AlignmentFile(paths['sam']), ref, var, open(paths['bed']))
+    oa, ot = OB.benchmark_fastq(paths['fq'], list(_shim.AlignmentFile(paths['sam'])), oref, OB.get_var_sites(paths['vcf']),
+                                paths['bed'])
+    assert np.array_equal(a, oa) and np.array_equal(t, ot)
