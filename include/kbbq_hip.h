@@ -116,9 +116,11 @@ int kbbq_accumulate_ex_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d
 /* The same for ONE LENGTH BAND of a mixed-length input: S2 sizes the (global) count tables as before, S_band >= the
  * longest read of THIS batch (0 = S2 / 2) sizes the kernel's LDS tables, so that short reads packed at a narrow pitch
  * use the table-driven kernel even when the input's longest read would not fit it.  Counts land in the same cells
- * (a second-in-pair column 2*len - 1 - i does not depend on the table width).                                     */
+ * (a second-in-pair column 2*len - 1 - i does not depend on the table width).  S_min: a promise that no (non-empty)
+ * read of the batch is shorter (0 = no promise); long bands (~200-300 bases) need it to fit the LDS -- a cycle row
+ * then has 3*S_band - S_min words -- and a read that breaks it is reported as KBBQ_E_INDEX, not counted.        */
 int kbbq_accumulate_band_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
-                             const uint32_t* d_meta, int64_t nreads, int pitch, int R, int S2, int S_band,
+                             const uint32_t* d_meta, int64_t nreads, int pitch, int R, int S2, int S_band, int S_min,
                              int minscore, int dinuc_minscore, int64_t* d_tables);
 int kbbq_accumulate(kbbq_ctx* ctx, const uint8_t* seq, const uint8_t* cseq,
                     const uint8_t* qual, const uint32_t* meta,
@@ -284,8 +286,8 @@ int    kbbq_apply_pairs_dev(kbbq_ctx* ctx, const uint8_t* d_pseq, const uint8_t*
  * The fast apply LUT must be range-safe (blob flags 0); rows it cannot serve are reported (KBBQ_E_LUT).  */
 int    kbbq_accumulate_grouped_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                                    const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2,
-                                   int S_band, int minscore, int dinuc_minscore, const int64_t* d_seg,
-                                   int64_t* d_tables);      /* S_band as in kbbq_accumulate_band_dev (0 with pairs) */
+                                   int S_band, int S_min, int minscore, int dinuc_minscore, const int64_t* d_seg,
+                                   int64_t* d_tables);      /* S_band, S_min as in kbbq_accumulate_band_dev (0 with pairs) */
 int    kbbq_apply_grouped_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta,
                               int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
                               const void* d_lut_blob, const void* d_pair_lut, const int64_t* d_seg, uint8_t* d_out);

@@ -289,19 +289,19 @@ int kbbq_accumulate_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq
 
 static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                            const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
-                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band = 0);
+                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band = 0, int S_min = 0);
 
 int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq,
                            const uint8_t* d_qual, const uint32_t* d_meta,
                            int64_t nreads, int pitch, int R, int S2, int minscore,
                            int dinuc_minscore, int64_t* d_tables)
 {
-    return kbbq_accumulate_band_dev(c, d_seq, d_cseq, d_qual, d_meta, nreads, pitch, R, S2, 0, minscore, dinuc_minscore, d_tables);
+    return kbbq_accumulate_band_dev(c, d_seq, d_cseq, d_qual, d_meta, nreads, pitch, R, S2, 0, 0, minscore, dinuc_minscore, d_tables);
 }
 
 int kbbq_accumulate_band_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq,
                              const uint8_t* d_qual, const uint32_t* d_meta,
-                             int64_t nreads, int pitch, int R, int S2, int S_band, int minscore,
+                             int64_t nreads, int pitch, int R, int S2, int S_band, int S_min, int minscore,
                              int dinuc_minscore, int64_t* d_tables)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
@@ -320,7 +320,7 @@ int kbbq_accumulate_band_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d
     if (!(force && !strcmp(force, "v1"))) {
         bool fits = false;
         rc = accumulate_rows(c, "kbbq_accumulate_dev", d_seq, d_cseq, d_qual, d_meta, nreads, pitch, 0, R, S2, minscore,
-                             dinuc_minscore, nullptr, d_tables, &fits, S_band);
+                             dinuc_minscore, nullptr, d_tables, &fits, S_band, S_min);
         if (rc || fits) return rc;                      // launched (or a real error); otherwise the tables do not fit the LDS
     }
     K1Params p;
@@ -665,10 +665,11 @@ int kbbq_unpack_pairs_dev(kbbq_ctx* c, const uint8_t* d_pplane, int64_t npairs, 
 // K1 (table-driven kernel) on one-read-per-row or mate-pair rows, optionally grouped by read group
 static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                            const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
-                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band)
+                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band, int S_min)
 {
     if (fits) *fits = true;
     if (S_band < 0 || S_band > S2 / 2 || (pairs && S_band)) return fail(KBBQ_E_ARG, "%s: S_band out of range (%d)", who, S_band);
+    if (S_min < 0 || S_min > (S_band ? S_band : S2 / 2)) return fail(KBBQ_E_ARG, "%s: S_min out of range (%d)", who, S_min);
     int rc = check_planes(who, nrows, pitch, d_seq, d_cseq, d_qual);
     if (rc) return rc;
     if (R <= 0 || R > 32767) return fail(KBBQ_E_ARG, "%s: R out of range (%d)", who, R);
@@ -685,14 +686,27 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     q.R = R; q.S = S; q.gS2 = S2; q.minscore = minscore; q.type_minscore = dinuc_minscore;
     q.qlo_m1 = 32u + (u32)minscore; q.dlo = 33u + (u32)dinuc_minscore;
     q.nrows = KQ + 1 - minscore;
-    q.row_bytes = (u32)((3 * S) | 1) * 4u;
-    q.slack_bytes = (u32)(S + 32) * 4u;
     q.maxlen = pairs ? S2 + 1 : S; q.gap = pairs ? 1 : 0;
     q.seg = reinterpret_cast<const long long*>(d_seg);
     q.tables = reinterpret_cast<u64*>(d_tables); q.status = c->d_status;
-    q.dn_flush_iters = std::max(1, 65535 / ((K1V3_THREADS / K1V3_DNREP) * 16 * q.cpr));
-    const size_t lds3 = (size_t)q.nrows * 128 * K1V3_DNREP + (size_t)q.nrows * q.row_bytes + q.slack_bytes;
-    if (lds3 > (size_t)c->lds_bytes) {
+    // LDS geometry.  A cycle row has one word per first-in-pair position [0, S) and per second-in-pair index
+    // S + 2(S - len) + pos <= 3S - len - 1: 3S words serve any length.  When that does not fit (reads of ~200 bases
+    // and more), a band whose shortest read is S_min needs only 3S - S_min words, and 8 copies of the context table
+    // instead of 16 free the rest: reads of up to ~300 bases still run this kernel.
+    const int trim = (!pairs && S_min > 0) ? std::min(S_min, S) : 0;
+    int dn = 0; size_t lds3 = 0;
+    for (int attempt = 0; attempt < (trim ? 3 : 1) && !dn; ++attempt) {
+        const int copies = attempt == 2 ? 8 : K1V3_DNREP, cut = attempt ? trim : 0;
+        const int words = (3 * S - cut) | 1;
+        q.row_bytes = (u32)words * 4u;
+        q.minlen = cut;
+        // bytes past a read's end (quality 0) land on the trash row, the last one, at indexes up to 3S - cut - 1 + 15
+        q.slack_bytes = (u32)(S + 32) * 4u;
+        q.dn_flush_iters = std::max(1, 65535 / ((K1V3_THREADS / copies) * 16 * q.cpr));
+        lds3 = (size_t)q.nrows * 128 * copies + (size_t)q.nrows * q.row_bytes + q.slack_bytes;
+        if (lds3 <= (size_t)c->lds_bytes && (K1V3_THREADS / copies) * 16 * q.cpr <= 65535) dn = copies;
+    }
+    if (!dn) {
         if (fits) { *fits = false; return KBBQ_OK; }     // the caller has another kernel for this shape
         return fail(KBBQ_E_LUT, "%s: %d-base reads with minscore %d do not fit the LDS tables; use plain one-read-per-row planes", who, S, minscore);
     }
@@ -703,8 +717,13 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     dim3 grid((unsigned)gx, (unsigned)R, 1), block(K1V3_THREADS, 1, 1);
     {
         Timed t(c, 0);
-        if (split) hipLaunchKernelGGL(k1v3_accumulate<true>, grid, block, lds3, c->stream, q);
-        else hipLaunchKernelGGL(k1v3_accumulate<false>, grid, block, lds3, c->stream, q);
+        if (dn == K1V3_DNREP) {
+            if (split) hipLaunchKernelGGL((k1v3_accumulate<true, K1V3_DNREP>), grid, block, lds3, c->stream, q);
+            else hipLaunchKernelGGL((k1v3_accumulate<false, K1V3_DNREP>), grid, block, lds3, c->stream, q);
+        } else {
+            if (split) hipLaunchKernelGGL((k1v3_accumulate<true, 8>), grid, block, lds3, c->stream, q);
+            else hipLaunchKernelGGL((k1v3_accumulate<false, 8>), grid, block, lds3, c->stream, q);
+        }
     }
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
@@ -723,12 +742,12 @@ int kbbq_accumulate_pairs_dev(kbbq_ctx* c, const uint8_t* d_pseq, const uint8_t*
 
 int kbbq_accumulate_grouped_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                                 const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int S_band,
-                                int minscore, int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables)
+                                int S_min, int minscore, int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
     if (!d_seg) return fail(KBBQ_E_ARG, "kbbq_accumulate_grouped_dev: d_seg is NULL");
     return accumulate_rows(c, "kbbq_accumulate_grouped_dev", d_seq, d_cseq, d_qual, d_meta, nrows, pitch, pairs ? 1 : 0,
-                           R, S2, minscore, dinuc_minscore, d_seg, d_tables, nullptr, S_band);
+                           R, S2, minscore, dinuc_minscore, d_seg, d_tables, nullptr, S_band, S_min);
 }
 
 int kbbq_pair_lut_dev(kbbq_ctx* c, const void* d_lut_blob, int R, int S2, int minscore, void* d_pair_lut)

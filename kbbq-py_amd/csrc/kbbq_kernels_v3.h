@@ -23,7 +23,7 @@
 #include <type_traits>
 
 #define K1V3_THREADS 1024        // one workgroup per CU: the replicated context table needs ~150 KB of LDS
-#define K1V3_DNREP 16            // copies of the context-total table (copy = lane & 15)
+#define K1V3_DNREP 16            // copies of the context-count table (copy = lane & (DN - 1)); long reads use 8 to fit the LDS
 #ifndef K2V3_THREADS
 #define K2V3_THREADS 512
 #endif
@@ -45,6 +45,7 @@ struct K1v3Params {
     int nrows;                  // 44 - minscore: one row per counted quality (row = 42 - q) + the trash row LAST
     u32 row_bytes;              // pos row stride in bytes ((3S | 1) words)
     u32 slack_bytes;            // after the last (trash) row: padding bytes of short reads index past its end
+    int minlen;                 // rows are trimmed to 3S - minlen words: a shorter read is reported (ST_INDEX), not counted
     int dn_flush_iters;         // workgroup iterations between flushes of the (16-bit packed) context table
     int maxlen;                 // longest row the tables take: S, or 2S + 1 for mate-pair rows
     int gap;                    // mate-pair rows: 1 (the separator byte between the mates), else 0
@@ -94,11 +95,11 @@ struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int k; int j; int nb; };
 //      rows are ordered by the INVERTED quality byte (row = 42 - q, one v_min clamps every
 //      uncounted byte onto the trash row, which is last); bytes past the end of a short read
 //      (quality 0 -> trash) can index beyond the trash row's end: `slack_bytes` absorb that.
-template <bool SPLIT>
+template <bool SPLIT, int DN = K1V3_DNREP>
 __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
-    const int dn_words = p.nrows * 32 * K1V3_DNREP;
+    const int dn_words = p.nrows * 32 * DN;
     const int pos_words = p.nrows * (int)(p.row_bytes >> 2) + (int)(p.slack_bytes >> 2);
     u32* dnt = lds;
     u32* pos = lds + dn_words;
@@ -117,9 +118,9 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
     const u32 row_bytes = p.row_bytes;
     const u32 tclamp = 255u - p.qlo_m1;                                // inverted bytes >= this are uncounted
     const u32 pos_base = (u32)dn_words * 4u - 180u * row_bytes;        // 180 = 255 - 'K': inverted byte of q = 42 is row 0
-    const u32 dnt_row = 128u * K1V3_DNREP;                             // bytes per row of the replicated totals
+    const u32 dnt_row = 128u * DN;                             // bytes per row of the replicated totals
     // LDS byte address (the low half of the flat address is the LDS offset) of this lane's copy, less the row bias
-    const u32 dnt_base = (u32)reinterpret_cast<size_t>(lds) - 180u * dnt_row + 4u * (u32)(lane_id() & (K1V3_DNREP - 1));
+    const u32 dnt_base = (u32)reinterpret_cast<size_t>(lds) - 180u * dnt_row + 4u * (u32)(lane_id() & (DN - 1));
     int since_flush = 0, since_dn_flush = 0;
     // work item of this lane at step 0 and the per-step advances (64 / 128 items)
     const int lane_k0 = p.cpr == 1 ? lane : (int)__umulhi((u32)lane, p.cpr_magic);
@@ -139,9 +140,9 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                 const int a = lane / 5, b = lane - 5 * a;
                 if (a < 4 && b < 4) {
                     u32 vt = 0u, ve = 0u;
-                    for (int cpy = 0; cpy < K1V3_DNREP; ++cpy) {
-                        const u32 v = dnt[(r * 32 + lane) * K1V3_DNREP + cpy];
-                        dnt[(r * 32 + lane) * K1V3_DNREP + cpy] = 0u;
+                    for (int cpy = 0; cpy < DN; ++cpy) {
+                        const u32 v = dnt[(r * 32 + lane) * DN + cpy];
+                        dnt[(r * 32 + lane) * DN + cpy] = 0u;
                         vt += v & 0xFFFFu; ve += v >> 16;
                     }
                     if (vt) {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
             const int q = KQ - 1 - r;
             const size_t grow = ((size_t)g * KQ + q) * p.gS2;
             u32* prow = pos + (size_t)r * (row_bytes >> 2);
-            for (int x = lane; x < 3 * S; x += 64) {
+            for (int x = lane; x < 3 * S - p.minlen; x += 64) {
                 const u32 v = prow[x];
                 if (v) {
                     prow[x] = 0u;
@@ -248,11 +249,12 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                 if (j == 0) { prev_code5 = 20u; prev_char = 0u; }                    // dinuc[0] = -1
                 if (act) {
                     const long long read = read0 + ch.off;
-                    if (hiq || len > p.maxlen) flag(p.status, ST_INDEX, read);       // recalibrate.py:114-115; read longer than the tables
+                    const bool fits_tables = (u32)(len - p.minlen) <= (u32)(p.maxlen - p.minlen);
+                    if (hiq || !fits_tables) flag(p.status, ST_INDEX, read);         // recalibrate.py:114-115; read longer (shorter) than the tables
                     if (badbits && chunk_type_error(ch.s[0], ch.s[1], ch.s[2], ch.s[3], ch.q[0], ch.q[1], ch.q[2], ch.q[3],
                                                     prev_char, nb, pos0, p.type_minscore))
                         flag(p.status, ST_TYPE, read);                               // compare_reads.py:224,292
-                    if (!hiq && len <= p.maxlen) {
+                    if (!hiq && fits_tables) {
                         // A: pos address less the row term; both mates ascend with the base index
                         const u32 half = second ? (u32)(S + 2 * (S - len)) : 0u;     // column 2*len-1-pos
                         const u32 A = pos_base + (half + (u32)pos0) * 4u;
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                                 u32 slot = (d5 >> (8 * b)) & 0xFFu;
                                 if (SPLIT) slot = qi <= 255u - p.dlo ? slot : 24u;             // context needs q >= its own threshold
                                 const u32 trow = tq * dnt_row + dnt_base;                      // constant powers of two: two shift-adds,
-                                const u32 ad = slot * (4u * K1V3_DNREP) + trow;                // the LDS base is inside dnt_base
+                                const u32 ad = slot * (4u * DN) + trow;                // the LDS base is inside dnt_base
 #ifndef KBBQ_ABL_NODN
                                 __hip_atomic_fetch_add(reinterpret_cast<lds_u32*>(ad), inc, __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_WORKGROUP);          // recalibrate.py:118-119

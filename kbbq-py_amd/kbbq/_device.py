@@ -218,10 +218,11 @@ def ungroup(batch, plane):
 _pair_luts = {}
 
 
-def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None, s_band=0):
+def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None, s_band=0, s_min=0):
     """K1 over a device batch, adding into `tables` (recalibrate.py:57-119).  s_band: the longest read of THIS batch
     when it is one length band of a mixed-length input (its rows packed at a narrower pitch than the tables' S):
-    the kernel's LDS tables are then laid out for s_band instead of tables.S2 / 2."""
+    the kernel's LDS tables are then laid out for s_band instead of tables.S2 / 2.  s_min: no non-empty read of the
+    batch is shorter (0: unknown); it lets bands of ~200-300-base reads fit the table-driven kernel."""
     ctx = context(batch.seq.device.index)
     if getattr(batch, 'seg', None) is not None:
         pairs = isinstance(batch, PairBatch)
@@ -229,7 +230,8 @@ def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None
             raise ValueError('mate-pair rows of %d-base reads need tables with 2S = %d columns' % (batch.S, 2 * batch.S))
         N.check(N.load().kbbq_accumulate_grouped_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual),
                                                      N.ptr(batch.meta), batch.n, batch.pitch, 1 if pairs else 0,
-                                                     tables.R, tables.S2, 0 if pairs else int(s_band), minscore,
+                                                     tables.R, tables.S2, 0 if pairs else int(s_band),
+                                                     0 if pairs else int(s_min), minscore,
                                                      minscore if dinuc_minscore is None else dinuc_minscore,
                                                      N.ptr(batch.seg), N.ptr(tables.buf)))
         if check:
@@ -247,7 +249,7 @@ def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None
         return
     N.check(N.load().kbbq_accumulate_band_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq),
                                             N.ptr(batch.qual), N.ptr(batch.meta), batch.n, batch.pitch,
-                                            tables.R, tables.S2, int(s_band), minscore,
+                                            tables.R, tables.S2, int(s_band), int(s_min), minscore,
                                             minscore if dinuc_minscore is None else dinuc_minscore,
                                             N.ptr(tables.buf)))
     if check:

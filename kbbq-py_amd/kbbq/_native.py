@@ -49,7 +49,7 @@ PROTOTYPES = {
     'kbbq_lut_count': (_sz, [_i, _i, _i]),
     'kbbq_accumulate_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     'kbbq_accumulate_ex_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
-    'kbbq_accumulate_band_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
+    'kbbq_accumulate_band_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'kbbq_accumulate': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'kbbq_lut_row_stride': (_i, [_i]),
     'kbbq_full_lut_bytes': (_sz, [_i, _i, _i]),
@@ -74,7 +74,7 @@ PROTOTYPES = {
     'kbbq_accumulate_pairs_dev': (_i, [_vp] * 5 + [_i64, _i, _i, _i, _i, _vp]),
     'kbbq_pair_lut_dev': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'kbbq_apply_pairs_dev': (_i, [_vp] * 4 + [_i64, _i, _i, _i] + [_vp] * 3),
-    'kbbq_accumulate_grouped_dev': (_i, [_vp] * 5 + [_i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'kbbq_accumulate_grouped_dev': (_i, [_vp] * 5 + [_i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'kbbq_apply_grouped_dev': (_i, [_vp] * 4 + [_i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'kbbq_sam_open': (_i, [_c.c_char_p, _vp]),
     'kbbq_sam_close': (_i, [_vp]),

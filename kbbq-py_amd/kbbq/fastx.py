@@ -332,7 +332,8 @@ BAND_CLASSES = (32, 48, 64, 96, 128, 160, 208, 256, 320, 400, 512, 768, 1024, 20
 
 
 def length_bands(lens, max_bands=16):
-    """[(lo, hi, longest)] -- maximal runs of reads whose lengths fall into one BAND_CLASSES class.  Valid inputs
+    """[(lo, hi, longest, shortest)] -- maximal runs of reads whose lengths fall into one BAND_CLASSES class
+    (shortest: of the non-empty reads, 0 when there is none).  Valid inputs
     have non-decreasing lengths, i.e. at most one run per class; anything with more than max_bands
     runs is kept as one band."""
     lens = np.asarray(lens, dtype=np.int64)
@@ -342,18 +343,24 @@ def length_bands(lens, max_bands=16):
     cls = np.searchsorted(np.asarray(BAND_CLASSES), np.maximum(lens, 1), side='left')
     cuts = np.flatnonzero(np.diff(cls)) + 1
     if len(cuts) + 1 > max_bands:
-        return [(0, n, int(lens.max()))]
+        cuts = cuts[:0]
     edges = [0] + cuts.tolist() + [n]
-    return [(lo, hi, int(lens[lo:hi].max())) for lo, hi in zip(edges[:-1], edges[1:])]
+    out = []
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        part = lens[lo:hi]
+        some = part[part > 0]
+        out.append((lo, hi, int(part.max()), int(some.min()) if len(some) else 0))
+    return out
 
 
 def _fill_bands(A, B, infer_rg_flag, lo, hi):
     """Reads [lo, hi) packed band by band: [dict(first, n, S, pitch, seq, cseq, qual, meta)], `first` counted from lo."""
     out = []
-    for b_lo, b_hi, longest in length_bands(A.lengths(lo, hi - lo)):
+    for b_lo, b_hi, longest, shortest in length_bands(A.lengths(lo, hi - lo)):
         pitch = pitch_for(longest)
         seq, cseq, qual, meta = A.fill(B, infer_rg_flag, b_hi - b_lo, pitch, first=lo + b_lo)
-        out.append(dict(first=b_lo, n=b_hi - b_lo, S=longest, pitch=pitch, seq=seq, cseq=cseq, qual=qual, meta=meta))
+        out.append(dict(first=b_lo, n=b_hi - b_lo, S=longest, Smin=shortest, pitch=pitch, seq=seq, cseq=cseq, qual=qual,
+                        meta=meta))
     return out
 
 

@@ -70,13 +70,13 @@ def _tally_local(packed, minscore, maxscore):
             if laid is not None:
                 part = dev.Tables(R, 2 * S)
                 try:
-                    dev.accumulate(laid, part, minscore, s_band=band['S'])
+                    dev.accumulate(laid, part, minscore, s_band=band['S'], s_min=band.get('Smin', 0))
                     tables.buf += part.buf
                     band['laid'] = laid
                     continue
                 except (IndexError, TypeError, dev.N.LutNeedsCheckedApply):
                     pass                     # bad input or an unsupported shape: the row-per-read kernel decides
-            dev.accumulate(batch, tables, minscore, s_band=band['S'])
+            dev.accumulate(batch, tables, minscore, s_band=band['S'], s_min=band.get('Smin', 0))
         except (IndexError, TypeError) as e:
             if hasattr(e, 'read_index'):
                 e.read_index = band['first'] + max(e.read_index, 0)

@@ -128,8 +128,8 @@ def test_product_fastq_path_takes_pair_rows_when_it_can(dev, oracle, tmp_path):
     from conftest import load_golden
     from kbbq import recalibrate
     from test_gpu_parity import VEC, _files
-    # c5cut: ragged lengths 36..300 in ascending order: several length bands, each at its own pitch; no pairs; the
-    # bands up to 200 bases run the table-driven K1 (grouped by read group), the longest the first-generation kernel
+    # c5cut: ragged lengths 36..300 in ascending order: several length bands, each at its own pitch; no pairs; every
+    # band runs the table-driven K1 grouped by read group (the long ones on rows trimmed by the band's shortest read)
     for name, expect in (('c1_10k_1rg', ('pairs', False)), ('c3cut_2k_8rg', ('pairs', True)),
                          ('c5cut_2k_mixed', None), ('q42_500_3rg', ('pairs', True))):
         info, gold = load_golden(name)
@@ -141,7 +141,7 @@ def test_product_fastq_path_takes_pair_rows_when_it_can(dev, oracle, tmp_path):
             assert len(bands) >= 6 and [b['pitch'] for b in bands] == sorted(b['pitch'] for b in bands)
             assert bands[0]['pitch'] <= 48 and bands[-1]['pitch'] == 304 and sum(b['n'] for b in bands) == packed['n']
             assert all(not isinstance(b['laid'], dev.PairBatch) for b in bands)
-            assert all((b['laid'] is not None) == (b['S'] <= 200) for b in bands), [(b['S'], b['laid']) for b in bands]
+            assert all(b['laid'] is not None and 0 < b['Smin'] <= b['S'] for b in bands), [(b['S'], b['laid']) for b in bands]
         else:
             assert len(bands) == 1
             laid = bands[0]['laid']
@@ -312,21 +312,23 @@ def test_length_bands_of_a_mixed_length_input(dev, oracle):
     for lo, hi in zip(edges[:-1], edges[1:]):
         if hi <= lo:
             continue
-        smax = int(lens[lo:hi].max())
+        smax, smin = int(lens[lo:hi].max()), int(lens[lo:hi].min())
         pitch = (smax + 15) // 16 * 16
         band = dev.ReadBatch.from_host(np.ascontiguousarray(host[0][lo:hi, :pitch]), np.ascontiguousarray(host[2][lo:hi, :pitch]),
                                        meta[lo:hi], cseq=np.ascontiguousarray(host[1][lo:hi, :pitch]))
+        ref = dev.Tables(nrg, 2 * S)
+        dev.accumulate(band, ref)                             # the same band without the hints: first-generation kernel
         for lay in (band, dev.group_by_rg(band, nrg)):
-            t = dev.Tables(nrg, 2 * S)
-            try:
-                dev.accumulate(lay, t, s_band=smax)
-            except dev.N.LutNeedsCheckedApply:
-                assert smax > 200 and lay is not band        # grouped rows have no first-generation fallback
-                continue
-            ref = dev.Tables(nrg, 2 * S)
-            dev.accumulate(band, ref)                         # the same band without the hint: first-generation kernel
-            assert torch.equal(t.buf, ref.buf), (lo, hi)
-        dev.accumulate(band, banded, s_band=smax)
+            for hint in (0, smin):                            # long bands fit the table-driven kernel only with s_min
+                t = dev.Tables(nrg, 2 * S)
+                try:
+                    dev.accumulate(lay, t, s_band=smax, s_min=hint)
+                except dev.N.LutNeedsCheckedApply:
+                    # grouped rows have no first-generation fallback: without the promise the long bands do not fit
+                    assert smax > 200 and lay is not band and hint == 0
+                    continue
+                assert torch.equal(t.buf, ref.buf), (lo, hi, hint)
+        dev.accumulate(band, banded, s_band=smax, s_min=smin)
         out = dev.apply(band, lut, shape)[:hi - lo].cpu().numpy()
         assert np.array_equal(out, want[lo:hi, :pitch]) and not want[lo:hi, pitch:].any()
         used += 1
@@ -337,3 +339,9 @@ def test_length_bands_of_a_mixed_length_input(dev, oracle):
                                     meta[-8:], cseq=np.ascontiguousarray(host[1][-8:, :304]))
     with pytest.raises(IndexError):
         dev.accumulate(short, t, s_band=150)
+    # ... and so is a read shorter than the band's promised minimum, when the promise was needed to fit the tables
+    mixed = np.r_[np.arange(0, 8), np.arange(n - 64, n)]       # 8 of the shortest reads among 300-base ones
+    odd = dev.ReadBatch.from_host(np.ascontiguousarray(host[0][mixed, :304]), np.ascontiguousarray(host[2][mixed, :304]),
+                                  meta[mixed], cseq=np.ascontiguousarray(host[1][mixed, :304]))
+    with pytest.raises(IndexError):
+        dev.accumulate(dev.group_by_rg(odd, nrg), dev.Tables(nrg, 2 * S), s_band=300, s_min=int(lens[-64]))
