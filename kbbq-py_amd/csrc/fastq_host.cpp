@@ -32,10 +32,21 @@
 extern "C" const char* kbbq_last_error(void);
 int kbbq_set_error_(int code, const char* msg);      // defined in kbbq_hip.hip
 
+// std::vector whose resize() leaves new elements uninitialised: the index arrays of a 50 M-read file are GBs that
+// the indexing threads overwrite anyway (and first-touch in parallel instead of in one zero-filling thread)
+template <typename T> struct raw_alloc : std::allocator<T> {
+    template <typename U> struct rebind { using other = raw_alloc<U>; };
+    template <typename U, typename... A> void construct(U* p, A&&... a)
+    {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+template <typename T> using raw_vector = std::vector<T, raw_alloc<T>>;
+
 struct kbbq_fastq {
     const uint8_t* buf = nullptr; size_t size = 0; bool mapped = false;
-    std::vector<uint64_t> h0, s0, q0;      // start offsets of header / sequence / quality lines
-    std::vector<uint32_t> hlen, slen;      // header line length (without '@', up to whitespace = name), sequence length
+    raw_vector<uint64_t> h0, s0, q0;       // start offsets of header / sequence / quality lines
+    raw_vector<uint32_t> hlen, slen;       // header line length (without '@', up to whitespace = name), sequence length
     std::vector<std::string> rg_names;     // first-appearance order (filled by scan / fill with infer_rg)
     ~kbbq_fastq() { if (mapped && buf) munmap((void*)buf, size); else free((void*)buf); }
 };
@@ -101,16 +112,20 @@ int kbbq_fastq_open(const char* path, kbbq_fastq** out)
         }
         close(fd);
     }
-    // line starts, in parallel: each thread scans a byte range for '\n'
+    // Line index, in parallel and without a merged list of line ends: (1) every thread collects the '\n' offsets of
+    // its byte range; (2) a prefix sum of the counts numbers the lines; (3) every thread turns ITS line ends into
+    // record fields -- line g is field g % 4 of record g / 4, and starts after the previous line end, which is the
+    // previous entry of the same list or the last entry of an earlier thread's.
     const unsigned nt = nthreads_for(f->size);
-    std::vector<std::vector<uint64_t>> parts(nt);
+    std::vector<raw_vector<uint64_t>> parts(nt);
+    const size_t per = (f->size + nt - 1) / nt;
     {
         std::vector<std::thread> th;
-        const size_t per = (f->size + nt - 1) / nt;
         for (unsigned t = 0; t < nt; ++t) {
             const size_t lo = std::min(f->size, t * per), hi = std::min(f->size, lo + per);
             th.emplace_back([f, lo, hi, &parts, t]() {
                 auto& v = parts[t];
+                v.reserve((hi - lo) / 64 + 16);
                 const uint8_t* p = f->buf + lo; const uint8_t* e = f->buf + hi;
                 while (p < e) {
                     const uint8_t* nl = (const uint8_t*)memchr(p, '\n', (size_t)(e - p));
@@ -122,30 +137,59 @@ int kbbq_fastq_open(const char* path, kbbq_fastq** out)
         }
         for (auto& t : th) t.join();
     }
-    std::vector<uint64_t> nl;
-    size_t tot = 0; for (auto& v : parts) tot += v.size();
-    nl.reserve(tot + 1);
-    for (auto& v : parts) nl.insert(nl.end(), v.begin(), v.end());
-    if (f->size && (nl.empty() || nl.back() != f->size - 1)) nl.push_back(f->size);   // last line without '\n'
-    if (nl.size() % 4 != 0) { delete f; return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": not a 4-line-per-record FASTQ file").c_str()); }
-    const int64_t n = (int64_t)(nl.size() / 4);
-    f->h0.resize(n); f->s0.resize(n); f->q0.resize(n); f->hlen.resize(n); f->slen.resize(n);
-    std::atomic<int> bad(0);
-    parallel_for(n, nt, [&](int64_t lo, int64_t hi) {
-        for (int64_t i = lo; i < hi; ++i) {
-            const uint64_t hs = i == 0 ? 0 : nl[4 * i - 1] + 1;
-            uint64_t he = nl[4 * i], ss = he + 1, se = nl[4 * i + 1], qs = nl[4 * i + 2] + 1, qe = nl[4 * i + 3];
-            auto trim = [&](uint64_t s, uint64_t& e) { if (e > s && f->buf[e - 1] == '\r') --e; };
-            trim(hs, he); trim(ss, se); trim(qs, qe);
-            if (he <= hs || f->buf[hs] != '@') { bad = 1; continue; }
-            if (se - ss != qe - qs) { bad = 2; continue; }
-            if (se - ss > 65535) { bad = 3; continue; }
-            uint64_t ne = hs + 1;                                   // name: up to the first whitespace
-            while (ne < he && f->buf[ne] != ' ' && f->buf[ne] != '\t') ++ne;
-            f->h0[i] = hs + 1; f->hlen[i] = (uint32_t)(ne - hs - 1);
-            f->s0[i] = ss; f->slen[i] = (uint32_t)(se - ss); f->q0[i] = qs;
+    if (f->size && f->buf[f->size - 1] != '\n') parts[nt - 1].push_back(f->size);   // last line without '\n'
+    std::vector<uint64_t> base(nt + 1, 0), before(nt, 0);      // first line number of a part; line end before its first
+    {
+        uint64_t last_end = (uint64_t)-1;                       // "line end" before offset 0
+        for (unsigned t = 0; t < nt; ++t) {
+            base[t + 1] = base[t] + parts[t].size();
+            before[t] = last_end;
+            if (!parts[t].empty()) last_end = parts[t].back();
         }
-    });
+    }
+    const uint64_t nlines = base[nt];
+    if (nlines % 4 != 0) { delete f; return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": not a 4-line-per-record FASTQ file").c_str()); }
+    const int64_t n = (int64_t)(nlines / 4);
+    f->h0.resize(n); f->s0.resize(n); f->q0.resize(n); f->hlen.resize(n); f->slen.resize(n);
+    raw_vector<uint32_t> qlen((size_t)n);
+    std::atomic<int> bad(0);
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) {
+            if (parts[t].empty()) continue;
+            th.emplace_back([f, t, &parts, &base, &before, &qlen, &bad]() {
+                const auto& v = parts[t];
+                uint64_t start = before[t] + 1;                  // (uint64_t)-1 + 1 == 0 for the file's first line
+                for (size_t j = 0; j < v.size(); ++j) {
+                    const uint64_t g = base[t] + j, i = g >> 2;
+                    uint64_t end = v[j];
+                    if (end > start && f->buf[end - 1] == '\r') --end;
+                    switch (g & 3) {
+                    case 0: {
+                        if (end <= start || f->buf[start] != '@') { bad = 1; break; }
+                        uint64_t ne = start + 1;                 // name: up to the first whitespace
+                        while (ne < end && f->buf[ne] != ' ' && f->buf[ne] != '\t') ++ne;
+                        f->h0[i] = start + 1; f->hlen[i] = (uint32_t)(ne - start - 1);
+                        break;
+                    }
+                    case 1:
+                        if (end - start > 65535) { bad = 3; f->s0[i] = start; f->slen[i] = 0; break; }
+                        f->s0[i] = start; f->slen[i] = (uint32_t)(end - start);
+                        break;
+                    case 2: break;                               // the '+' line
+                    default:
+                        f->q0[i] = start; qlen[i] = (uint32_t)std::min<uint64_t>(end - start, 0xFFFFFFFFu);
+                    }
+                    start = v[j] + 1;
+                }
+            });
+        }
+        for (auto& t : th) t.join();
+    }
+    if (!bad.load())
+        parallel_for(n, nt, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) if (qlen[(size_t)i] != f->slen[i]) { bad = 2; break; }
+        });
     if (bad.load()) {
         const int b = bad.load(); delete f;
         return kbbq_set_error_(KBBQ_E_ARG, b == 1 ? "record header does not start with @"
@@ -204,52 +248,100 @@ int kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* i
     if (!a || !info) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_scan: NULL argument");
     int64_t n = (int64_t)a->h0.size();
     if (b) n = std::min<int64_t>(n, (int64_t)b->h0.size());
-    int64_t err_idx = -1; int err_kind = 0;
-    auto consider = [&](int64_t idx, int kind) {         // lowest index wins; kinds are in check order
-        if (err_idx < 0 || idx < err_idx || (idx == err_idx && kind < err_kind)) { err_idx = idx; err_kind = kind; }
+    // The reference walks the reads once and stops at the first offender (checks per read in the order of the
+    // kinds).  Here contiguous chunks of reads are walked in parallel, each recording ITS first offender, its read
+    // groups in first-appearance order and its longest read; the chunks are then merged in read order.  "Shorter
+    // than the running maximum" needs the maximum over all earlier chunks: a second parallel walk over the lengths.
+    struct Chunk {
+        int64_t lo = 0, hi = 0;
+        int64_t rg_err = -1; int rg_kind = 0;              // first read whose read group cannot be inferred
+        std::vector<std::string> rgs;                       // first-appearance order, up to rg_err
+        int64_t pair_err = -1; int pair_kind = 0;          // first read failing check 3, 4 or 5
+        uint32_t longest = 0;
     };
-    a->rg_names.clear();
-    std::unordered_map<std::string, int> rgmap;
-    if (infer_rg) {
+    int64_t chunk_reads = 1 << 16; bool forced = false;
+    if (const char* e = getenv("KBBQ_SCAN_CHUNK")) if (atoll(e) > 0) { chunk_reads = atoll(e); forced = true; }   // tests: tiny chunks, on threads
+    const int64_t nchunks = std::max<int64_t>(1, (n + chunk_reads - 1) / chunk_reads);
+    std::vector<Chunk> ch((size_t)nchunks);
+    for (int64_t c = 0; c < nchunks; ++c) { ch[(size_t)c].lo = std::min(n, c * chunk_reads); ch[(size_t)c].hi = std::min(n, (c + 1) * chunk_reads); }
+    const unsigned nt = (unsigned)std::min<int64_t>(nthreads_for(forced ? (size_t)1 << 40 : (size_t)n * 256), nchunks);
+    auto over_chunks = [&](auto body) {
+        std::atomic<int64_t> next(0);
+        auto run = [&]() { for (int64_t c; (c = next.fetch_add(1)) < nchunks;) body(ch[(size_t)c]); };
+        if (nt <= 1) { run(); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(run);
+        for (auto& t : th) t.join();
+    };
+    auto rgs_of = [&](int64_t lo, int64_t hi, std::vector<std::string>& out, int64_t* err, int* kind) {
         const char* last = nullptr; int lastlen = -1;          // consecutive reads mostly share a read group
-        for (int64_t i = 0; i < n; ++i) {
+        for (int64_t i = lo; i < hi; ++i) {
             const char* rg; int rl;
             const int rc = name_rg((const char*)a->buf + a->h0[i], (int)a->hlen[i], &rg, &rl);
-            if (rc) { consider(i, rc); break; }
+            if (rc) { if (err) { *err = i; *kind = rc; } return; }
             if (rl == lastlen && memcmp(rg, last, (size_t)rl) == 0) continue;
             last = rg; lastlen = rl;
-            auto it = rgmap.find(std::string(rg, (size_t)rl));
-            if (it == rgmap.end()) { rgmap.emplace(std::string(rg, (size_t)rl), (int)a->rg_names.size()); a->rg_names.emplace_back(rg, (size_t)rl); }
+            bool seen = false;
+            for (const auto& s : out) if ((int)s.size() == rl && memcmp(s.data(), rg, (size_t)rl) == 0) { seen = true; break; }
+            if (!seen) out.emplace_back(rg, (size_t)rl);
+        }
+    };
+    over_chunks([&](Chunk& c) {
+        if (infer_rg) rgs_of(c.lo, c.hi, c.rgs, &c.rg_err, &c.rg_kind);
+        uint32_t longest = 0;
+        for (int64_t i = c.lo; i < c.hi; ++i) longest = std::max(longest, a->slen[i]);
+        c.longest = longest;
+        if (!b) return;
+        for (int64_t i = c.lo; i < c.hi; ++i) {
+            const uint32_t la = a->hlen[i], lb = b->hlen[i];
+            if (lb < la || memcmp(a->buf + a->h0[i], b->buf + b->h0[i], la) != 0) { c.pair_err = i; c.pair_kind = 3; break; }
+            if (a->slen[i] != b->slen[i]) { c.pair_err = i; c.pair_kind = 4; break; }
+        }
+    });
+    if (b) {
+        std::vector<uint32_t> before((size_t)nchunks, 0);      // longest read of all earlier chunks
+        for (int64_t c = 1; c < nchunks; ++c) before[(size_t)c] = std::max(before[(size_t)c - 1], ch[(size_t)c - 1].longest);
+        over_chunks([&](Chunk& c) {
+            uint32_t runmax = before[(size_t)(&c - ch.data())];
+            const int64_t stop = c.pair_err >= 0 ? c.pair_err : c.hi;      // checks 3 and 4 come first at the same read
+            for (int64_t i = c.lo; i < stop; ++i) {
+                if (a->slen[i] < runmax) { c.pair_err = i; c.pair_kind = 5; break; }
+                runmax = std::max(runmax, a->slen[i]);
+            }
+        });
+    }
+    // merge in read order
+    int64_t err_idx = -1; int err_kind = 0;
+    auto consider = [&](int64_t idx, int kind) {         // lowest index wins; kinds are in check order
+        if (idx >= 0 && (err_idx < 0 || idx < err_idx || (idx == err_idx && kind < err_kind))) { err_idx = idx; err_kind = kind; }
+    };
+    a->rg_names.clear();
+    auto add_rgs = [](std::vector<std::string>& to, const std::vector<std::string>& from) {
+        for (const auto& s : from) if (std::find(to.begin(), to.end(), s) == to.end()) to.push_back(s);
+    };
+    if (infer_rg) {
+        for (const auto& c : ch) {
+            add_rgs(a->rg_names, c.rgs);
+            if (c.rg_err >= 0) { consider(c.rg_err, c.rg_kind); break; }      // the reference never looks further
         }
     } else if (n > 0) a->rg_names.emplace_back("0");
-    if (b) {
-        uint32_t runmax = 0;
-        for (int64_t i = 0; i < n && (err_idx < 0 || i <= err_idx); ++i) {
-            const uint32_t la = a->hlen[i], lb = b->hlen[i];
-            if (lb < la || memcmp(a->buf + a->h0[i], b->buf + b->h0[i], la) != 0) { consider(i, 3); break; }
-            if (a->slen[i] != b->slen[i]) { consider(i, 4); break; }
-            if (a->slen[i] < runmax) { consider(i, 5); break; }
-            runmax = std::max(runmax, a->slen[i]);
-        }
-    }
+    for (const auto& c : ch) if (c.pair_err >= 0) { consider(c.pair_err, c.pair_kind); break; }
     int64_t usable = n;
     if (err_idx >= 0) usable = err_idx + (err_kind == 5 ? 1 : 0);
+    // longest read and read groups among the usable reads only
     uint32_t S = 0;
-    for (int64_t i = 0; i < usable; ++i) S = std::max(S, a->slen[i]);
-    // read groups among the usable reads only
-    int R = 0;
-    if (usable > 0) {
-        if (!infer_rg) R = 1;
-        else {
-            std::unordered_map<std::string, int> seen;
-            for (int64_t i = 0; i < usable; ++i) {
-                const char* rg; int rl;
-                if (name_rg((const char*)a->buf + a->h0[i], (int)a->hlen[i], &rg, &rl)) break;
-                seen.emplace(std::string(rg, (size_t)rl), 0);
-            }
-            R = (int)seen.size();
+    std::vector<std::string> seen;
+    for (const auto& c : ch) {
+        if (c.lo >= usable) break;
+        if (c.hi <= usable) {
+            S = std::max(S, c.longest);
+            if (infer_rg) add_rgs(seen, c.rgs);
+        } else {
+            for (int64_t i = c.lo; i < usable; ++i) S = std::max(S, a->slen[i]);
+            if (infer_rg) { std::vector<std::string> part; rgs_of(c.lo, usable, part, nullptr, nullptr); add_rgs(seen, part); }
         }
     }
+    const int R = usable > 0 ? (infer_rg ? (int)seen.size() : 1) : 0;
     info[0] = usable; info[1] = S; info[2] = R; info[3] = err_kind; info[4] = err_idx;
     return KBBQ_OK;
 }

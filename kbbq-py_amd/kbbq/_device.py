@@ -24,6 +24,18 @@ def _torch():
     return torch
 
 
+def warm_up(device=0):
+    """Everything the first call of a process pays once -- importing torch (and SciPy, which the solve's model
+    constants need), creating the HIP context, loading libkbbq_hip's code object with a first kernel launch --
+    so that a caller can run it on a thread while the host reads its input files."""
+    torch = _torch()
+    import scipy.special                      # noqa: F401
+    with torch.cuda.device(device):          # a new thread starts on device 0, whatever the process selected
+        context()
+        ReadBatch.synthetic(0, 64, 64, seed=1)
+        torch.cuda.synchronize()
+
+
 def context(device=None):
     """The process-wide kbbq context of a device, bound to torch's current stream."""
     torch = _torch()

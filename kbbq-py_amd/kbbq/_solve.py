@@ -16,7 +16,6 @@ longdouble prior add + argmax exactly (csrc/solve_core.h, csrc/x87add.h).
 tests/test_solve_core_host.py pins this decomposition against logpmf itself.
 """
 import numpy as np
-import scipy.special
 
 from . import compare_reads as utils
 
@@ -30,6 +29,7 @@ def model_consts():
     prior = utils.RescaledNormal.prior_dist.astype(np.float64)
     assert np.all((prior.astype(np.longdouble) == utils.RescaledNormal.prior_dist)
                   | ~np.isfinite(prior))
+    import scipy.special                      # lazily: 0.15 s of the command line's start-up otherwise
     with np.errstate(divide='ignore'):
         logp = scipy.special.xlogy(1.0, p)
         log1mp = scipy.special.xlog1py(1.0, -p)
@@ -43,6 +43,7 @@ def combiln_scipy(numerrs, numtotal):
     """The candidate-independent term of logpmf(errs + 1; total + 2, p) with SciPy's own calls
     (scipy/stats/_discrete_distns.py binom_gen._logpmf): the definition the native routine is
     tested against, bit for bit."""
+    import scipy.special
     x = np.asarray(numerrs) + 1
     n = np.asarray(numtotal) + 2
     k = np.floor(x)

@@ -297,14 +297,15 @@ class NativeFastq:
                                                  _N.ptr(cseq), _N.ptr(qual), _N.ptr(meta)))
         return seq, cseq, qual, meta
 
-    def format_array(self, first, n, newqual):
+    def format_array(self, first, n, newqual, out=None):
         """FASTQ text of reads [first, first+n) with qualities from rows of `newqual`, as a uint8 array
-        (written once by the C++ writer: no zero fill, no copy)."""
+        (written once by the C++ writer: no zero fill, no copy).  out: callable nbytes -> uint8 array of at least
+        that size to render into (a re-used buffer) instead of a fresh one."""
         newqual = np.ascontiguousarray(newqual)
         pitch = newqual.shape[1]
         lib = _N.load()
         need = int(-lib.kbbq_fastq_format(self._h, first, n, pitch, _N.ptr(newqual), None, 0))
-        buf = np.empty(max(need, 1), dtype=np.uint8)
+        buf = np.empty(max(need, 1), dtype=np.uint8) if out is None else out(max(need, 1))
         got = lib.kbbq_fastq_format(self._h, first, n, pitch, _N.ptr(newqual), _N.ptr(buf), need)
         assert got == need
         return buf[:need]
@@ -372,6 +373,27 @@ def _shard(n, shard):
     return shard_range(n, shard[0], shard[1])
 
 
+def _open_both(path_a, path_b):
+    """The two files of a pair, opened (mapped and line-indexed by the C++ reader) at the same time."""
+    import threading
+    got = {}
+
+    def open_b():
+        try:
+            got['b'] = NativeFastq(path_b)
+        except BaseException as e:           # noqa: BLE001 -- re-raised below
+            got['error'] = e
+    t = threading.Thread(target=open_b)
+    t.start()
+    try:
+        a = NativeFastq(path_a)              # the reference opens (and fails on) file A first
+    finally:
+        t.join()
+    if 'error' in got:
+        raise got['error']
+    return a, got['b']
+
+
 def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False):
     """Pass-1 input (recalibrate.py:56-57) through the C++ packer; same dictionary as pack_pair_py
     except that `text` is the NativeFastq of file A and `names` is filled lazily by callers.
@@ -379,8 +401,11 @@ def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False):
     the first host-detectable error are global) and packs only its own records [first, first + n);
     `total` is the global number of usable reads.  bands=True: instead of one set of planes at the widest pitch,
     `bands` holds the reads packed by length band (length_bands), each at its own pitch."""
-    A, B = NativeFastq(path_a), NativeFastq(path_b)
-    total, S, R, kind, idx = A.scan(B, infer_rg_flag)
+    from ._trace import stage
+    with stage('open+index'):
+        A, B = _open_both(path_a, path_b)
+    with stage('scan'):
+        total, S, R, kind, idx = A.scan(B, infer_rg_flag)
     pending = (idx, _SCAN_ERRORS[kind](idx), kind == 5) if kind else None
     pitch = pitch_for(S)
     lo, hi = _shard(total, shard)
@@ -388,9 +413,10 @@ def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False):
     common = dict(n=hi - lo, first=lo, total=total, pitch=pitch, S=S, R=R,
                   rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)},
                   text=A, pending_error=pending)
-    if bands:
-        return dict(common, bands=_fill_bands(A, B, infer_rg_flag, lo, hi))
-    seq, cseq, qual, meta = A.fill(B, infer_rg_flag, hi - lo, pitch, first=lo)
+    with stage('fill'):
+        if bands:
+            return dict(common, bands=_fill_bands(A, B, infer_rg_flag, lo, hi))
+        seq, cseq, qual, meta = A.fill(B, infer_rg_flag, hi - lo, pitch, first=lo)
     return dict(common, seq=seq, cseq=cseq, qual=qual, meta=meta)
 
 

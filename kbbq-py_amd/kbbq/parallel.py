@@ -7,7 +7,18 @@ solve replicated on every rank and a purely local apply.  SURVEY.md 8(e).
 Nothing here computes on the data path: K1 / K2 are the HIP kernels, the
 collective is torch.distributed's.
 """
+import sys
+
 import numpy as np
+
+
+def _dist():
+    """torch.distributed when a process group can exist: a process that has not imported torch has none (and the
+    single-GPU command line should not pay for the import before its files are being read)."""
+    if 'torch' not in sys.modules:
+        return None
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
 
 
 def shard_range(nreads, rank, world):
@@ -21,8 +32,8 @@ def shard_range(nreads, rank, world):
 def allreduce_tables(buf):
     """In-place SUM over all ranks of the concatenated count tables
     [pos_errs | pos_total | dinuc_errs | dinuc_total] (int64)."""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
+    dist = _dist()
+    if dist is not None:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 
@@ -31,8 +42,8 @@ def merge_rg_maps(local_names):
     """Global first-appearance read-group order from per-rank first-appearance lists
     (rank order == read order for contiguous shards).  Returns (global_names, remap) where
     remap[i] is the global id of this rank's local id i."""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    dist = _dist()
+    if dist is not None and dist.get_world_size() > 1:
         gathered = [None] * dist.get_world_size()
         dist.all_gather_object(gathered, list(local_names))
     else:
@@ -46,8 +57,8 @@ def merge_rg_maps(local_names):
 
 def world_rank():
     """(world size, rank) of the initialised process group, (1, 0) without one."""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
+    dist = _dist()
+    if dist is not None:
         return dist.get_world_size(), dist.get_rank()
     return 1, 0
 
@@ -57,9 +68,11 @@ def init_from_env():
     (backend "nccl" is RCCL on ROCm; KBBQ_DIST_BACKEND=gloo lets several ranks share one GPU for
     rehearsals).  No-op outside a launcher or when already initialised."""
     import os
+    if 'RANK' not in os.environ or int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        return world_rank()
     import torch
     import torch.distributed as dist
-    if 'RANK' not in os.environ or int(os.environ.get('WORLD_SIZE', '1')) <= 1 or dist.is_initialized():
+    if dist.is_initialized():
         return world_rank()
     backend = os.environ.get('KBBQ_DIST_BACKEND', 'nccl')
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -92,8 +105,8 @@ def init_from_env():
 
 
 def barrier():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    dist = _dist()
+    if dist is not None and dist.get_world_size() > 1:
         dist.barrier()
 
 
@@ -102,9 +115,9 @@ def raise_first_error(exc=None, index=None):
     the GLOBAL index of the read that caused it.  If any rank has one, ALL ranks raise the error of the
     smallest read index -- what a single process walking the reads in order would have raised -- so no
     rank is left waiting in a collective."""
-    import torch.distributed as dist
+    dist = _dist()
     mine = None if exc is None else (int(index if index is not None else 0), type(exc).__name__, str(exc))
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.get_world_size() > 1:
         everyone = [None] * dist.get_world_size()
         dist.all_gather_object(everyone, mine)
     else:
@@ -130,9 +143,9 @@ def in_rank_order(fn):
 
 def max_over_ranks(value):
     """Largest `value` over all ranks (the global longest read -> S)."""
-    import torch
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    dist = _dist()
+    if dist is not None and dist.get_world_size() > 1:
+        import torch
         backend = dist.get_backend()
         t = torch.tensor([int(value)], dtype=torch.int64,
                          device='cuda' if backend == 'nccl' else 'cpu')

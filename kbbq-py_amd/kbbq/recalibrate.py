@@ -21,6 +21,7 @@ from . import fastx
 from . import _device as dev
 from . import _solve
 from . import parallel
+from ._trace import stage
 from .gatk import applybqsr
 
 
@@ -62,21 +63,29 @@ def _tally_local(packed, minscore, maxscore):
     if R == 0 or S == 0:
         return None
     tables = dev.Tables(R, 2 * S)
+
+    def tally_band(band, batch, laid):
+        hints = dict(s_band=band['S'], s_min=band.get('Smin', 0))
+        if laid is not None:
+            part = dev.Tables(R, 2 * S)
+            try:
+                dev.accumulate(laid, part, minscore, **hints)
+                tables.buf += part.buf
+                band['laid'] = laid
+                return
+            except (IndexError, TypeError, dev.N.LutNeedsCheckedApply):
+                pass                         # bad input or an unsupported shape: the row-per-read kernel decides
+        dev.accumulate(batch, tables, minscore, **hints)
+
     for band in packed['bands']:
-        batch = dev.ReadBatch.from_host(band['seq'], band['qual'], band['meta'], cseq=band['cseq'])
+        with stage('H2D', sync=True):
+            batch = dev.ReadBatch.from_host(band['seq'], band['qual'], band['meta'], cseq=band['cseq'])
         band['batch'], band['laid'] = batch, None      # still resident: pass 2 re-uses them when it covers file A
-        laid = _lay_out(batch, R, band['S'])
+        with stage('layout', sync=True):
+            laid = _lay_out(batch, R, band['S'])
         try:
-            if laid is not None:
-                part = dev.Tables(R, 2 * S)
-                try:
-                    dev.accumulate(laid, part, minscore, s_band=band['S'], s_min=band.get('Smin', 0))
-                    tables.buf += part.buf
-                    band['laid'] = laid
-                    continue
-                except (IndexError, TypeError, dev.N.LutNeedsCheckedApply):
-                    pass                     # bad input or an unsupported shape: the row-per-read kernel decides
-            dev.accumulate(batch, tables, minscore, s_band=band['S'], s_min=band.get('Smin', 0))
+            with stage('K1', sync=True):
+                tally_band(band, batch, laid)
         except (IndexError, TypeError) as e:
             if hasattr(e, 'read_index'):
                 e.read_index = band['first'] + max(e.read_index, 0)
@@ -100,9 +109,39 @@ def _tally(packed, minscore, maxscore):
     return tables
 
 
+def _warm_up_while(work):
+    """work() -- host-only file reading -- while a thread pays the process's one-time device costs (dev.warm_up).
+    A failure of the warm-up (no GPU, no library) is raised after work() returned normally; an exception of
+    work() itself wins."""
+    import sys
+    import threading
+    failure = []
+    # the device this process selected (parallel.init_from_env); a process that has not imported torch yet is on 0
+    torch = sys.modules.get('torch')
+    device = torch.cuda.current_device() if torch is not None and torch.cuda.is_available() else 0
+
+    def warm():
+        try:
+            with stage('warm-up (overlapped)'):
+                dev.warm_up(device)
+        except BaseException as e:           # noqa: BLE001 -- re-raised below
+            failure.append(e)
+    t = threading.Thread(target=warm, daemon=True)
+    t.start()
+    try:
+        res = work()
+    finally:
+        with stage('warm-up wait'):
+            t.join()
+    if failure:
+        raise failure[0]
+    return res
+
+
 def _pack_and_tally(fastq, infer_rg, minscore, maxscore):
     world, rank = parallel.world_rank()
-    packed = fastx.pack_pair(fastq[0], fastq[1], infer_rg, shard=(rank, world) if world > 1 else None, bands=True)
+    packed = _warm_up_while(lambda: fastx.pack_pair(fastq[0], fastq[1], infer_rg,
+                                                    shard=(rank, world) if world > 1 else None, bands=True))
     err = packed.get('pending_error')
     if err is not None:
         # the reference fails at the FIRST offending read: let the kernel look at the reads
@@ -177,10 +216,12 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
     shard = (rank, world) if world > 1 else None
     packed, single = None, None
     if gatkreport is not None and os.path.exists(gatkreport):
-        text = fastx.NativeFastq(fastq[0])
+        def read_a():
+            text = fastx.NativeFastq(fastq[0])
+            return text, (fastx.pack_single(text, infer_rg, shard, bands=True) if text.n else None)
+        text, single = _warm_up_while(read_a)
         if text.n == 0:
             return
-        single = fastx.pack_single(text, infer_rg, shard, bands=True)
         tables = load_model(gatkreport, single['rg_to_int'])
     else:
         packed, tables = _pack_and_tally(fastq, infer_rg, 6, 42)
@@ -193,7 +234,8 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
             if rank == 0:
                 save_model(tables, packed['rg_to_int'], gatkreport)
             parallel.barrier()
-    lut, shape, _, _ = dev.solve(tables)
+    with stage('solve', sync=True):
+        lut, shape, _, _ = dev.solve(tables)
     R = shape[0]
     if packed is not None and packed['total'] == text.n:
         # pass 2 walks the same reads with the same first-appearance read groups (:141-148):
@@ -233,24 +275,61 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
                     e.read_index = band['first'] + max(e.read_index, 0)
                 raise
         return outs
-    outs = _collective(apply_shard, single['first'])
+    with stage('apply', sync=True):
+        outs = _collective(apply_shard, single['first'])
 
-    # recalibrate.py:153-156: '@' + name, sequence, '+', qualities -- rendered by the C++ writer in
-    # slabs, written through print() like the reference
-    def emit():
-        import sys
-        raw = getattr(sys.stdout, 'buffer', None)      # a text-only stdout (StringIO) gets print(), like the reference
-        step = 1 << 20
+    # recalibrate.py:153-156: '@' + name, sequence, '+', qualities -- rendered by the C++ writer in slabs.  A binary
+    # stdout gets the bytes (copy off the device, rendering and write(2) of successive slabs overlap); a text-only
+    # stdout (StringIO) gets print(), like the reference
+    def slabs(step):
+        k = 0
         for band, out in zip(single['bands'], outs):
             for first in range(0, band['n'], step):
-                m = min(step, band['n'] - first)
-                newq = out[first:first + m].cpu().numpy()
-                rendered = text.format_array(single['first'] + band['first'] + first, m, newq)
-                if raw is not None:
-                    sys.stdout.flush()
-                    raw.write(memoryview(rendered))
-                else:
-                    print(rendered.tobytes().decode('latin-1'), end='')
+                yield k, band, out, first, min(step, band['n'] - first)
+                k += 1
+
+    def emit_text():
+        for _, band, out, first, m in slabs(1 << 20):
+            newq = out[first:first + m].cpu().numpy()
+            rendered = text.format_array(single['first'] + band['first'] + first, m, newq)
+            print(rendered.tobytes().decode('latin-1'), end='')
+
+    def emit_bytes(raw):
+        import torch
+        from . import _egress
+        step = 1 << 18
+        widest = max([band['pitch'] for band in single['bands']] + [16])
+        staging = _egress.Slots(4, lambda nbytes: torch.empty(max(nbytes, step * widest), dtype=torch.uint8, pin_memory=True))
+        rendered = _egress.Slots(4, lambda nbytes: np.empty(nbytes + (nbytes >> 3), dtype=np.uint8))
+
+        def fetch(item):
+            k, band, out, first, m = item
+            with stage('D2H'), torch.cuda.device(out.device):       # a new thread starts on device 0
+                host = staging.get(k, m * band['pitch'])[:m * band['pitch']].view(m, band['pitch'])
+                host.copy_(out[first:first + m], non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+            return k, single['first'] + band['first'] + first, m, host.numpy()
+
+        def render(item):
+            k, first, m, newq = item
+            with stage('format'):
+                return text.format_array(first, m, newq, out=lambda nbytes: rendered.get(k, nbytes))
+
+        def write(buf):
+            with stage('write'):
+                raw.write(memoryview(buf))
+
+        _egress.pipeline(slabs(step), fetch, render, write)
+
+    def emit():
+        import sys
+        sys.stdout.flush()
+        raw = getattr(sys.stdout, 'buffer', None)
+        if raw is None:
+            emit_text()
+        else:
+            emit_bytes(raw)
+            raw.flush()
         sys.stdout.flush()
     parallel.in_rank_order(emit)
 

@@ -427,11 +427,16 @@ def test_cli_without_arguments_and_version(monkeypatch, capfd):
     assert e.value.code == 2
 
 
-def test_native_packer_agrees_with_numpy_twin_on_random_inputs(tmp_path):
+@pytest.mark.parametrize('scan_chunk', [None, 1, 3, 7])
+def test_native_packer_agrees_with_numpy_twin_on_random_inputs(tmp_path, monkeypatch, scan_chunk):
     """Differential test: the C++ packer (pack_pair) against the readable NumPy statement of the rules (pack_pair_py)
     on random FASTQ pairs with random defects -- same usable reads, same first offending read and exception class,
-    same planes, sidecars and read-group order."""
-    rng = np.random.default_rng(77)
+    same planes, sidecars and read-group order.  The scan walks chunks of reads in parallel and merges them in read
+    order: tiny chunks (KBBQ_SCAN_CHUNK) put the defects on, before and after chunk boundaries."""
+    if scan_chunk is not None:
+        monkeypatch.setenv('KBBQ_SCAN_CHUNK', str(scan_chunk))
+        monkeypatch.setenv('KBBQ_HOST_THREADS', '4')
+    rng = np.random.default_rng(77 + (scan_chunk or 0))
     acgt = np.array(list('ACGTN'))
     for case in range(120):
         n = int(rng.integers(0, 40))
@@ -471,3 +476,34 @@ def test_native_packer_agrees_with_numpy_twin_on_random_inputs(tmp_path):
         for k in ('seq', 'cseq', 'qual', 'meta'):
             assert np.array_equal(got[k], want[k]), (case, k)
         assert list(got['rg_to_int'])[:len(want['rg_to_int'])] == list(want['rg_to_int']), case
+
+
+def test_egress_pipeline_orders_items_and_surfaces_the_first_error():
+    """kbbq._egress.pipeline: items leave in order; an exception in the source or in any stage is re-raised in the
+    caller's thread after every stage thread has drained (no hang on the bounded queues)."""
+    from kbbq import _egress
+    out = []
+    _egress.pipeline(range(50), lambda x: x * 2, lambda x: x + 1, out.append)
+    assert out == [2 * i + 1 for i in range(50)]
+    _egress.pipeline([], lambda x: x, out.append)
+    _egress.pipeline(range(3), out.append)
+    assert out[-3:] == [0, 1, 2]
+
+    def boom(x):
+        if x == 6:
+            raise ValueError('six')
+        return x
+    for stages in ((boom, lambda x: x, out.append), (lambda x: x, boom, out.append), (lambda x: x, lambda x: x, boom)):
+        with pytest.raises(ValueError):
+            _egress.pipeline(range(200), *stages)
+
+    def source():
+        yield 1
+        raise KeyError('source')
+    with pytest.raises(KeyError):
+        _egress.pipeline(source(), lambda x: x, out.append)
+    # round-robin buffers grow on demand and are reused
+    made = []
+    slots = _egress.Slots(3, lambda nbytes: made.append(nbytes) or np.empty(nbytes, dtype=np.uint8))
+    assert slots.get(0, 10) is slots.get(3, 8) and slots.get(1, 10) is not slots.get(0, 10)
+    assert slots.get(0, 50).shape[0] == 50 and made == [10, 10, 50]

@@ -22,7 +22,7 @@ def harness(tmp_path_factory):
 
     def run(*args):
         env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='halt_on_error=1:print_stacktrace=1',
-                   KBBQ_HOST_THREADS='4')
+                   KBBQ_HOST_THREADS='4', KBBQ_SCAN_CHUNK='97')      # the scan's chunks on threads even for small inputs
         r = subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=300, env=env)
         assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
         assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
