@@ -336,7 +336,18 @@ int         kbbq_fastq_name(const kbbq_fastq* f, int64_t i, const char** name, i
 int         kbbq_fastq_rg_count(const kbbq_fastq* f);
 const char* kbbq_fastq_rg_name(const kbbq_fastq* f, int i);
 int         kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* info5);
+/* kbbq_fastq_open of both files (b may be NULL) + kbbq_fastq_scan on the library's own threads; _begin returns at
+ * once, _wait joins, hands over the readers and info5 and frees the job (call it exactly once).  File A's error is
+ * reported before file B's.  Lets a Python caller set its device up while the files are being read. */
+typedef struct kbbq_fastq_job kbbq_fastq_job;
+int         kbbq_fastq_pair_begin(const char* path_a, const char* path_b, int infer_rg, kbbq_fastq_job** job);
+int         kbbq_fastq_pair_wait(kbbq_fastq_job* job, kbbq_fastq** a, kbbq_fastq** b, int64_t* info5);
 int         kbbq_fastq_lengths(const kbbq_fastq* f, int64_t first, int64_t n, uint32_t* out);   /* sequence lengths */
+/* length bands of reads [first, first + n): maximal runs of reads of one length class (class = first entry of the
+ * ascending classes[] >= the length); out[run] = {lo, hi, longest, shortest non-empty}; returns the number of runs,
+ * or 1 run covering everything when there are more than max_runs */
+int         kbbq_fastq_length_runs(const kbbq_fastq* f, int64_t first, int64_t n, const uint32_t* classes, int nclasses,
+                                   int max_runs, int64_t* out);
 int         kbbq_fastq_fill(const kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t n, int pitch,
                             uint8_t* seq, uint8_t* cseq, uint8_t* qual, uint32_t* meta);
 /* the same for reads [first, first + n) -> rows [0, n): one rank's shard; read-group ids are those of the scan */

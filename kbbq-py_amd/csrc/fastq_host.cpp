@@ -12,6 +12,7 @@
 // host-detectable offender and its kind; the caller lets the device look at the reads before
 // it (and at it, for kind 5) before raising.
 #include "../../include/kbbq_hip.h"
+#include "host_threads.h"
 
 #include <algorithm>
 #include <atomic>
@@ -51,14 +52,7 @@ struct kbbq_fastq {
     ~kbbq_fastq() { if (mapped && buf) munmap((void*)buf, size); else free((void*)buf); }
 };
 
-static unsigned nthreads_for(size_t work)
-{
-    unsigned hw = std::thread::hardware_concurrency();
-    if (hw == 0) hw = 4;
-    const char* e = getenv("KBBQ_HOST_THREADS");
-    if (e && atoi(e) > 0) hw = (unsigned)atoi(e);
-    return (unsigned)std::max<size_t>(1, std::min<size_t>(hw, work / (1 << 20) + 1));
-}
+static unsigned nthreads_for(size_t work) { return kbbq_threads_for(work); }
 
 template <typename F> static void parallel_for(int64_t n, unsigned nt, F f)
 {
@@ -346,6 +340,49 @@ int kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* i
     return KBBQ_OK;
 }
 
+// Open + index both files of a pair (at the same time) and scan them, on threads of the library's own: the caller
+// -- Python, which would otherwise hold or wait for its interpreter lock between the calls -- is free to do its
+// one-time device set-up meanwhile.  kbbq_fastq_pair_wait joins, hands the two readers and the scan's info[5] over
+// and frees the job (call it exactly once); file A's error is reported before file B's, like two opens in a row.
+struct kbbq_fastq_job {
+    std::thread th;
+    std::string path_a, path_b; bool has_b = false; int infer_rg = 0;
+    kbbq_fastq* a = nullptr; kbbq_fastq* b = nullptr;
+    int rc = KBBQ_OK; std::string err; int64_t info[5] = {0, 0, 0, 0, 0};
+};
+
+int kbbq_fastq_pair_begin(const char* path_a, const char* path_b, int infer_rg, kbbq_fastq_job** out)
+{
+    if (!path_a || !out) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_pair_begin: NULL argument");
+    kbbq_fastq_job* j = new kbbq_fastq_job();
+    j->path_a = path_a; j->has_b = path_b != nullptr; if (path_b) j->path_b = path_b; j->infer_rg = infer_rg;
+    j->th = std::thread([j]() {
+        int rc_b = KBBQ_OK; std::string err_b;
+        std::thread tb;
+        if (j->has_b) tb = std::thread([&]() { rc_b = kbbq_fastq_open(j->path_b.c_str(), &j->b); if (rc_b) err_b = kbbq_last_error(); });
+        j->rc = kbbq_fastq_open(j->path_a.c_str(), &j->a);
+        if (j->rc) j->err = kbbq_last_error();
+        if (tb.joinable()) tb.join();
+        if (!j->rc && rc_b) { j->rc = rc_b; j->err = err_b; }
+        if (!j->rc) { j->rc = kbbq_fastq_scan(j->a, j->b, j->infer_rg, j->info); if (j->rc) j->err = kbbq_last_error(); }
+        if (j->rc) { delete j->a; delete j->b; j->a = j->b = nullptr; }
+    });
+    *out = j;
+    return KBBQ_OK;
+}
+
+int kbbq_fastq_pair_wait(kbbq_fastq_job* j, kbbq_fastq** a, kbbq_fastq** b, int64_t* info)
+{
+    if (!j) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_pair_wait: NULL job");
+    if (j->th.joinable()) j->th.join();
+    const int rc = j->rc;
+    if (rc) kbbq_set_error_(rc, j->err.c_str());
+    else if (!a || !info || (j->has_b && !b)) { delete j->a; delete j->b; delete j; return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_pair_wait: NULL argument"); }
+    else { *a = j->a; if (b) *b = j->b; memcpy(info, j->info, sizeof j->info); }
+    delete j;
+    return rc;
+}
+
 // Fill the padded planes for reads [0, n): seq / qual from `a`, cseq from `b` (b, cseq may be NULL).
 // Padding: 'N' in seq / cseq, 0 in qual (include/kbbq_hip.h).  Call kbbq_fastq_scan first (it
 // builds the read-group table used here).
@@ -356,6 +393,40 @@ int kbbq_fastq_lengths(const kbbq_fastq* f, int64_t first, int64_t n, uint32_t* 
         return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_lengths: bad argument");
     for (int64_t i = 0; i < n; ++i) out[i] = f->slen[first + i];
     return KBBQ_OK;
+}
+
+// Length bands of reads [first, first + n) (kbbq/fastx.py length_bands): maximal runs of reads whose lengths fall
+// into the same class -- class of a length = index of the first entry of classes[nclasses] (ascending) that is >= it,
+// empty reads counted as length 1.  out[run] = {lo, hi, longest, shortest non-empty (0: none)}, lo / hi relative to
+// `first`.  Returns the number of runs; when there are more than max_runs, ONE run covering everything.
+int kbbq_fastq_length_runs(const kbbq_fastq* f, int64_t first, int64_t n, const uint32_t* classes, int nclasses,
+                           int max_runs, int64_t* out)
+{
+    if (!f || !out || (nclasses > 0 && !classes) || max_runs < 1 || first < 0 || n < 0 || first + n > (int64_t)f->h0.size())
+        return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_length_runs: bad argument");
+    if (n == 0) return 0;
+    auto cls = [&](uint32_t len) { return (int)(std::lower_bound(classes, classes + nclasses, std::max<uint32_t>(len, 1)) - classes); };
+    int runs = 0, cur = -1;
+    uint32_t all_long = 0, all_short = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t L = f->slen[first + i];
+        all_long = std::max(all_long, L);
+        if (L && (all_short == 0 || L < all_short)) all_short = L;
+        if (runs > max_runs) continue;                         // too many: only the overall figures are still needed
+        const int c = cls(L);
+        if (c != cur) {
+            cur = c;
+            if (++runs > max_runs) continue;
+            int64_t* o = out + 4 * (runs - 1);
+            o[0] = i; o[1] = i + 1; o[2] = L; o[3] = L;
+        } else {
+            int64_t* o = out + 4 * (runs - 1);
+            o[1] = i + 1; o[2] = std::max<int64_t>(o[2], L);
+            if (L && (o[3] == 0 || L < o[3])) o[3] = L;
+        }
+    }
+    if (runs > max_runs) { out[0] = 0; out[1] = n; out[2] = all_long; out[3] = all_short; return 1; }
+    return runs;
 }
 
 int kbbq_fastq_fill(const kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t n, int pitch,

@@ -12,6 +12,7 @@
 // CIGAR operations are stored as (length << 4 | op) with BAM op codes MIDNSHP=X = 0..8; an unknown
 // operation letter is stored as op 15 and rejected by K4 (ValueError, like the reference's walk).
 #include "../../include/kbbq_hip.h"
+#include "host_threads.h"
 
 #include <algorithm>
 #include <atomic>
@@ -47,14 +48,7 @@ struct kbbq_sam {
 
 namespace {
 
-unsigned threads_for(size_t work)
-{
-    unsigned hw = std::thread::hardware_concurrency();
-    if (hw == 0) hw = 4;
-    const char* e = getenv("KBBQ_HOST_THREADS");
-    if (e && atoi(e) > 0) hw = (unsigned)atoi(e);
-    return (unsigned)std::max<size_t>(1, std::min<size_t>(hw, work / (1 << 20) + 1));
-}
+unsigned threads_for(size_t work) { return kbbq_threads_for(work); }
 
 template <typename F> void par_for(int64_t n, unsigned nt, F f)
 {

@@ -26,14 +26,26 @@ def _torch():
 
 def warm_up(device=0):
     """Everything the first call of a process pays once -- importing torch (and SciPy, which the solve's model
-    constants need), creating the HIP context, loading libkbbq_hip's code object with a first kernel launch --
-    so that a caller can run it on a thread while the host reads its input files."""
+    constants need), creating the HIP context, loading the code objects of libkbbq_hip and of the torch kernels the
+    path uses -- as a miniature run (64 synthetic pairs: tally, solve, apply), so that a caller can pay it while the
+    host reads its input files.  Does nothing the second time."""
+    global _warm
+    if _warm:
+        return
     torch = _torch()
     import scipy.special                      # noqa: F401
-    with torch.cuda.device(device):          # a new thread starts on device 0, whatever the process selected
-        context()
-        ReadBatch.synthetic(0, 64, 64, seed=1)
+    with torch.cuda.device(device):
+        batch = ReadBatch.synthetic(0, 128, 128, seed=1)
+        pairs = PairBatch.from_reads(batch)
+        tables = Tables(1, 2 * pairs.S)
+        accumulate(pairs, tables)
+        lut, shape, _, _ = solve(tables)
+        pairs.unpack(apply(pairs, lut, shape)).cpu()
         torch.cuda.synchronize()
+    _warm = True
+
+
+_warm = False
 
 
 def context(device=None):

@@ -92,7 +92,10 @@ PROTOTYPES = {
     'kbbq_fastq_rg_count': (_i, [_vp]),
     'kbbq_fastq_rg_name': (_c.c_char_p, [_vp, _i]),
     'kbbq_fastq_scan': (_i, [_vp, _vp, _i, _vp]),
+    'kbbq_fastq_pair_begin': (_i, [_c.c_char_p, _c.c_char_p, _i, _c.POINTER(_vp)]),
+    'kbbq_fastq_pair_wait': (_i, [_vp, _c.POINTER(_vp), _c.POINTER(_vp), _vp]),
     'kbbq_fastq_lengths': (_i, [_vp, _i64, _i64, _vp]),
+    'kbbq_fastq_length_runs': (_i, [_vp, _i64, _i64, _vp, _i, _i, _vp]),
     'kbbq_fastq_fill': (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     'kbbq_fastq_fill_range': (_i, [_vp, _vp, _i, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
     'kbbq_fastq_format': (_i64, [_vp, _i64, _i64, _i, _vp, _vp, _i64]),

@@ -246,9 +246,10 @@ from . import _native as _N
 class NativeFastq:
     """A FASTQ file opened by libkbbq_hip's host reader (kbbq_fastq_*)."""
 
-    def __init__(self, path):
-        self._h = _ct.c_void_p()
-        _N.check(_N.load().kbbq_fastq_open(str(path).encode(), _ct.byref(self._h)))
+    def __init__(self, path, _handle=None):
+        self._h = _ct.c_void_p() if _handle is None else _handle
+        if _handle is None:
+            _N.check(_N.load().kbbq_fastq_open(str(path).encode(), _ct.byref(self._h)))
         self.n = int(_N.load().kbbq_fastq_count(self._h))
 
     def close(self):
@@ -285,6 +286,16 @@ class NativeFastq:
         out = np.zeros(max(n, 1), dtype=np.uint32)
         _N.check(_N.load().kbbq_fastq_lengths(self._h, first, n, _N.ptr(out)))
         return out[:n]
+
+    def length_bands(self, first=0, n=None, max_bands=16):
+        """length_bands (below) of reads [first, first + n), computed by the reader."""
+        n = self.n - first if n is None else n
+        classes = np.asarray(BAND_CLASSES, dtype=np.uint32)
+        out = np.zeros((max_bands, 4), dtype=np.int64)
+        runs = _N.load().kbbq_fastq_length_runs(self._h, first, n, _N.ptr(classes), len(classes), max_bands, _N.ptr(out))
+        if runs < 0:
+            _N.check(runs)
+        return [tuple(int(x) for x in row) for row in out[:runs]]
 
     def fill(self, other, infer_rg_flag, n, pitch, first=0):
         """Planes and sidecar of reads [first, first + n) (rows 0..n-1)."""
@@ -356,8 +367,11 @@ def length_bands(lens, max_bands=16):
 
 def _fill_bands(A, B, infer_rg_flag, lo, hi):
     """Reads [lo, hi) packed band by band: [dict(first, n, S, pitch, seq, cseq, qual, meta)], `first` counted from lo."""
+    from ._trace import stage
     out = []
-    for b_lo, b_hi, longest, shortest in length_bands(A.lengths(lo, hi - lo)):
+    with stage('bands'):
+        bands = A.length_bands(lo, hi - lo)
+    for b_lo, b_hi, longest, shortest in bands:
         pitch = pitch_for(longest)
         seq, cseq, qual, meta = A.fill(B, infer_rg_flag, b_hi - b_lo, pitch, first=lo + b_lo)
         out.append(dict(first=b_lo, n=b_hi - b_lo, S=longest, Smin=shortest, pitch=pitch, seq=seq, cseq=cseq, qual=qual,
@@ -373,39 +387,45 @@ def _shard(n, shard):
     return shard_range(n, shard[0], shard[1])
 
 
-def _open_both(path_a, path_b):
-    """The two files of a pair, opened (mapped and line-indexed by the C++ reader) at the same time."""
-    import threading
-    got = {}
+class PairScan:
+    """Both files of a pair being opened (mapped, line-indexed) and scanned by the C++ reader on its own threads --
+    started by the constructor, which returns at once; result() waits.  The work needs no interpreter lock, so a
+    caller can import torch and set the device up meanwhile (recalibrate._pack_and_tally)."""
 
-    def open_b():
+    def __init__(self, path_a, path_b, infer_rg_flag):
+        self._job = _ct.c_void_p()
+        _N.check(_N.load().kbbq_fastq_pair_begin(str(path_a).encode(), None if path_b is None else str(path_b).encode(),
+                                                 1 if infer_rg_flag else 0, _ct.byref(self._job)))
+        self._has_b = path_b is not None
+
+    def result(self):
+        """(A, B or None, [total, S, R, kind, idx]); raises what opening file A, then file B, would have."""
+        job, self._job = self._job, None
+        if job is None:
+            raise RuntimeError('PairScan.result() may be called once')
+        a, b, info = _ct.c_void_p(), _ct.c_void_p(), np.zeros(5, dtype=np.int64)
+        _N.check(_N.load().kbbq_fastq_pair_wait(job, _ct.byref(a), _ct.byref(b), _N.ptr(info)))
+        return NativeFastq(None, _handle=a), (NativeFastq(None, _handle=b) if self._has_b else None), [int(x) for x in info]
+
+    def __del__(self):
         try:
-            got['b'] = NativeFastq(path_b)
-        except BaseException as e:           # noqa: BLE001 -- re-raised below
-            got['error'] = e
-    t = threading.Thread(target=open_b)
-    t.start()
-    try:
-        a = NativeFastq(path_a)              # the reference opens (and fails on) file A first
-    finally:
-        t.join()
-    if 'error' in got:
-        raise got['error']
-    return a, got['b']
+            if getattr(self, '_job', None) is not None:
+                self.result()                # joins the threads; the readers close with their wrappers
+        except Exception:
+            pass
 
 
-def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False):
+def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None):
     """Pass-1 input (recalibrate.py:56-57) through the C++ packer; same dictionary as pack_pair_py
     except that `text` is the NativeFastq of file A and `names` is filled lazily by callers.
     shard = (rank, world): every rank scans the whole pair (so read-group ids, the longest read and
     the first host-detectable error are global) and packs only its own records [first, first + n);
     `total` is the global number of usable reads.  bands=True: instead of one set of planes at the widest pitch,
-    `bands` holds the reads packed by length band (length_bands), each at its own pitch."""
+    `bands` holds the reads packed by length band (length_bands), each at its own pitch.  scan: a PairScan of the
+    same arguments started earlier."""
     from ._trace import stage
-    with stage('open+index'):
-        A, B = _open_both(path_a, path_b)
-    with stage('scan'):
-        total, S, R, kind, idx = A.scan(B, infer_rg_flag)
+    with stage('open+index+scan (wait)'):
+        A, B, (total, S, R, kind, idx) = (scan or PairScan(path_a, path_b, infer_rg_flag)).result()
     pending = (idx, _SCAN_ERRORS[kind](idx), kind == 5) if kind else None
     pitch = pitch_for(S)
     lo, hi = _shard(total, shard)

@@ -109,39 +109,21 @@ def _tally(packed, minscore, maxscore):
     return tables
 
 
-def _warm_up_while(work):
-    """work() -- host-only file reading -- while a thread pays the process's one-time device costs (dev.warm_up).
-    A failure of the warm-up (no GPU, no library) is raised after work() returned normally; an exception of
-    work() itself wins."""
+def _warm_up():
+    """The process's one-time device costs (dev.warm_up), paid while the C++ reader works on the input files."""
     import sys
-    import threading
-    failure = []
-    # the device this process selected (parallel.init_from_env); a process that has not imported torch yet is on 0
-    torch = sys.modules.get('torch')
+    torch = sys.modules.get('torch')         # the device this process selected (parallel.init_from_env), else 0
     device = torch.cuda.current_device() if torch is not None and torch.cuda.is_available() else 0
-
-    def warm():
-        try:
-            with stage('warm-up (overlapped)'):
-                dev.warm_up(device)
-        except BaseException as e:           # noqa: BLE001 -- re-raised below
-            failure.append(e)
-    t = threading.Thread(target=warm, daemon=True)
-    t.start()
-    try:
-        res = work()
-    finally:
-        with stage('warm-up wait'):
-            t.join()
-    if failure:
-        raise failure[0]
-    return res
+    with stage('warm-up'):
+        dev.warm_up(device)
 
 
 def _pack_and_tally(fastq, infer_rg, minscore, maxscore):
     world, rank = parallel.world_rank()
-    packed = _warm_up_while(lambda: fastx.pack_pair(fastq[0], fastq[1], infer_rg,
-                                                    shard=(rank, world) if world > 1 else None, bands=True))
+    scan = fastx.PairScan(fastq[0], fastq[1], infer_rg)       # the reader's own threads: no interpreter lock needed
+    _warm_up()
+    packed = fastx.pack_pair(fastq[0], fastq[1], infer_rg, shard=(rank, world) if world > 1 else None, bands=True,
+                             scan=scan)
     err = packed.get('pending_error')
     if err is not None:
         # the reference fails at the FIRST offending read: let the kernel look at the reads
@@ -216,12 +198,12 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
     shard = (rank, world) if world > 1 else None
     packed, single = None, None
     if gatkreport is not None and os.path.exists(gatkreport):
-        def read_a():
-            text = fastx.NativeFastq(fastq[0])
-            return text, (fastx.pack_single(text, infer_rg, shard, bands=True) if text.n else None)
-        text, single = _warm_up_while(read_a)
+        scan = fastx.PairScan(fastq[0], None, infer_rg)
+        _warm_up()
+        text = scan.result()[0]
         if text.n == 0:
             return
+        single = fastx.pack_single(text, infer_rg, shard, bands=True)
         tables = load_model(gatkreport, single['rg_to_int'])
     else:
         packed, tables = _pack_and_tally(fastq, infer_rg, 6, 42)
@@ -344,6 +326,7 @@ def recalibrate(bam, fastq, infer_rg=False, use_oq=False, set_oq=False, gatkrepo
     if bam is not None:
         recalibrate_bam(bam, use_oq, set_oq)
     elif fastq is not None:
-        recalibrate_fastq(fastq, infer_rg=infer_rg, gatkreport=gatkreport)
+        with stage('[recalibrate_fastq, wall]'):
+            recalibrate_fastq(fastq, infer_rg=infer_rg, gatkreport=gatkreport)
     else:
         raise ValueError('A BAM or FASTQ file should be provided for recalibration.')

@@ -9,12 +9,26 @@
 #include <string>
 #include <vector>
 
-static std::string g_err;
+static thread_local std::string g_err;
 int kbbq_set_error_(int code, const char* msg) { g_err = msg ? msg : ""; return code; }
 extern "C" const char* kbbq_last_error(void) { return g_err.c_str(); }
 
 static int run_pair(const char* pa, const char* pb, int infer)
 {
+    {   // the same through the background job: same outcome, nothing leaked on either path
+        kbbq_fastq_job* job = nullptr;
+        kbbq_fastq *ja = nullptr, *jb = nullptr; int64_t jinfo[5] = {0, 0, 0, 0, 0};
+        int jrc = kbbq_fastq_pair_begin(pa, pb, infer, &job);
+        if (!jrc) jrc = kbbq_fastq_pair_wait(job, &ja, pb ? &jb : nullptr, jinfo);
+        printf("job rc=%d n=%lld S=%lld R=%lld kind=%lld idx=%lld %s\n", jrc, (long long)jinfo[0], (long long)jinfo[1],
+               (long long)jinfo[2], (long long)jinfo[3], (long long)jinfo[4], jrc ? g_err.c_str() : "");
+        if (!jrc) {
+            int64_t runs[4 * 4]; const uint32_t classes[3] = {48, 96, 160};
+            const int k = kbbq_fastq_length_runs(ja, 0, kbbq_fastq_count(ja), classes, 3, 4, runs);
+            printf("length runs %d\n", k);
+            kbbq_fastq_close(ja); if (jb) kbbq_fastq_close(jb);
+        }
+    }
     kbbq_fastq *a = nullptr, *b = nullptr;
     int rc = kbbq_fastq_open(pa, &a);
     if (rc) { printf("open A rc=%d (%s)\n", rc, g_err.c_str()); return 0; }

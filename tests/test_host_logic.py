@@ -507,3 +507,25 @@ def test_egress_pipeline_orders_items_and_surfaces_the_first_error():
     slots = _egress.Slots(3, lambda nbytes: made.append(nbytes) or np.empty(nbytes, dtype=np.uint8))
     assert slots.get(0, 10) is slots.get(3, 8) and slots.get(1, 10) is not slots.get(0, 10)
     assert slots.get(0, 50).shape[0] == 50 and made == [10, 10, 50]
+
+
+def test_reader_length_bands_agree_with_the_numpy_statement(tmp_path):
+    """NativeFastq.length_bands (C++, over the reader's own length index) against fastx.length_bands (NumPy) on
+    ascending, ragged and empty-read inputs, ranges and the too-many-runs case."""
+    rng = np.random.default_rng(5)
+    for case in range(40):
+        n = int(rng.integers(0, 300))
+        kind = case % 4
+        lens = rng.integers(0 if kind == 3 else 1, 330, n)
+        if kind in (0, 3):
+            lens = np.sort(lens)
+        elif kind == 1:
+            lens = np.sort(rng.integers(140, 152, n))
+        recs = [('r%d' % i, 'A' * int(L), 'I' * int(L)) for i, L in enumerate(lens)]
+        f = fastx.NativeFastq(_write(tmp_path, 'b%d.fq' % case, recs))
+        assert f.n == n
+        assert f.length_bands() == fastx.length_bands(lens), (case, lens)
+        if n > 10:
+            lo, m = int(rng.integers(0, n // 2)), int(rng.integers(1, n // 2))
+            assert f.length_bands(lo, m) == fastx.length_bands(lens[lo:lo + m]), case
+            assert f.length_bands(lo, m, max_bands=2) == fastx.length_bands(lens[lo:lo + m], max_bands=2), case
