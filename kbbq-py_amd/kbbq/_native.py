@@ -116,6 +116,19 @@ class LutNeedsCheckedApply(KbbqHipError):
     """kbbq_ctx_status: the device-built LUT is not usable by the table-driven apply kernel."""
 
 
+def _preload_torch_hip_runtime():
+    import sys
+    if 'torch' in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')          # locates the package without importing it
+        path = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        import torch  # noqa: F401 -- an unexpected layout: the import maps the runtime itself
+
+
 def load():
     """dlopen libkbbq_hip.so and attach prototypes.  Raises if it is not built."""
     global _lib
@@ -127,8 +140,9 @@ def load():
             'this package has no CPU fallback.' % LIB_PATH)
     # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Two HIP runtimes in one
     # process cannot both open the GPU, so torch's must be the one already mapped when
-    # libkbbq_hip.so resolves its DT_NEEDED libamdhip64.so.7.
-    import torch  # noqa: F401
+    # libkbbq_hip.so resolves its DT_NEEDED libamdhip64.so.7.  Mapping that file is enough (torch finds it mapped
+    # when it is imported later): the host-side readers can start before the second-long `import torch`.
+    _preload_torch_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

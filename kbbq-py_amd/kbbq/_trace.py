@@ -6,7 +6,20 @@ import sys
 import time
 
 ON = bool(os.environ.get('KBBQ_TIMING'))
+TIMELINE = os.environ.get('KBBQ_TIMING') == '2'      # also every stage's start / end since the process started
 _acc = {}
+_events = []
+
+
+def _process_start():
+    try:
+        import psutil
+        return psutil.Process().create_time()
+    except Exception:
+        return _imported
+
+
+_imported = time.time()
 
 
 @contextlib.contextmanager
@@ -14,7 +27,7 @@ def stage(name, sync=False):
     if not ON:
         yield
         return
-    t0 = time.perf_counter()
+    t0, w0 = time.perf_counter(), time.time()
     try:
         yield
     finally:
@@ -24,6 +37,8 @@ def stage(name, sync=False):
                 torch.cuda.synchronize()
         s, k = _acc.get(name, (0.0, 0))
         _acc[name] = (s + time.perf_counter() - t0, k + 1)
+        if TIMELINE:
+            _events.append((w0, time.time(), name))
 
 
 def report(reset=True):
@@ -31,8 +46,16 @@ def report(reset=True):
         total = sum(s for s, _ in _acc.values())
         sys.stderr.write('kbbq stages: ' + '  '.join('%s %.3fs' % (n, s) for n, (s, _) in _acc.items())
                          + '  (sum %.3fs)\n' % total)
+        if TIMELINE:
+            t0 = _process_start()
+            sys.stderr.write('kbbq timeline (s since the process started; this module was imported at %.3f, now %.3f):\n'
+                             % (_imported - t0, time.time() - t0))
+            for a, b, n in sorted(_events):
+                if b - a >= 0.002:
+                    sys.stderr.write('  %7.3f .. %7.3f  %s\n' % (a - t0, b - t0, n))
         if reset:
             _acc.clear()
+            del _events[:]
 
 
 atexit.register(report)

@@ -387,6 +387,13 @@ def _shard(n, shard):
     return shard_range(n, shard[0], shard[1])
 
 
+def close_later(reader):
+    """Close a NativeFastq on a helper thread: unmapping GBs of file costs tens of milliseconds, which need not sit on
+    the path to the first kernel (the C call runs without the interpreter lock)."""
+    import threading
+    threading.Thread(target=reader.close, daemon=True).start()
+
+
 class PairScan:
     """Both files of a pair being opened (mapped, line-indexed) and scanned by the C++ reader on its own threads --
     started by the constructor, which returns at once; result() waits.  The work needs no interpreter lock, so a
@@ -433,11 +440,14 @@ def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None)
     common = dict(n=hi - lo, first=lo, total=total, pitch=pitch, S=S, R=R,
                   rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)},
                   text=A, pending_error=pending)
-    with stage('fill'):
-        if bands:
-            return dict(common, bands=_fill_bands(A, B, infer_rg_flag, lo, hi))
-        seq, cseq, qual, meta = A.fill(B, infer_rg_flag, hi - lo, pitch, first=lo)
-    return dict(common, seq=seq, cseq=cseq, qual=qual, meta=meta)
+    try:
+        with stage('fill'):
+            if bands:
+                return dict(common, bands=_fill_bands(A, B, infer_rg_flag, lo, hi))
+            seq, cseq, qual, meta = A.fill(B, infer_rg_flag, hi - lo, pitch, first=lo)
+        return dict(common, seq=seq, cseq=cseq, qual=qual, meta=meta)
+    finally:
+        close_later(B)                       # file B is not needed after the fill: unmap it off the critical path
 
 
 def pack_single(text, infer_rg_flag, shard=None, bands=False):
