@@ -529,3 +529,28 @@ def test_reader_length_bands_agree_with_the_numpy_statement(tmp_path):
             lo, m = int(rng.integers(0, n // 2)), int(rng.integers(1, n // 2))
             assert f.length_bands(lo, m) == fastx.length_bands(lens[lo:lo + m]), case
             assert f.length_bands(lo, m, max_bands=2) == fastx.length_bands(lens[lo:lo + m], max_bands=2), case
+
+
+def test_pair_scan_job_matches_the_step_by_step_reader(tmp_path):
+    """fastx.PairScan (both files opened and scanned on the reader's own threads) hands over what NativeFastq +
+    scan() give step by step; file A's failure is reported before file B's; a job nobody waits for is cleaned up."""
+    recs = [('r%d/%d_RG:Z:g%d' % (i // 2, 1 + (i & 1), (i // 2) % 3), 'ACGTN'[i % 5] * (20 + i // 8), 'I' * (20 + i // 8)) for i in range(64)]
+    fa, fb = _write(tmp_path, 'a.fq', recs), _write(tmp_path, 'b.fq', recs[:40])
+    for infer in (False, True):
+        A, B, info = fastx.PairScan(fa, fb, infer).result()
+        a, b = fastx.NativeFastq(fa), fastx.NativeFastq(fb)
+        assert (A.n, B.n) == (a.n, b.n) == (64, 40) and info == a.scan(b, infer) and A.rg_names() == a.rg_names()
+        assert info[0] == 40 and info[2] == (3 if infer else 1)
+        A1, none, info1 = fastx.PairScan(fa, None, infer).result()
+        assert none is None and info1 == a.scan(None, infer) and info1[0] == 64
+    missing = str(tmp_path / 'missing.fq')
+    for pa, pb, where in ((missing, fb, 'missing.fq'), (fa, missing, 'missing.fq'), (missing, str(tmp_path / 'gone.fq'), 'missing.fq')):
+        with pytest.raises(ValueError, match=where):
+            fastx.PairScan(pa, pb, False).result()
+    job = fastx.PairScan(fa, fb, True)
+    with pytest.raises(RuntimeError):
+        job.result(), job.result()
+    del job
+    fastx.PairScan(fa, fb, True)             # never waited for: joined and freed by the wrapper's destructor
+    import gc
+    gc.collect()
