@@ -112,3 +112,29 @@ def test_sam_reader(harness, oracle, tmp_path):
     for name, text in cases.items():
         harness('sam', _write(tmp_path / (name + '.sam'), text.encode('latin-1'), 'wb'))
     harness('sam', str(tmp_path / 'missing.sam'))
+
+
+def test_threaded_readers_under_thread_sanitizer(tmp_path, oracle):
+    """The same harness under ThreadSanitizer: the line index, the chunk-parallel scan, the background pair job, the
+    fill / format threads, the parked gammaln pool and the SAM reader, on inputs large enough to start every thread."""
+    exe = str(tmp_path / 'host_tsan')
+    csrc = os.path.join(ROOT, 'kbbq-py_amd', 'csrc')
+    cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=thread', '-pthread', '-o', exe,
+           os.path.join(ROOT, 'tests', 'native', 'host_sanitize.cpp'),
+           os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'solve_host.cpp'), os.path.join(csrc, 'sam_host.cpp'), '-lz']
+    if subprocess.run(cmd, capture_output=True).returncode != 0:
+        pytest.skip('this g++ cannot link -fsanitize=thread')
+    n = 20000
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 4, 36, 151, 3)
+    names = oracle.synth_names(0, n, 3, with_rg=True)
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, names, cseq, qual, meta)
+    import oracle_bqsr as OQ
+    sam = OQ.synth_bqsr_set(str(tmp_path), seed=3, npairs=3000, S=60)['sam']
+    env = dict(os.environ, KBBQ_HOST_THREADS='6', KBBQ_SCAN_CHUNK='501', TSAN_OPTIONS='halt_on_error=0')
+    for args in (['pair', fa, fb, '1'], ['pair', fa, '-', '0'], ['combiln'], ['sam', sam]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=env)
+        assert 'ThreadSanitizer' not in r.stderr, r.stderr[-3000:]
+        assert r.returncode == 0, (args, r.returncode, r.stderr[-2000:])
+    assert 'job rc=0 n=%d' % n in subprocess.run([exe, 'pair', fa, fb, '1'], capture_output=True, text=True, env=env).stdout
