@@ -403,13 +403,17 @@ def solve(tables, want_dq=False, minscore=MINSCORE):
     R, S2 = tables.R, tables.S2
     vectors = _solve.vectors_from_tables(*tables.to_host())
     meanq, rg_e, rg_t, q_e, q_t, p_e, p_t, d_e, d_t = vectors
-    aux = np.concatenate([_solve.combiln(rg_e, rg_t).ravel(), _solve.combiln(q_e, q_t).ravel(),
-                          _solve.combiln(p_e, p_t).ravel(), _solve.combiln(d_e, d_t).ravel()])
+    # the gammaln terms of all four levels in ONE call (elementwise: one wake-up of the library's parked threads)
+    aux = _solve.combiln(np.concatenate([rg_e.ravel(), q_e.ravel(), p_e.ravel(), d_e.ravel()]),
+                         np.concatenate([rg_t.ravel(), q_t.ravel(), p_t.ravel(), d_t.ravel()]))
     lib = N.load()
     assert aux.size == lib.kbbq_solve_aux_count(R, S2)
     dev = tables.buf.device
-    d_aux = torch.from_numpy(np.ascontiguousarray(aux, dtype=np.float64)).to(dev)
-    d_meanq = torch.from_numpy(np.ascontiguousarray(meanq, dtype=np.int32)).to(dev)
+    # one upload: [aux float64 | meanq int32]
+    host = np.concatenate([np.ascontiguousarray(aux, dtype=np.float64).view(np.uint8),
+                           np.ascontiguousarray(meanq, dtype=np.int32).view(np.uint8)])
+    d_host = torch.from_numpy(host).to(dev)
+    d_aux, d_meanq = d_host[:aux.size * 8], d_host[aux.size * 8:]
     post_q = torch.empty(R * NQ, dtype=torch.int32, device=dev)
     lut = torch.zeros(lib.kbbq_lut_bytes(R, NQ, S2), dtype=torch.uint8, device=dev)
     dq = torch.empty(lib.kbbq_solve_dq_count(R, S2), dtype=torch.int32, device=dev) if want_dq else None
