@@ -10,6 +10,7 @@ import numpy as np
 from . import aln
 from . import compare_reads
 from . import fastx
+from . import parallel
 
 
 def get_ref_dict(reffilename):
@@ -74,27 +75,34 @@ class _Genome:
         self.sizes = {c: len(a) for c, a in refdict.items()}
 
 
-def _read_arrays(reads, genome, flip_reverse):
+def _read_arrays(reads, genome, flip_reverse, rows=None):
     """Host arrays K4 needs, from an aln.AlignmentFile (native reader: vectorised) or from a list of
-    pysam-like read objects (one Python pass; the form the reference's own tests use)."""
+    pysam-like read objects (one Python pass; the form the reference's own tests use).  rows = (lo, hi): only
+    those alignments (one rank's shard); the row pitch is the whole file's, so shards agree on it."""
     if isinstance(reads, aln.AlignmentFile):
         b = reads.batch()
-        n = b.n
-        lens = b.qlen.astype(np.uint32)
-        pitch = fastx.pitch_for(int(lens.max()) if n else 1)
-        seq = b.plane(0, pitch)
+        lo, hi = (0, b.n) if rows is None else rows
+        sl = slice(lo, hi)
+        n = hi - lo
+        lens = b.qlen[sl].astype(np.uint32)
+        pitch = fastx.pitch_for(int(b.qlen.max()) if b.n else 1)
+        seq = b.plane(0, pitch, lo, n)
         sizes = np.array([genome.sizes[c] for c in b.contig_names] + [0], dtype=np.int64)      # KeyError: unknown contig
         offs = np.array([genome.offset[c] for c in b.contig_names] + [0], dtype=np.int64)
-        size = sizes[b.contig] if n else np.zeros(0, np.int64)
-        start = np.minimum(np.maximum(b.pos, 0), size)               # Python slice clamping of the reference window
-        end = np.minimum(np.maximum(b.pos + b.ref_span, start), size)
-        ref_start = (offs[b.contig] if n else np.zeros(0, np.int64)) + start
+        contig, pos = b.contig[sl], b.pos[sl]
+        size = sizes[contig] if n else np.zeros(0, np.int64)
+        start = np.minimum(np.maximum(pos, 0), size)                 # Python slice clamping of the reference window
+        end = np.minimum(np.maximum(pos + b.ref_span[sl], start), size)
+        ref_start = (offs[contig] if n else np.zeros(0, np.int64)) + start
         ref_len = (end - start).astype(np.int32)
-        flip = ((b.flag & 16) != 0).astype(np.uint8) if flip_reverse else np.zeros(n, dtype=np.uint8)
-        return n, lens, pitch, seq, ref_start, ref_len, b.cig_off, b.cig_n, b.cigar, flip
+        flip = ((b.flag[sl] & 16) != 0).astype(np.uint8) if flip_reverse else np.zeros(n, dtype=np.uint8)
+        return n, lens, pitch, seq, ref_start, ref_len, b.cig_off[sl], b.cig_n[sl], b.cigar, flip   # offsets into the whole CIGAR array
+    longest = max([len(r.query_sequence) for r in reads] + [1])
+    if rows is not None:
+        reads = reads[rows[0]:rows[1]]
     n = len(reads)
     lens = np.array([len(r.query_sequence) for r in reads], dtype=np.uint32)
-    pitch = fastx.pitch_for(int(lens.max()) if n else 1)
+    pitch = fastx.pitch_for(longest)
     seq = np.zeros((max(n, 1), pitch), dtype=np.uint8)
     ref_start = np.zeros(n, dtype=np.int64); ref_len = np.zeros(n, dtype=np.int32)
     cig_off = np.zeros(n, dtype=np.uint32); cig_n = np.zeros(n, dtype=np.uint32)
@@ -115,13 +123,14 @@ def _read_arrays(reads, genome, flip_reverse):
     return n, lens, pitch, seq, ref_start, ref_len, cig_off, cig_n, np.array(cigar, dtype=np.uint32), flip
 
 
-def _flag_batch(reads, genome, flip_reverse, keep=None):
+def _flag_batch(reads, genome, flip_reverse, keep=None, rows=None):
     """K4 over aligned reads (an aln.AlignmentFile or a list of read objects) -> (err, skip) device planes
-    [n, pitch], lens (host).  `keep`, a dict, receives the device seq plane for callers that go on to K6."""
+    [n, pitch], lens (host).  `keep`, a dict, receives the device seq plane for callers that go on to K6.
+    rows = (lo, hi): only those alignments (one rank's shard)."""
     from . import _device as dev
     from . import _native as N
     torch = dev._torch()
-    n, lens, pitch, seq, ref_start, ref_len, cig_off, cig_n, cigar, flip = _read_arrays(reads, genome, flip_reverse)
+    n, lens, pitch, seq, ref_start, ref_len, cig_off, cig_n, cigar, flip = _read_arrays(reads, genome, flip_reverse, rows)
     pad = lambda a, dt: np.ascontiguousarray(a if len(a) else np.zeros(1), dtype=dt)
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     d_seq, d_len = up(seq), up(pad(lens, np.uint32).view(np.int32))
@@ -163,8 +172,8 @@ def _bam_names(reads):
     return [get_bam_readname(r) for r in reads]
 
 
-def _count_q(qual, err, skip, lens, pitch, qoffset):
-    """K5 -> (numerrs[256], numtotal[256]) as int64 host arrays."""
+def _count_q(qual, err, skip, lens, pitch, qoffset, reduce=False):
+    """K5 -> (numerrs[256], numtotal[256]) as int64 host arrays; reduce: summed over all ranks."""
     from . import _device as dev
     from . import _native as N
     torch = dev._torch()
@@ -175,6 +184,8 @@ def _count_q(qual, err, skip, lens, pitch, qoffset):
     N.check(N.load().kbbq_count_q_dev(ctx.handle, N.ptr(qual), N.ptr(err), N.ptr(skip), N.ptr(d_len),
                                       n, pitch, qoffset, N.ptr(counts)))
     ctx.status()
+    if reduce:
+        parallel.allreduce_tables(counts)                        # one 4 KB sum over the ranks' shards
     h = counts.cpu().numpy()
     return h[256:].copy(), h[:256].copy()
 
@@ -231,22 +242,26 @@ def get_bamread_quals(read, use_oq=False):
     return np.array(read.query_qualities, dtype=np.int_)
 
 
-def _qual_plane(reads, lens, pitch, use_oq):
-    """uint8 plane of phred values (not characters) per read."""
+def _qual_plane(reads, lens, pitch, use_oq, rows=None):
+    """uint8 plane of phred values (not characters) per read (of alignments rows = (lo, hi) only)."""
     if isinstance(reads, aln.AlignmentFile):
         b = reads.batch()
-        have = b.oq_len if use_oq else b.qual_len
-        if use_oq and b.n and int(have.min()) < 0:
+        lo, hi = (0, b.n) if rows is None else rows
+        n = hi - lo
+        have = (b.oq_len if use_oq else b.qual_len)[lo:hi]
+        if use_oq and n and int(have.min()) < 0:
             raise KeyError("tag 'OQ' not present")
-        if b.n and np.any(have != lens):
+        if n and np.any(have != lens):
             i = int(np.flatnonzero(have != lens)[0])
-            raise IndexError('boolean index did not match indexed array: read %d has %d qualities for %d bases'
-                             % (i, int(have[i]), int(lens[i])))
-        chars = b.plane(2 if use_oq else 1, pitch)
-        inside = np.arange(pitch)[None, :] < np.asarray(lens)[:, None] if b.n else np.zeros((1, pitch), dtype=bool)
-        if b.n and int(chars[:b.n][inside].min(initial=255)) < 33:
+            raise _at(IndexError('boolean index did not match indexed array: read %d has %d qualities for %d bases'
+                                 % (lo + i, int(have[i]), int(lens[i]))), i)
+        chars = b.plane(2 if use_oq else 1, pitch, lo, n)
+        inside = np.arange(pitch)[None, :] < np.asarray(lens)[:, None] if n else np.zeros((1, pitch), dtype=bool)
+        if n and int(chars[:n][inside].min(initial=255)) < 33:
             raise ValueError('qualities must lie in 0..255')
-        return np.where(inside, chars[:max(b.n, 1)] - 33, 0).astype(np.uint8)
+        return np.where(inside, chars[:max(n, 1)] - 33, 0).astype(np.uint8)
+    if rows is not None:
+        reads = reads[rows[0]:rows[1]]
     q = np.zeros((max(len(reads), 1), pitch), dtype=np.uint8)
     for i, r in enumerate(reads):
         v = get_bamread_quals(r, use_oq)
@@ -259,17 +274,47 @@ def _qual_plane(reads, lens, pitch, use_oq):
     return q
 
 
+def _at(exc, index):
+    """Tag an exception with the read of this rank's shard it is about (as the kernels' status does): the ranks then
+    agree on the first one (parallel.raise_first_error)."""
+    exc.read_index = int(index)
+    return exc
+
+
+def _on_all_ranks(fn, first=0):
+    """fn() on this rank's shard; an exception of any rank's data is raised by every rank (the one of the smallest
+    read index), so that nobody is left waiting in the sum of the counts."""
+    exc, res = None, None
+    try:
+        res = fn()
+    except (IndexError, TypeError, ValueError, KeyError) as e:
+        exc = e
+    parallel.raise_first_error(exc, None if exc is None else first + max(getattr(exc, 'read_index', 0), 0))
+    return res
+
+
 def benchmark_bam(bamfile, ref, var_sites, use_oq=False, bedfh=None):
+    """Under torch.distributed (parallel.init_from_env) every rank flags and counts a contiguous shard of the
+    alignments; the per-quality counts are summed with one allreduce (SURVEY 8(e) applied to this path)."""
     from . import _device as dev
     torch = dev._torch()
     fullskips = get_full_skips(ref, var_sites, bedfh)
     reads = bamfile if isinstance(bamfile, aln.AlignmentFile) else list(bamfile)
-    err, skip, lens, pitch = _flag_batch(reads, _Genome(ref, fullskips), flip_reverse=False)
-    qual = torch.from_numpy(_qual_plane(reads, lens, pitch, use_oq)).cuda()
-    return _actual_q(*_count_q(qual, err, skip, lens, pitch, 0))
+    world, rank = parallel.world_rank()
+    rows = parallel.shard_range(len(reads), rank, world) if world > 1 else None
+    genome = _Genome(ref, fullskips)
+
+    def shard():
+        err, skip, lens, pitch = _flag_batch(reads, genome, flip_reverse=False, rows=rows)
+        qual = torch.from_numpy(_qual_plane(reads, lens, pitch, use_oq, rows)).cuda()
+        return qual, err, skip, lens, pitch
+    qual, err, skip, lens, pitch = _on_all_ranks(shard, rows[0] if rows else 0)
+    return _actual_q(*_count_q(qual, err, skip, lens, pitch, 0, reduce=world > 1))
 
 
 def benchmark_fastq(fqfile, bamfile, ref, var_sites, bedfh=None):
+    """Under torch.distributed every rank counts a contiguous shard of the FASTQ reads (the alignments they map to
+    are anywhere in the file: each rank flags all of them -- K4 is a fraction of the work) and the counts are summed."""
     from . import _device as dev
     torch = dev._torch()
     fullskips = get_full_skips(ref, var_sites, bedfh)
@@ -284,16 +329,24 @@ def benchmark_fastq(fqfile, bamfile, ref, var_sites, bedfh=None):
             row[name] = i                                            # later reads replace earlier ones (dict)
         idx = np.array([row[fq.name(i).split('_')[0]] for i in range(fq.n)], dtype=np.int64)   # KeyError if absent
     n, S, _, kind, bad = fq.scan(None, False)
-    _, _, fqual, fmeta = fq.fill(None, False, fq.n, max(pitch, fastx.pitch_for(S)))
+    world, rank = parallel.world_rank()
+    lo, hi = parallel.shard_range(fq.n, rank, world) if world > 1 else (0, fq.n)
+    m = hi - lo
+    idx = idx[lo:hi]
+    _, _, fqual, fmeta = fq.fill(None, False, m, max(pitch, fastx.pitch_for(S)), first=lo)
     flens = (fmeta & 0xFFFF).astype(np.uint32)
-    if np.any(flens != lens[idx]):
-        raise IndexError('boolean index did not match indexed array: FASTQ and BAM read lengths differ')
-    d_idx = torch.from_numpy(idx).cuda()
+
+    def check():
+        if np.any(flens != lens[idx]):
+            raise _at(IndexError('boolean index did not match indexed array: FASTQ and BAM read lengths differ'),
+                      int(np.flatnonzero(flens != lens[idx])[0]))
+    _on_all_ranks(check, lo)
+    d_idx = torch.from_numpy(np.ascontiguousarray(idx)).cuda()
     fp = fqual.shape[1]
-    e = torch.zeros((max(fq.n, 1), fp), dtype=torch.uint8, device='cuda'); s = torch.zeros_like(e)
-    if fq.n:
-        e[:fq.n, :pitch] = err.index_select(0, d_idx); s[:fq.n, :pitch] = skip.index_select(0, d_idx)
-    return _actual_q(*_count_q(torch.from_numpy(fqual).cuda(), e, s, flens, fp, 33))
+    e = torch.zeros((max(m, 1), fp), dtype=torch.uint8, device='cuda'); s = torch.zeros_like(e)
+    if m:
+        e[:m, :pitch] = err.index_select(0, d_idx); s[:m, :pitch] = skip.index_select(0, d_idx)
+    return _actual_q(*_count_q(torch.from_numpy(fqual).cuda(), e, s, flens, fp, 33, reduce=world > 1))
 
 
 def print_benchmark(actual_q, label, nbases):
@@ -314,4 +367,5 @@ def benchmark(bamfile, fafile, vcffile, fastqfile=None, label=None, use_oq=False
     else:
         actual_q, nbases = benchmark_bam(bam, ref, var_sites, use_oq, bedfh)
         label = (bamfile if label is None else label)
-    print_benchmark(actual_q, label, nbases)
+    if parallel.world_rank()[1] == 0:                                # every rank holds the same totals
+        print_benchmark(actual_q, label, nbases)

@@ -136,10 +136,12 @@ def trim_bamread(read, boundary=_UNSET):
 def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxscore=42):
     """The nine model vectors from aligned reads, a FASTA reference and known variant sites
     (reference bqsr.py:52-123): K4 -> K6 -> K1.  Every read must have the first read's length
-    (the reference indexes with masks of that length: IndexError otherwise); quality = OQ tag."""
+    (the reference indexes with masks of that length: IndexError otherwise); quality = OQ tag.
+    Under torch.distributed (parallel.init_from_env) every rank runs the three kernels on a contiguous shard of the
+    alignments and the count tables are summed with one allreduce, as in kbbq.recalibrate."""
     from .. import _device as dev
     from .. import _native as N
-    from .. import _solve, aln, benchmark
+    from .. import _solve, aln, benchmark, fastx, parallel
     if maxscore != 42:
         raise ValueError('the Q axis of the device tables is fixed at 43 (maxscore = 42)')
     torch = dev._torch()
@@ -158,8 +160,7 @@ def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxsc
     if n == 0:
         raise StopIteration                                                    # next(bamfileobj) at :71
     genome = benchmark._Genome(ref, fullskips)
-    kept = {}
-    err, skip, lens, pitch = benchmark._flag_batch(reads, genome, flip_reverse=False, keep=kept)
+    world, rank = parallel.world_rank()
     bad_length = None
     if native:
         # arrays straight from the SAM reader; only reads whose adaptor boundary falls inside them need a CIGAR pass
@@ -170,7 +171,7 @@ def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxsc
             raise KeyError("tag 'RG' not present" if b.rg[i] == -1 else b._text(1, i).split('RG:Z:')[1].split('\t')[0])
         if int(b.oq_len.min()) < 0:
             raise KeyError("tag 'OQ' not present")
-        oq = b.plane(2, pitch)
+        lens = b.qlen.astype(np.uint32)
         wrong = np.flatnonzero((b.oq_len != S) | (lens != S))
         if wrong.size:
             bad_length = int(wrong[0])
@@ -191,33 +192,44 @@ def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxsc
         flags = (rev.astype(np.uint32) | (((b.flag & 128) != 0).astype(np.uint32) << 1) | (b.rg.astype(np.uint32) << 16))
     else:
         S = len(reads[0].query_qualities)
-        oq = np.zeros((n, pitch), dtype=np.uint8)
+        lens = np.array([len(r.query_sequence) for r in reads], dtype=np.uint32)
+        pitch_all = fastx.pitch_for(int(lens.max()))
+        oq_all = np.zeros((n, pitch_all), dtype=np.uint8)
         clip = np.zeros(n, dtype=np.uint32); trim = np.zeros(n, dtype=np.uint32); flags = np.zeros(n, dtype=np.uint32)
         for i, r in enumerate(reads):
             rg = rg_to_int[r.get_tag('RG')]
             q = aln.codes(r.get_tag('OQ'))
             if (len(q) != S or lens[i] != S) and bad_length is None:
                 bad_length = i
-            m = min(len(q), pitch)
-            oq[i, :m] = q[:m]
+            m = min(len(q), pitch_all)
+            oq_all[i, :m] = q[:m]
             clip[i] = r.query_alignment_start | (r.query_alignment_end << 16)
             lo, hi = _trim_range(r)
             trim[i] = lo | (hi << 16)
             flags[i] = (1 if r.is_reverse else 0) | (2 if r.is_read2 else 0) | (rg << 16)
     upto = n if bad_length is None else bad_length       # reads before the offending one are still examined
+    lo, hi = parallel.shard_range(upto, rank, world) if world > 1 else (0, upto)      # this rank's alignments
+    m = hi - lo
     tables = dev.Tables(max(R, 1), 2 * S)
-    if upto:
+
+    def shard():
+        kept = {}
+        err, skip, _, pitch = benchmark._flag_batch(reads, genome, flip_reverse=False, keep=kept, rows=(lo, hi))
+        oq = reads.batch().plane(2, pitch, lo, m) if native else oq_all[lo:hi, :pitch]
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
         d_seq, d_oq = kept['seq'], up(oq)
-        d_len, d_clip, d_trim, d_flags = (up(x[:max(upto, 1)].view(np.int32)) for x in (lens.astype(np.uint32), clip, trim, flags))
-        batch = dev.ReadBatch(upto, pitch, with_corrected=True)
+        d_len, d_clip, d_trim, d_flags = (up(x[lo:hi].view(np.int32)) for x in (lens, clip, trim, flags))
+        batch = dev.ReadBatch(m, pitch, with_corrected=True)
         ctx = dev.context()
         N.check(N.load().kbbq_canonical_reads_dev(
             ctx.handle, N.ptr(d_seq), N.ptr(d_oq), N.ptr(err), N.ptr(skip), N.ptr(d_len), N.ptr(d_clip),
-            N.ptr(d_trim), N.ptr(d_flags), upto, pitch, S, minscore, 6,
+            N.ptr(d_trim), N.ptr(d_flags), m, pitch, S, minscore, 6,
             N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual), N.ptr(batch.meta)))
         ctx.status()
         dev.accumulate(batch, tables, minscore, dinuc_minscore=6)
+    benchmark._on_all_ranks(shard if m else (lambda: None), lo)
+    if world > 1:
+        parallel.allreduce_tables(tables.buf)
     if bad_length is not None:
         raise IndexError('boolean index did not match indexed array along axis 0; size of axis is %d but size of '
                          'corresponding boolean axis is %d' % (S, int(lens[bad_length])))

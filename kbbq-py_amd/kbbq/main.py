@@ -18,6 +18,8 @@ def recalibrate(args):
 
 def benchmark(args):
     from . import benchmark as _bm
+    from . import parallel
+    parallel.init_from_env()          # one process per GPU under torch.distributed.run; no-op otherwise
     _bm.benchmark(bamfile=args.bam, fafile=args.reference, vcffile=args.vcf, fastqfile=args.fastq,
                   label=args.label, use_oq=args.use_oq, bedfh=args.bedfile)
 

@@ -345,3 +345,52 @@ def test_length_bands_of_a_mixed_length_input(dev, oracle):
                                   meta[mixed], cseq=np.ascontiguousarray(host[1][mixed, :304]))
     with pytest.raises(IndexError):
         dev.accumulate(dev.group_by_rg(odd, nrg), dev.Tables(nrg, 2 * S), s_band=300, s_min=int(lens[-64]))
+
+
+@pytest.mark.parametrize('name', ['bench_a', 'bench_b'])
+def test_two_ranks_print_the_reference_benchmark(dev, oracle, name, tmp_path):
+    """`kbbq benchmark` under torch.distributed.run with 2 ranks: alignments (FASTQ reads) sharded, the per-quality
+    counts summed with one allreduce, rank 0 prints the single-process (= reference) table."""
+    import oracle_benchmark as OB
+    from conftest import load_golden
+    info, _ = load_golden(name)
+    paths = OB.synth_truthset(str(tmp_path), **info['case'])
+    for tag, extra in (('bam', []), ('fastq', ['-f', paths['fq']])):
+        argv = ['benchmark', '-b', paths['sam'], '-r', paths['fa'], '-v', paths['vcf'], '-d', paths['bed'], '-l', 'lbl'] + extra
+        r = _run_ranks(2, argv)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert r.stdout.decode() == info['printed'][tag], tag
+
+
+def test_two_ranks_tally_alignments_like_one(dev, oracle, tmp_path):
+    """kbbq.gatk.bqsr.bam_to_bqsr_covariates on 2 ranks (K4 -> K6 -> K1 on shards of the alignments, one allreduce of
+    the tables): the nine vectors of the reference golden; a read of another length stops every rank."""
+    import json, os, socket, subprocess, sys
+    from conftest import ROOT
+    from test_oracle_bqsr import VEC, _inputs
+
+    def run(paths, native, out):
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, KBBQ_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.join(ROOT, 'tests', 'dist_api_worker.py'),
+               paths['sam'], paths['fa'], paths['vcf'], native, out]
+        return subprocess.run(cmd, env=env, capture_output=True, timeout=300)
+    info, gold, paths = _inputs('bqsr_a', tmp_path, oracle)
+    for native in ('1', '0'):
+        out = str(tmp_path / ('vec%s.json' % native))
+        r = run(paths, native, out)
+        assert r.returncode == 0, r.stderr.decode()[-8000:]
+        got = json.load(open(out))['vectors']
+        for k, g in zip(VEC, got):
+            assert np.array_equal(np.array(g, dtype=np.int64), gold[k]), (native, k)
+    # the last alignment loses a base: the IndexError of the reference on every rank, after the reads before it
+    lines = open(paths['sam']).read().rstrip('\n').split('\n')
+    f = lines[-1].split('\t')
+    f[5] = '%dM' % (len(f[9]) - 1); f[9] = f[9][:-1]; f[10] = f[10][:-1]
+    lines[-1] = '\t'.join(x if not x.startswith('OQ:Z:') else x[:-1] for x in f)
+    open(paths['sam'], 'w').write('\n'.join(lines) + '\n')
+    out = str(tmp_path / 'err.json')
+    r = run(paths, '1', out)
+    assert r.returncode != 0 and json.load(open(out)) == {'error': 'IndexError'}
+    assert r.stderr.decode().count('IndexError') >= 2
