@@ -1012,35 +1012,60 @@ struct K5Params {
     u64* status;
 };
 
-// lane <-> 16-byte chunk; LDS histograms (256 totals + 256 errors, u32) per workgroup
-__global__ __launch_bounds__(256) void k5_count_q(K5Params p)
+// lane <-> 16-byte chunk.  LDS: [257 bins][16 copies] u32, errs << 16 | total (copy = lane & 15: the 40-odd bins in
+// use are hot; copies cut the same-address collisions of a wave's atomic 16-fold), bin 256 = trash (skipped sites,
+// bytes past the read, values below the offset) so that every byte costs exactly one unconditional LDS atomic.
+// 16-bit halves: a copy receives at most 16 lanes x 16 bytes per workgroup iteration -> flushed every 255 iterations.
+#define K5_THREADS 256
+#define K5_COPIES 16
+#define K5_FLUSH_ITERS (65535 / ((K5_THREADS / K5_COPIES) * 16))
+__global__ __launch_bounds__(K5_THREADS) void k5_count_q(K5Params p)
 {
-    __shared__ u32 h[512];
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) h[i] = 0u;
+    __shared__ u32 h[257 * K5_COPIES];
+    for (int i = threadIdx.x; i < 257 * K5_COPIES; i += blockDim.x) h[i] = 0u;
     __syncthreads();
     const long long nchunks = p.nreads * p.cpr;
-    // a workgroup adds at most 2^31 counts into its u32 bins before flushing
-    for (long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks;
-         ch += (long long)gridDim.x * blockDim.x) {
-        const long long r = ch / p.cpr;
-        const int j = (int)(ch - r * p.cpr);
-        const int nb = (int)p.len[r] - 16 * j;
-        if (nb <= 0) continue;
-        const size_t off = (size_t)r * p.pitch + (size_t)16 * j;
-        const uint4 qv = *reinterpret_cast<const uint4*>(p.qual + off);
-        const uint4 ev = *reinterpret_cast<const uint4*>(p.err + off);
-        const uint4 sv = *reinterpret_cast<const uint4*>(p.skip + off);
-        const u32 q[4] = {qv.x, qv.y, qv.z, qv.w}, e[4] = {ev.x, ev.y, ev.z, ev.w}, s[4] = {sv.x, sv.y, sv.z, sv.w};
-        for (int i = 0; i < 16 && i < nb; ++i) {
-            const int sh = 8 * (i & 3);
-            if ((s[i >> 2] >> sh) & 0xFFu) continue;
-            const int qq = (int)((q[i >> 2] >> sh) & 0xFFu) - p.qoffset;
-            if (qq < 0) { flag(p.status, ST_RANGE, r); continue; }      // np.bincount rejects negative values: ValueError
-            atomicAdd(&h[qq], 1u);
-            if ((e[i >> 2] >> sh) & 0xFFu) atomicAdd(&h[256 + qq], 1u);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long iters = (nchunks + stride - 1) / stride;                 // the same for every thread: barriers are safe
+    const u32 copy = threadIdx.x & (K5_COPIES - 1);
+    auto flush = [&]() {
+        __syncthreads();
+        for (int b = threadIdx.x; b < 256; b += blockDim.x) {
+            u32 t = 0u, e = 0u;
+            for (int c = 0; c < K5_COPIES; ++c) { const u32 v = h[b * K5_COPIES + c]; h[b * K5_COPIES + c] = 0u; t += v & 0xFFFFu; e += v >> 16; }
+            if (t) atomicAdd(&p.counts[b], (u64)t);
+            if (e) atomicAdd(&p.counts[256 + b], (u64)e);
         }
+        __syncthreads();
+    };
+    int since = 0;
+    long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long it = 0; it < iters; ++it, ch += stride) {
+        if (ch < nchunks) {
+            const long long r = ch / p.cpr;
+            const int j = (int)(ch - r * p.cpr);
+            const int nb = (int)p.len[r] - 16 * j;
+            if (nb > 0) {
+                const size_t off = (size_t)r * p.pitch + (size_t)16 * j;
+                const uint4 qv = *reinterpret_cast<const uint4*>(p.qual + off);
+                const uint4 ev = *reinterpret_cast<const uint4*>(p.err + off);
+                const uint4 sv = *reinterpret_cast<const uint4*>(p.skip + off);
+                const u32 q[4] = {qv.x, qv.y, qv.z, qv.w}, e[4] = {ev.x, ev.y, ev.z, ev.w}, s[4] = {sv.x, sv.y, sv.z, sv.w};
+                bool negative = false;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int sh = 8 * (i & 3);
+                    const int qq = (int)((q[i >> 2] >> sh) & 0xFFu) - p.qoffset;
+                    const bool counted = i < nb && ((s[i >> 2] >> sh) & 0xFFu) == 0u;
+                    negative |= counted && qq < 0;                               // np.bincount rejects negative values: ValueError
+                    const u32 bin = (counted && qq >= 0) ? (u32)qq : 256u;
+                    const u32 inc = ((e[i >> 2] >> sh) & 0xFFu) ? 0x10001u : 1u;
+                    atomicAdd(&h[bin * K5_COPIES + copy], inc);
+                }
+                if (negative) flag(p.status, ST_RANGE, r);
+            }
+        }
+        if (++since == K5_FLUSH_ITERS) { flush(); since = 0; }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 512; i += blockDim.x)
-        if (h[i]) atomicAdd(&p.counts[i], (u64)h[i]);
+    flush();
 }

@@ -8,6 +8,8 @@ sys.path.insert(0, os.path.join(ROOT, 'kbbq-py_amd'))
 ap = argparse.ArgumentParser(); ap.add_argument('--reads', type=int, default=4_000_000); ap.add_argument('--len', type=int, default=150)
 ap.add_argument('--genome', type=int, default=200_000_000)
 ap.add_argument('--sorted', action='store_true', help='reads in coordinate order (a sorted BAM) instead of random order')
+ap.add_argument('--ins', type=float, default=0.2, help='fraction of reads with a 2-base insertion (3 CIGAR operations)')
+ap.add_argument('--flip', type=float, default=0.5, help='fraction of reverse-strand reads')
 a = ap.parse_args()
 import numpy as np, torch
 from kbbq import _device as dev, _native as N
@@ -26,7 +28,7 @@ err_at = torch.rand((n, pitch), device='cuda') < 0.01
 seq = torch.where(err_at, torch.tensor(65, dtype=torch.uint8, device='cuda'), seq)   # ... with 1 % substitutions
 lens = torch.full((n,), L, dtype=torch.int32, device='cuda')
 # CIGAR: 80 % "LM", 20 % "50M2I(L-52)M" (ref window L-2)
-ins = torch.rand(n, device='cuda') < 0.2
+ins = torch.rand(n, device='cuda') < a.ins
 ref_len = torch.where(ins, L - 2, L).to(torch.int32)
 cig_n = torch.where(ins, 3, 1).to(torch.int32)
 cig_off = torch.cumsum(cig_n, 0).to(torch.int32) - cig_n
@@ -35,7 +37,7 @@ cigar = torch.zeros(ncig, dtype=torch.int32, device='cuda')
 o = cig_off.long()
 cigar[o[~ins]] = (L << 4) | 0
 cigar[o[ins]] = (50 << 4) | 0; cigar[o[ins] + 1] = (2 << 4) | 1; cigar[o[ins] + 2] = ((L - 52) << 4) | 0
-flip = (torch.rand(n, device='cuda') < 0.5).to(torch.uint8)
+flip = (torch.rand(n, device='cuda') < a.flip).to(torch.uint8)
 err = torch.zeros((n, pitch), dtype=torch.uint8, device='cuda'); skip = torch.zeros_like(err)
 qual = torch.randint(2, 42, (n, pitch), dtype=torch.uint8, device='cuda')
 counts = torch.zeros(512, dtype=torch.int64, device='cuda')
