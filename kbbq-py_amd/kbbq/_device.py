@@ -103,6 +103,34 @@ class Tables:
                 h[2 * npos + ndn:].reshape(R, NQ, 16).copy())
 
 
+_pinned = {}
+
+
+def pinned(tag, index, nbytes):
+    """A page-locked host buffer (uint8 tensor of at least nbytes) kept for the life of the process: page-locking is
+    slow (milliseconds per MB), so the staging buffers of the file path -- ingest slabs, then the egress pipeline's --
+    are allocated once and shared by index; `tag` separates users whose buffers are in use at the same time."""
+    torch = _torch()
+    key = (tag, index)
+    buf = _pinned.get(key)
+    if buf is None or buf.shape[0] < nbytes:
+        for other, cand in list(_pinned.items()):                # a free buffer of another tag that is large enough
+            if other[0] == '' and cand.shape[0] >= nbytes:
+                buf = _pinned.pop(other)
+                break
+        else:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, pin_memory=True)
+        _pinned[key] = buf
+    return buf
+
+
+def release_pinned(tag):
+    """The buffers of `tag` become available to other users (kept allocated)."""
+    for key in [k for k in _pinned if k[0] == tag]:
+        free = [k for k in _pinned if k[0] == '']
+        _pinned[('', len(free))] = _pinned.pop(key)
+
+
 class ReadBatch:
     """Device-resident padded SoA of reads: seq / cseq / qual planes [n, pitch] uint8
     and the uint32 sidecar (layout: include/kbbq_hip.h)."""
@@ -128,6 +156,40 @@ class ReadBatch:
             if cseq is not None:
                 b.cseq[:n].copy_(torch.from_numpy(np.ascontiguousarray(cseq)))
             b.meta[:n].copy_(torch.from_numpy(np.ascontiguousarray(meta).view(np.int32)))
+        return b
+
+    @classmethod
+    def from_reader(cls, text, other, infer_rg_flag, first, n, pitch, slab=1 << 17, device=None):
+        """Reads [first, first + n) of a fastx.NativeFastq (and their corrections from `other`, or None) straight onto
+        the device: the C++ packer fills page-locked slabs (all host threads) while the copy engine uploads the
+        previous ones -- no host copy of the planes is ever materialised."""
+        torch = _torch()
+        b = cls(n, pitch, with_corrected=other is not None, device=device)
+        planes = 3 if other is not None else 2
+        events = {}
+        with torch.cuda.device(b.seq.device):
+            for k, lo in enumerate(range(0, n, slab)):
+                m = min(slab, n - lo)
+                slot = k % 3
+                if slot in events:
+                    events[slot].synchronize()                   # the slab's previous upload has left the buffer
+                buf = pinned('ingest', slot, slab * (planes * pitch + 4))
+                view = lambda i: buf[i * slab * pitch:i * slab * pitch + m * pitch].view(m, pitch)
+                h_seq, h_qual = view(0), view(1)
+                h_cseq = view(2) if other is not None else None
+                h_meta = buf[planes * slab * pitch:planes * slab * pitch + 4 * m].view(torch.int32)
+                text.fill_into(other, infer_rg_flag, m, pitch, first + lo, h_seq.numpy(), None if h_cseq is None else h_cseq.numpy(),
+                               h_qual.numpy(), h_meta.numpy().view(np.uint32))
+                b.seq[lo:lo + m].copy_(h_seq, non_blocking=True)
+                b.qual[lo:lo + m].copy_(h_qual, non_blocking=True)
+                if other is not None:
+                    b.cseq[lo:lo + m].copy_(h_cseq, non_blocking=True)
+                b.meta[lo:lo + m].copy_(h_meta, non_blocking=True)
+                events[slot] = torch.cuda.Event()
+                events[slot].record()
+            for e in events.values():
+                e.synchronize()
+        release_pinned('ingest')
         return b
 
     @classmethod

@@ -303,10 +303,18 @@ class NativeFastq:
         qual = np.empty((n, pitch), dtype=np.uint8)
         cseq = np.empty((n, pitch), dtype=np.uint8) if other is not None else None
         meta = np.empty(n, dtype=np.uint32)
+        self.fill_into(other, infer_rg_flag, n, pitch, first, seq, cseq, qual, meta)
+        return seq, cseq, qual, meta
+
+    def fill_into(self, other, infer_rg_flag, n, pitch, first, seq, cseq, qual, meta):
+        """The same into caller-provided C-contiguous arrays ([n, pitch] uint8 planes, [n] uint32 sidecar), e.g. views
+        of page-locked staging buffers."""
+        for a, shape in ((seq, (n, pitch)), (qual, (n, pitch)), (cseq, (n, pitch)), (meta, (n,))):
+            if a is not None and (tuple(a.shape) != shape or not a.flags['C_CONTIGUOUS']):
+                raise ValueError('fill_into: array of shape %s, expected C-contiguous %s' % (a.shape, shape))
         _N.check(_N.load().kbbq_fastq_fill_range(self._h, other._h if other is not None else None,
                                                  1 if infer_rg_flag else 0, first, n, pitch, _N.ptr(seq),
                                                  _N.ptr(cseq), _N.ptr(qual), _N.ptr(meta)))
-        return seq, cseq, qual, meta
 
     def format_array(self, first, n, newqual, out=None):
         """FASTQ text of reads [first, first+n) with qualities from rows of `newqual`, as a uint8 array
@@ -365,17 +373,24 @@ def length_bands(lens, max_bands=16):
     return out
 
 
-def _fill_bands(A, B, infer_rg_flag, lo, hi):
-    """Reads [lo, hi) packed band by band: [dict(first, n, S, pitch, seq, cseq, qual, meta)], `first` counted from lo."""
+def _fill_bands(A, B, infer_rg_flag, lo, hi, to_device=False):
+    """Reads [lo, hi) packed band by band: [dict(first, n, S, Smin, pitch, seq, cseq, qual, meta)], `first` counted from
+    lo.  to_device: instead of host planes every band carries `batch`, a _device.ReadBatch filled slab by slab through
+    page-locked staging (ReadBatch.from_reader) -- the form the file path uses."""
     from ._trace import stage
     out = []
     with stage('bands'):
         bands = A.length_bands(lo, hi - lo)
     for b_lo, b_hi, longest, shortest in bands:
         pitch = pitch_for(longest)
-        seq, cseq, qual, meta = A.fill(B, infer_rg_flag, b_hi - b_lo, pitch, first=lo + b_lo)
-        out.append(dict(first=b_lo, n=b_hi - b_lo, S=longest, Smin=shortest, pitch=pitch, seq=seq, cseq=cseq, qual=qual,
-                        meta=meta))
+        band = dict(first=b_lo, n=b_hi - b_lo, S=longest, Smin=shortest, pitch=pitch)
+        if to_device:
+            from . import _device as dev
+            band['batch'] = dev.ReadBatch.from_reader(A, B, infer_rg_flag, lo + b_lo, b_hi - b_lo, pitch)
+        else:
+            seq, cseq, qual, meta = A.fill(B, infer_rg_flag, b_hi - b_lo, pitch, first=lo + b_lo)
+            band.update(seq=seq, cseq=cseq, qual=qual, meta=meta)
+        out.append(band)
     return out
 
 
@@ -422,14 +437,14 @@ class PairScan:
             pass
 
 
-def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None):
+def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None, to_device=False):
     """Pass-1 input (recalibrate.py:56-57) through the C++ packer; same dictionary as pack_pair_py
     except that `text` is the NativeFastq of file A and `names` is filled lazily by callers.
     shard = (rank, world): every rank scans the whole pair (so read-group ids, the longest read and
     the first host-detectable error are global) and packs only its own records [first, first + n);
     `total` is the global number of usable reads.  bands=True: instead of one set of planes at the widest pitch,
     `bands` holds the reads packed by length band (length_bands), each at its own pitch.  scan: a PairScan of the
-    same arguments started earlier."""
+    same arguments started earlier.  to_device (with bands): the bands are filled straight onto the device (_fill_bands)."""
     from ._trace import stage
     with stage('open+index+scan (wait)'):
         A, B, (total, S, R, kind, idx) = (scan or PairScan(path_a, path_b, infer_rg_flag)).result()
@@ -443,14 +458,14 @@ def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None)
     try:
         with stage('fill'):
             if bands:
-                return dict(common, bands=_fill_bands(A, B, infer_rg_flag, lo, hi))
+                return dict(common, bands=_fill_bands(A, B, infer_rg_flag, lo, hi, to_device))
             seq, cseq, qual, meta = A.fill(B, infer_rg_flag, hi - lo, pitch, first=lo)
         return dict(common, seq=seq, cseq=cseq, qual=qual, meta=meta)
     finally:
         close_later(B)                       # file B is not needed after the fill: unmap it off the critical path
 
 
-def pack_single(text, infer_rg_flag, shard=None, bands=False):
+def pack_single(text, infer_rg_flag, shard=None, bands=False, to_device=False):
     """Pass-2 input: every read of file A with its own first-appearance RG map
     (recalibrate.py:141-148); shard = (rank, world) as in pack_pair."""
     total, S, R, kind, idx = text.scan(None, infer_rg_flag)
@@ -462,6 +477,6 @@ def pack_single(text, infer_rg_flag, shard=None, bands=False):
     common = dict(n=hi - lo, first=lo, total=total, pitch=pitch, S=S, R=R,
                   rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)})
     if bands:
-        return dict(common, bands=_fill_bands(text, None, infer_rg_flag, lo, hi))
+        return dict(common, bands=_fill_bands(text, None, infer_rg_flag, lo, hi, to_device))
     seq, _, qual, meta = text.fill(None, infer_rg_flag, hi - lo, pitch, first=lo)
     return dict(common, seq=seq, qual=qual, meta=meta)

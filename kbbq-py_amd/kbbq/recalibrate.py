@@ -78,8 +78,10 @@ def _tally_local(packed, minscore, maxscore):
         dev.accumulate(batch, tables, minscore, **hints)
 
     for band in packed['bands']:
-        with stage('H2D', sync=True):
-            batch = dev.ReadBatch.from_host(band['seq'], band['qual'], band['meta'], cseq=band['cseq'])
+        batch = band.get('batch')                      # filled straight onto the device by the packer (to_device)
+        if batch is None:
+            with stage('H2D', sync=True):
+                batch = dev.ReadBatch.from_host(band['seq'], band['qual'], band['meta'], cseq=band['cseq'])
         band['batch'], band['laid'] = batch, None      # still resident: pass 2 re-uses them when it covers file A
         with stage('layout', sync=True):
             laid = _lay_out(batch, R, band['S'])
@@ -123,7 +125,7 @@ def _pack_and_tally(fastq, infer_rg, minscore, maxscore):
     scan = fastx.PairScan(fastq[0], fastq[1], infer_rg)       # the reader's own threads: no interpreter lock needed
     _warm_up()
     packed = fastx.pack_pair(fastq[0], fastq[1], infer_rg, shard=(rank, world) if world > 1 else None, bands=True,
-                             scan=scan)
+                             scan=scan, to_device=True)
     err = packed.get('pending_error')
     if err is not None:
         # the reference fails at the FIRST offending read: let the kernel look at the reads
@@ -203,7 +205,7 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
         text = scan.result()[0]
         if text.n == 0:
             return
-        single = fastx.pack_single(text, infer_rg, shard, bands=True)
+        single = fastx.pack_single(text, infer_rg, shard, bands=True, to_device=True)
         tables = load_model(gatkreport, single['rg_to_int'])
     else:
         packed, tables = _pack_and_tally(fastq, infer_rg, 6, 42)
@@ -227,9 +229,8 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
         # file B was shorter (zip truncation), or the model came from a report: pass 2 covers
         # all of file A with its own first-appearance read groups
         if single is None:
-            single = fastx.pack_single(text, infer_rg, shard, bands=True)
+            single = fastx.pack_single(text, infer_rg, shard, bands=True, to_device=True)
         for band in single['bands']:
-            band['batch'] = dev.ReadBatch.from_host(band['seq'], band['qual'], band['meta'])
             band['laid'] = _lay_out(band['batch'], R, band['S'])
 
     def apply_band(band):
@@ -281,7 +282,12 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
         from . import _egress
         step = 1 << 18
         widest = max([band['pitch'] for band in single['bands']] + [16])
-        staging = _egress.Slots(4, lambda nbytes: torch.empty(max(nbytes, step * widest), dtype=torch.uint8, pin_memory=True))
+        pool = [0]
+
+        def page_locked(nbytes):
+            pool[0] += 1
+            return dev.pinned('egress', pool[0], max(nbytes, step * widest))
+        staging = _egress.Slots(4, page_locked)
         rendered = _egress.Slots(4, lambda nbytes: np.empty(nbytes + (nbytes >> 3), dtype=np.uint8))
 
         def fetch(item):
@@ -301,7 +307,10 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
             with stage('write'):
                 raw.write(memoryview(buf))
 
-        _egress.pipeline(slabs(step), fetch, render, write)
+        try:
+            _egress.pipeline(slabs(step), fetch, render, write)
+        finally:
+            dev.release_pinned('egress')
 
     def emit():
         import sys
