@@ -2,7 +2,12 @@
 of successive slabs overlapping (device -> pinned host copy | C++ FASTQ writer | write(2)); replaces the per-read
 print of recalibrate.py:153-156 for a binary stdout."""
 import queue
+import sys
 import threading
+
+import numpy as np
+
+from ._trace import stage
 
 _END = object()
 
@@ -70,3 +75,62 @@ class Slots:
         if b is None or b.shape[0] < nbytes:
             b = self._bufs[i] = self._make(nbytes)
         return b
+
+
+def _slabs(bands, outs, step):
+    """(serial number, band, its device plane of new qualities, first row, rows) for slabs of `step` reads."""
+    k = 0
+    for band, out in zip(bands, outs):
+        for first in range(0, band['n'], step):
+            yield k, band, out, first, min(step, band['n'] - first)
+            k += 1
+
+
+def emit_records(text, base, bands, outs, slab=1 << 18):
+    """Print the recalibrated records of this rank -- reads base + band['first'] + row of the fastx.NativeFastq `text`,
+    new quality characters in the device planes `outs` (one per band) -- to sys.stdout, rendered by the C++ writer in
+    slabs.  A binary stdout gets the bytes through the three-stage pipeline above (copy off the device into
+    page-locked buffers | rendering into re-used buffers | write(2)); a text-only stdout (StringIO) gets print(),
+    like the reference."""
+    sys.stdout.flush()
+    raw = getattr(sys.stdout, 'buffer', None)
+    if raw is None:
+        for _, band, out, first, m in _slabs(bands, outs, 1 << 20):
+            newq = out[first:first + m].cpu().numpy()
+            print(text.format_array(base + band['first'] + first, m, newq).tobytes().decode('latin-1'), end='')
+        sys.stdout.flush()
+        return
+    import torch
+    from . import _device as dev
+    widest = max([band['pitch'] for band in bands] + [16])
+    made = [0]
+
+    def page_locked(nbytes):
+        made[0] += 1
+        return dev.pinned('egress', made[0], max(nbytes, slab * widest))
+    staging = Slots(4, page_locked)
+    rendered = Slots(4, lambda nbytes: np.empty(nbytes + (nbytes >> 3), dtype=np.uint8))
+
+    def fetch(item):
+        k, band, out, first, m = item
+        with stage('D2H'), torch.cuda.device(out.device):           # a new thread starts on device 0
+            host = staging.get(k, m * band['pitch'])[:m * band['pitch']].view(m, band['pitch'])
+            host.copy_(out[first:first + m], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        return k, base + band['first'] + first, m, host.numpy()
+
+    def render(item):
+        k, first, m, newq = item
+        with stage('format'):
+            return text.format_array(first, m, newq, out=lambda nbytes: rendered.get(k, nbytes))
+
+    def write(buf):
+        with stage('write'):
+            raw.write(memoryview(buf))
+
+    try:
+        pipeline(_slabs(bands, outs, slab), fetch, render, write)
+    finally:
+        dev.release_pinned('egress')
+    raw.flush()
+    sys.stdout.flush()

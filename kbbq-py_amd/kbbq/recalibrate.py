@@ -261,68 +261,9 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
     with stage('apply', sync=True):
         outs = _collective(apply_shard, single['first'])
 
-    # recalibrate.py:153-156: '@' + name, sequence, '+', qualities -- rendered by the C++ writer in slabs.  A binary
-    # stdout gets the bytes (copy off the device, rendering and write(2) of successive slabs overlap); a text-only
-    # stdout (StringIO) gets print(), like the reference
-    def slabs(step):
-        k = 0
-        for band, out in zip(single['bands'], outs):
-            for first in range(0, band['n'], step):
-                yield k, band, out, first, min(step, band['n'] - first)
-                k += 1
-
-    def emit_text():
-        for _, band, out, first, m in slabs(1 << 20):
-            newq = out[first:first + m].cpu().numpy()
-            rendered = text.format_array(single['first'] + band['first'] + first, m, newq)
-            print(rendered.tobytes().decode('latin-1'), end='')
-
-    def emit_bytes(raw):
-        import torch
-        from . import _egress
-        step = 1 << 18
-        widest = max([band['pitch'] for band in single['bands']] + [16])
-        pool = [0]
-
-        def page_locked(nbytes):
-            pool[0] += 1
-            return dev.pinned('egress', pool[0], max(nbytes, step * widest))
-        staging = _egress.Slots(4, page_locked)
-        rendered = _egress.Slots(4, lambda nbytes: np.empty(nbytes + (nbytes >> 3), dtype=np.uint8))
-
-        def fetch(item):
-            k, band, out, first, m = item
-            with stage('D2H'), torch.cuda.device(out.device):       # a new thread starts on device 0
-                host = staging.get(k, m * band['pitch'])[:m * band['pitch']].view(m, band['pitch'])
-                host.copy_(out[first:first + m], non_blocking=True)
-                torch.cuda.current_stream().synchronize()
-            return k, single['first'] + band['first'] + first, m, host.numpy()
-
-        def render(item):
-            k, first, m, newq = item
-            with stage('format'):
-                return text.format_array(first, m, newq, out=lambda nbytes: rendered.get(k, nbytes))
-
-        def write(buf):
-            with stage('write'):
-                raw.write(memoryview(buf))
-
-        try:
-            _egress.pipeline(slabs(step), fetch, render, write)
-        finally:
-            dev.release_pinned('egress')
-
-    def emit():
-        import sys
-        sys.stdout.flush()
-        raw = getattr(sys.stdout, 'buffer', None)
-        if raw is None:
-            emit_text()
-        else:
-            emit_bytes(raw)
-            raw.flush()
-        sys.stdout.flush()
-    parallel.in_rank_order(emit)
+    # recalibrate.py:153-156: '@' + name, sequence, '+', qualities
+    from . import _egress
+    parallel.in_rank_order(lambda: _egress.emit_records(text, single['first'], single['bands'], outs))
 
 
 def recalibrate_bam(bam, use_oq=False, set_oq=False):
