@@ -124,11 +124,14 @@ def pinned(tag, index, nbytes):
     return buf
 
 
+_released = [0]
+
+
 def release_pinned(tag):
     """The buffers of `tag` become available to other users (kept allocated)."""
     for key in [k for k in _pinned if k[0] == tag]:
-        free = [k for k in _pinned if k[0] == '']
-        _pinned[('', len(free))] = _pinned.pop(key)
+        _released[0] += 1
+        _pinned[('', _released[0])] = _pinned.pop(key)
 
 
 class ReadBatch:

@@ -394,3 +394,31 @@ def test_two_ranks_tally_alignments_like_one(dev, oracle, tmp_path):
     r = run(paths, '1', out)
     assert r.returncode != 0 and json.load(open(out)) == {'error': 'IndexError'}
     assert r.stderr.decode().count('IndexError') >= 2
+
+
+def test_planes_streamed_from_the_reader_equal_the_host_packed_ones(dev, oracle, tmp_path):
+    """ReadBatch.from_reader (page-locked slabs, uploads overlapping the packer) against the host planes of
+    NativeFastq.fill, for slab sizes that do and do not divide the batch, with and without the corrected file,
+    a shard that starts in the middle, and the buffers handed on to the output pipeline afterwards."""
+    import torch
+    from kbbq import fastx
+    n = 10000
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 4, 36, 151, 3)
+    names = oracle.synth_names(0, n, 3, with_rg=True)
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, names, cseq, qual, meta)
+    A, B = fastx.NativeFastq(fa), fastx.NativeFastq(fb)
+    assert A.scan(B, True)[0] == n
+    for other in (B, None):
+        for first, m, slab in ((0, n, 1 << 17), (0, n, 999), (3001, 5000, 1000), (n - 1, 1, 7), (5, 0, 64)):
+            want = A.fill(other, True, m, 160, first=first)
+            got = dev.ReadBatch.from_reader(A, other, True, first, m, 160, slab=slab)
+            assert got.n == m and (got.cseq is None) == (other is None)
+            pairs = [(got.seq, want[0]), (got.qual, want[2]), (got.meta, want[3].view(np.int32))]
+            if other is not None:
+                pairs.append((got.cseq, want[1]))
+            for g, w in pairs:
+                assert np.array_equal(g[:m].cpu().numpy(), w), (first, m, slab)
+    assert not [k for k in dev._pinned if k[0] == 'ingest']          # released for the next user
+    assert any(k[0] == '' for k in dev._pinned)
