@@ -306,6 +306,7 @@ int    kbbq_apply_grouped_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t
  * kbbq_sam_fill: plane rows [0, n) <- SEQ (0) / QUAL (1) / OQ (2) of alignments [first, first + n), zero padded.
  * kbbq_sam_text: 0 QNAME, 1 whole alignment line, 2 header line, 3 contig name, 4 @RG ID (not NUL-terminated).  */
 typedef struct kbbq_sam kbbq_sam;
+/* path: SAM text, gzip / bgzip-compressed SAM, or BAM (inflated with zlib, records rendered as SAM lines) */
 int kbbq_sam_open(const char* path, kbbq_sam** out);
 int kbbq_sam_close(kbbq_sam* f);
 int kbbq_sam_info(const kbbq_sam* f, int64_t* info6);

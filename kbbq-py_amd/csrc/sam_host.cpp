@@ -3,8 +3,9 @@
 // Replaces, for those paths, what the reference gets from pysam.AlignmentFile / AlignedSegment
 // (benchmark.py:57-74,102-143; gatk/bqsr.py:23-123): per alignment the flag, contig, position, CIGAR,
 // mate position, template length, sequence, qualities and the RG / OQ tags -- as ARRAYS, because the
-// kernels (K4 find_errors, K6 canonical reads) take whole batches.  SAM text only (binary BAM needs
-// htslib); the file is mapped, lines are indexed and parsed in parallel.
+// kernels (K4 find_errors, K6 canonical reads) take whole batches.  The file is mapped, lines are indexed and
+// parsed in parallel; BAM and gzip-compressed SAM are inflated (BGZF blocks in parallel) and BAM records rendered
+// as SAM lines first (bam_host.cpp: zlib only, no htslib).
 //
 // Field semantics follow the SAM specification and pysam's attribute definitions:
 //   reference_start = POS - 1; next_reference_start = PNEXT - 1; reference_end = start + sum of M/D/N/=/X;
@@ -13,6 +14,7 @@
 // operation letter is stored as op 15 and rejected by K4 (ValueError, like the reference's walk).
 #include "../../include/kbbq_hip.h"
 #include "host_threads.h"
+#include "bam_host.h"
 
 #include <algorithm>
 #include <atomic>
@@ -33,6 +35,7 @@ int kbbq_set_error_(int code, const char* msg);      // defined in kbbq_hip.hip
 
 struct kbbq_sam {
     const uint8_t* buf = nullptr; size_t size = 0;
+    std::vector<uint8_t> owned;                // the text when it was inflated / rendered from BAM instead of mapped
     std::vector<uint64_t> hdr0; std::vector<uint32_t> hdrlen;      // header lines ('@...')
     std::vector<uint64_t> line0; std::vector<uint32_t> linelen;    // alignment lines
     // per alignment
@@ -43,7 +46,7 @@ struct kbbq_sam {
     std::vector<uint32_t> cigar;
     std::vector<std::string> contigs;          // first-appearance order of RNAME
     std::vector<std::string> rg_ids;           // @RG ID in header order
-    ~kbbq_sam() { if (buf) munmap((void*)buf, size); }
+    ~kbbq_sam() { if (buf && owned.empty()) munmap((void*)buf, size); }
 };
 
 namespace {
@@ -123,9 +126,20 @@ int kbbq_sam_open(const char* path, kbbq_sam** out)
         madvise(m, f->size, MADV_SEQUENTIAL);
     }
     close(fd);
-    if (f->size >= 4 && (!memcmp(f->buf, "BAM\1", 4) || !memcmp(f->buf, "\x1f\x8b\x08\x04", 4))) {
-        delete f;
-        return kbbq_set_error_(KBBQ_E_NAME, "binary BAM needs htslib; convert with `samtools view -h`");
+    if (f->size >= 4 && (!memcmp(f->buf, "BAM\1", 4) || (f->buf[0] == 0x1f && f->buf[1] == 0x8b))) {
+        // gzip / BGZF: inflate; BAM (inflated or not): render the records as SAM lines; then parse the text as usual
+        std::vector<uint8_t> raw, text; std::string err;
+        bool ok = true;
+        const bool zipped = f->buf[0] == 0x1f;
+        if (zipped) ok = kbbq_inflate_all(f->buf, f->size, raw, err);
+        const uint8_t* img = zipped ? raw.data() : f->buf; const size_t img_n = zipped ? raw.size() : f->size;
+        const bool bam = ok && img_n >= 4 && !memcmp(img, "BAM\1", 4);
+        if (bam) ok = kbbq_bam_to_sam(img, img_n, text, err);
+        if (!ok) { delete f; return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": " + err).c_str()); }
+        munmap((void*)f->buf, f->size);
+        f->owned = bam ? std::move(text) : std::move(raw);
+        if (f->owned.empty()) f->owned.push_back('\n');          // keeps "owned" distinguishable from "mapped"
+        f->buf = f->owned.data(); f->size = f->owned.size();
     }
     // line ends, in parallel
     const unsigned nt = threads_for(f->size);

@@ -222,16 +222,12 @@ class SamBatch:
 
 
 class AlignmentFile:
-    """A SAM text file (mode is accepted and ignored): parsed once by the native reader (csrc/sam_host.cpp) into
-    arrays -- `batch()`, what the kernels consume -- and, for code written against pysam, an iterable of
-    AlignedRead objects built on demand from the same lines."""
+    """A BAM file, a SAM text file or a gzip-compressed SAM file (mode is accepted and ignored): parsed once by the
+    native reader (csrc/sam_host.cpp; BAM through csrc/bam_host.cpp: zlib, no htslib) into arrays -- `batch()`, what
+    the kernels consume -- and, for code written against pysam, an iterable of AlignedRead objects built on demand
+    from the same (for BAM: rendered) SAM lines."""
 
     def __init__(self, path, mode='r'):
-        with open(path, 'rb') as fh:
-            if fh.read(4) in (b'BAM\x01', b'\x1f\x8b\x08\x04'):
-                raise NotImplementedError('binary BAM needs htslib; convert with `samtools view -h`')
-        if str(path).endswith('.gz'):
-            raise NotImplementedError('compressed SAM is not read here; decompress it first')
         from . import _native as N
         self._handle = _SamHandle(path)
         self._batch = SamBatch(self._handle)

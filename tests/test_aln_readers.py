@@ -1,5 +1,6 @@
 """CPU tests of the product's text readers (kbbq/aln.py) against the oracle-side stand-ins."""
 import numpy as np
+import pytest
 
 from test_oracle_benchmark import simple, OB    # noqa: F401
 from kbbq import aln
@@ -26,3 +27,74 @@ def test_readers_agree_with_oracle_side(OB, tmp_path):
     c = aln.chars('ACGTN')
     assert c.dtype == np.dtype('U1') and list(c) == list('ACGTN') and list(aln.codes(c)) == [65, 67, 71, 84, 78]
     assert aln.parse_cigar('8M2I4M1D3M') == [(0, 8), (1, 2), (0, 4), (2, 1), (0, 3)] and aln.parse_cigar('*') == []
+
+
+ARRAYS = ('flag', 'contig', 'pos', 'pnext', 'tlen', 'qlen', 'ref_span', 'clip', 'cig_n', 'rg', 'qual_len', 'oq_len', 'cigar')
+
+
+def _same_batches(a, b):
+    assert a.n == b.n and a.contig_names == b.contig_names and a.rg_ids == b.rg_ids
+    for name in ARRAYS:
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    pitch = (max(a.maxlen, 1) + 15) // 16 * 16
+    for which in (0, 1, 2):
+        assert np.array_equal(a.plane(which, pitch), b.plane(which, pitch)), which
+
+
+def test_bam_and_gzipped_sam_are_read_like_sam_text(OB, oracle, tmp_path):
+    """The reference reads BAM through pysam; here BAM (BGZF blocks inflated in parallel, records rendered as SAM
+    lines by csrc/bam_host.cpp) and gzip-compressed SAM go through the same parser as SAM text: identical arrays,
+    planes, names and -- for BAM -- identical rendered lines, on the synthetic truth set and the BAM-sourced-tally set."""
+    import gzip
+    import bamwriter
+    import oracle_bqsr as OQ
+    sets = [OB.synth_truthset(str(tmp_path / 'bench'), seed=5, npairs=600)['sam'] if (tmp_path / 'bench').mkdir() is None else None,
+            OQ.synth_bqsr_set(str(tmp_path), seed=9, npairs=500, S=75)['sam']]
+    for k, sam in enumerate(sets):
+        text = open(sam).read()
+        ref = aln.AlignmentFile(sam)
+        bam = aln.AlignmentFile(bamwriter.write_bam(tmp_path / ('x%d.bam' % k), text))
+        _same_batches(ref.batch(), bam.batch())
+        assert [bam.batch().line(i) for i in range(ref.batch().n)] == [ln for ln in text.split('\n') if ln and not ln.startswith('@')]
+        assert bam.header.as_dict() == ref.header.as_dict() and bam.batch().names() == ref.batch().names()
+        gz = tmp_path / ('x%d.sam.gz' % k)
+        with gzip.open(gz, 'wt') as fh:
+            fh.write(text)
+        _same_batches(ref.batch(), aln.AlignmentFile(str(gz)).batch())
+        # the read objects built on demand are the same objects' worth of attributes
+        for r, q in list(zip(ref, bam))[:40]:
+            assert (r.query_name, r.flag, r.reference_start, r.cigartuples, r.query_sequence) == \
+                   (q.query_name, q.flag, q.reference_start, q.cigartuples, q.query_sequence)
+            assert list(r.query_qualities) == list(q.query_qualities) and r.get_tag('RG') == q.get_tag('RG')
+
+
+def test_bam_edge_cases_and_malformed_files(tmp_path):
+    import bamwriter
+    hdr = '@HD\tVN:1.6\n@SQ\tSN:c1\tLN:1000\n@SQ\tSN:c2\tLN:500\n@RG\tID:a\tPU:u\n'
+    recs = ['r1\t99\tc1\t5\t60\t2S4M1I3M2D1M\t=\t40\t50\tACGTNACGTAA\tIIIIIIIIIII\tRG:Z:a\tOQ:Z:JJJJJJJJJJJ\tNM:i:3\tXA:A:q\tXF:f:1.5\tXB:B:c,-1,2,3\tXS:B:S,1,65535\tXH:H:1AE3',
+            'r2\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*',
+            'r3\t16\tc2\t7\t3\t5M\tc1\t100\t-20\tAC=TM\t*\tXI:i:-70000\tXU:i:4000000000',
+            'r4\t0\tc2\t1\t255\t3M\t*\t0\t0\tGGG\t!!~']
+    text = hdr + '\n'.join(recs) + '\n'
+    sam = tmp_path / 'e.sam'; sam.write_text(text)
+    bam = aln.AlignmentFile(bamwriter.write_bam(tmp_path / 'e.bam', text))
+    _same_batches(aln.AlignmentFile(str(sam)).batch(), bam.batch())
+    assert [bam.batch().line(i) for i in range(4)] == recs
+    # no header text in the BAM: the binary reference list becomes @SQ lines
+    bare = aln.AlignmentFile(bamwriter.write_bam(tmp_path / 'bare.bam', text, header_text=False))
+    assert bare.batch().contig_names == bam.batch().contig_names and [x['SN'] for x in bare.header.as_dict()['SQ']] == ['c1', 'c2']
+    assert bare.batch().rg_ids == [] and int(bare.batch().rg[0]) < 0
+    # an uncompressed BAM image, an empty BAM, and many blocks
+    raw = bamwriter.sam_to_bam_bytes(text)
+    (tmp_path / 'raw.bam').write_bytes(raw)
+    assert aln.AlignmentFile(str(tmp_path / 'raw.bam')).batch().n == 4
+    assert aln.AlignmentFile(bamwriter.write_bam(tmp_path / 'none.bam', hdr)).batch().n == 0
+    (tmp_path / 'small.bam').write_bytes(bamwriter.bgzf(raw, block=37))
+    _same_batches(bam.batch(), aln.AlignmentFile(str(tmp_path / 'small.bam')).batch())
+    # damaged files: an error, never a crash
+    z = bamwriter.bgzf(raw)
+    for name, data in (('cut', z[:len(z) // 2]), ('crc', z[:40] + bytes([z[40] ^ 1]) + z[41:]), ('rec', bamwriter.bgzf(raw[:-7])),
+                       ('magic', bamwriter.bgzf(b'BAM\1' + b'\xff' * 40)), ('refs', bamwriter.bgzf(raw[:len(hdr) + 14]))):
+        (tmp_path / (name + '.bam')).write_bytes(data)
+        with pytest.raises(ValueError):
+            aln.AlignmentFile(str(tmp_path / (name + '.bam')))

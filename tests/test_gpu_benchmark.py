@@ -166,3 +166,27 @@ def test_random_truth_sets_against_the_oracle(bm, OB, case, tmp_path):
     oa, ot = OB.benchmark_fastq(paths['fq'], list(_shim.AlignmentFile(paths['sam'])), oref, OB.get_var_sites(paths['vcf']),
                                 paths['bed'])
     assert np.array_equal(a, oa) and np.array_equal(t, ot)
+
+
+@pytest.mark.parametrize('name', ['bench_a'])
+def test_bam_input_prints_the_reference_tables(bm, OB, name, tmp_path, capfd):
+    """The same truth set as a BAM file (what the reference's users have): `kbbq benchmark` prints the golden tables,
+    and the BAM-sourced tally gives the golden vectors from a BAM."""
+    import bamwriter
+    info, gold = load_golden(name)
+    paths = OB.synth_truthset(str(tmp_path), **info['case'])
+    bam = bamwriter.write_bam(tmp_path / 'truth.bam', open(paths['sam']).read())
+    capfd.readouterr()
+    for tag, kw in (('bam', dict()), ('fastq', dict(fastqfile=paths['fq']))):
+        with open(paths['bed']) as fh:
+            bm.benchmark(bam, paths['fa'], paths['vcf'], label='lbl', bedfh=fh, **kw)
+        assert capfd.readouterr().out == info['printed'][tag]
+    from kbbq import aln
+    from kbbq.gatk import bqsr
+    from test_oracle_bqsr import VEC, _inputs
+    import oracle as O
+    binfo, bgold, bpaths = _inputs('bqsr_a', tmp_path, O)
+    bbam = bamwriter.write_bam(tmp_path / 'tally.bam', open(bpaths['sam']).read())
+    got = bqsr.bam_to_bqsr_covariates(aln.AlignmentFile(bbam), bpaths['fa'], bm.get_var_sites(bpaths['vcf']))
+    for k, g in zip(VEC, got):
+        assert np.array_equal(g, bgold[k]), k

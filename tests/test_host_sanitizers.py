@@ -17,16 +17,18 @@ def harness(tmp_path_factory):
     csrc = os.path.join(ROOT, 'kbbq-py_amd', 'csrc')
     cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-pthread',
            '-o', exe, os.path.join(ROOT, 'tests', 'native', 'host_sanitize.cpp'),
-           os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'solve_host.cpp'), os.path.join(csrc, 'sam_host.cpp'), '-lz']
+           os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'solve_host.cpp'), os.path.join(csrc, 'sam_host.cpp'),
+           os.path.join(csrc, 'bam_host.cpp'), '-lz']
     subprocess.check_call(cmd)
 
     def run(*args):
         env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='halt_on_error=1:print_stacktrace=1',
                    KBBQ_HOST_THREADS='4', KBBQ_SCAN_CHUNK='97')      # the scan's chunks on threads even for small inputs
-        r = subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=300, env=env)
-        assert 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr, r.stderr[-3000:]
-        assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
-        return r.stdout
+        r = subprocess.run([exe] + list(args), capture_output=True, timeout=300, env=env)
+        out, err = r.stdout.decode('latin-1'), r.stderr.decode('latin-1')      # error texts may quote bytes of a damaged file
+        assert 'ERROR: AddressSanitizer' not in err and 'runtime error' not in err, err[-3000:]
+        assert r.returncode == 0, (r.returncode, err[-2000:])
+        return out
     return run
 
 
@@ -112,6 +114,28 @@ def test_sam_reader(harness, oracle, tmp_path):
     for name, text in cases.items():
         harness('sam', _write(tmp_path / (name + '.sam'), text.encode('latin-1'), 'wb'))
     harness('sam', str(tmp_path / 'missing.sam'))
+    # BAM / BGZF / gzip images of the same alignments, intact and damaged (csrc/bam_host.cpp)
+    import gzip
+    import random
+    import bamwriter
+    text = open(paths['sam']).read()
+    raw = bamwriter.sam_to_bam_bytes(text)
+    z = bamwriter.bgzf(raw)
+    assert 'sam n=800' in harness('sam', _write(tmp_path / 'ok.bam', z, 'wb'))
+    assert 'sam n=800' in harness('sam', _write(tmp_path / 'raw.bam', raw, 'wb'))
+    assert 'sam n=800' in harness('sam', _write(tmp_path / 'ok.sam.gz', gzip.compress(text.encode()), 'wb'))
+    rng = random.Random(7)
+    damaged = {'cut_z': z[:len(z) // 3], 'cut_raw': raw[:len(raw) // 3], 'gz_cut': gzip.compress(text.encode())[:5000],
+               'no_records': bamwriter.bgzf(raw[:200]), 'bad_block_size': z[:16] + b'\xff\xff' + z[18:],
+               'tiny': b'BAM\1', 'gz_magic_only': b'\x1f\x8b', 'huge_l_text': b'BAM\1\xff\xff\xff\x7f' + b'x' * 64,
+               'neg_refs': b'BAM\1\0\0\0\0\xff\xff\xff\xff', 'huge_seq': bamwriter.bgzf(raw[:len(raw) - 900] + b'\x7f' * 900)}
+    for k in range(12):                                          # random byte flips in the uncompressed image, re-compressed
+        b = bytearray(raw)
+        for _ in range(rng.randint(1, 6)):
+            b[rng.randrange(len(b))] = rng.randrange(256)
+        damaged['flip%d' % k] = bamwriter.bgzf(bytes(b))
+    for name, data in damaged.items():
+        harness('sam', _write(tmp_path / (name + '.bam'), data, 'wb'))
 
 
 def test_threaded_readers_under_thread_sanitizer(tmp_path, oracle):
@@ -121,7 +145,8 @@ def test_threaded_readers_under_thread_sanitizer(tmp_path, oracle):
     csrc = os.path.join(ROOT, 'kbbq-py_amd', 'csrc')
     cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=thread', '-pthread', '-o', exe,
            os.path.join(ROOT, 'tests', 'native', 'host_sanitize.cpp'),
-           os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'solve_host.cpp'), os.path.join(csrc, 'sam_host.cpp'), '-lz']
+           os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'solve_host.cpp'), os.path.join(csrc, 'sam_host.cpp'),
+           os.path.join(csrc, 'bam_host.cpp'), '-lz']
     if subprocess.run(cmd, capture_output=True).returncode != 0:
         pytest.skip('this g++ cannot link -fsanitize=thread')
     n = 20000
@@ -132,8 +157,10 @@ def test_threaded_readers_under_thread_sanitizer(tmp_path, oracle):
     oracle.write_fastq(fb, names, cseq, qual, meta)
     import oracle_bqsr as OQ
     sam = OQ.synth_bqsr_set(str(tmp_path), seed=3, npairs=3000, S=60)['sam']
+    import bamwriter
+    bam = bamwriter.write_bam(tmp_path / 't.bam', open(sam).read())
     env = dict(os.environ, KBBQ_HOST_THREADS='6', KBBQ_SCAN_CHUNK='501', TSAN_OPTIONS='halt_on_error=0')
-    for args in (['pair', fa, fb, '1'], ['pair', fa, '-', '0'], ['combiln'], ['sam', sam]):
+    for args in (['pair', fa, fb, '1'], ['pair', fa, '-', '0'], ['combiln'], ['sam', sam], ['sam', bam]):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=env)
         assert 'ThreadSanitizer' not in r.stderr, r.stderr[-3000:]
         assert r.returncode == 0, (args, r.returncode, r.stderr[-2000:])
