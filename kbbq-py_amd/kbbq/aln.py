@@ -49,13 +49,22 @@ class AlignedRead:
     def reference_end(self):
         return self.reference_start + sum(l for op, l in self.cigartuples if op in (0, 2, 3, 7, 8))
 
-    is_paired = property(lambda self: bool(self.flag & 1))
-    is_unmapped = property(lambda self: bool(self.flag & 4))
-    mate_is_unmapped = property(lambda self: bool(self.flag & 8))
-    is_reverse = property(lambda self: bool(self.flag & 16))
-    mate_is_reverse = property(lambda self: bool(self.flag & 32))
-    is_read1 = property(lambda self: bool(self.flag & 64))
-    is_read2 = property(lambda self: bool(self.flag & 128))
+    def _flag_bit(bit):                   # pysam's flag properties: readable and assignable
+        def fget(self):
+            return bool(self.flag & bit)
+
+        def fset(self, value):
+            self.flag = (self.flag | bit) if value else (self.flag & ~bit)
+        return property(fget, fset)
+
+    is_paired = _flag_bit(1)
+    is_unmapped = _flag_bit(4)
+    mate_is_unmapped = _flag_bit(8)
+    is_reverse = _flag_bit(16)
+    mate_is_reverse = _flag_bit(32)
+    is_read1 = _flag_bit(64)
+    is_read2 = _flag_bit(128)
+    del _flag_bit
 
     @property
     def tlen(self):                       # pysam's older name of template_length

@@ -1,9 +1,8 @@
 """
 kbbq.read -- ReadData, the per-read record CovariateData.consume_read takes
 (reference kbbq/read.py:21-378).  Host-side data class: arrays of one read plus
-the class-level read-group registry.  The BAM factories of the reference
-(from_bamread, load_rgs_from_bamfile) need pysam and are out of scope
-(SURVEY.md section 2, row 5).
+the class-level read-group registry.  The BAM factories (from_bamread,
+load_rgs_from_bamfile) take the read / file objects of kbbq.aln (or pysam's).
 """
 import numpy as np
 
@@ -56,11 +55,26 @@ class ReadData():
 
     @classmethod
     def from_bamread(cls, bamread, use_oq=False):
-        raise NotImplementedError('BAM input is outside the MI355X hot path (SURVEY.md section 8)')
+        """From an aligned read (reference read.py:101-141): sequence and qualities in SEQUENCING orientation
+        (reverse-strand reads reverse-complemented, letters outside ACGT -> 'N'), the OQ tag's qualities when
+        use_oq, rg = the RG tag or None; skips / errors all False."""
+        seq = np.array(list(bamread.query_sequence), dtype=np.str_)
+        qual = bamread_get_quals(bamread, use_oq)
+        if bamread.is_reverse:
+            seq = compare_reads.Dinucleotide.veccomplement(np.flip(seq), 'N')
+            qual = np.flip(qual)
+        n = len(seq)
+        return cls(seq=seq, qual=qual, skips=np.zeros(n, dtype=bool), name=bamread.query_name,
+                   rg=bamread.get_tag('RG') if bamread.has_tag('RG') else None, second=bamread.is_read2,
+                   errors=np.zeros(n, dtype=bool))
 
     @classmethod
     def load_rgs_from_bamfile(cls, bamfileobj):
-        raise NotImplementedError('BAM input is outside the MI355X hot path (SURVEY.md section 8)')
+        """Register the header's read groups (ID -> PU, ID -> index in header order; reference read.py:199-218)."""
+        for rg in bamfileobj.header.as_dict()['RG']:
+            cls.rg_to_pu[rg['ID']] = rg['PU']
+            cls.rg_to_int[rg['ID']] = cls.numrgs
+            cls.numrgs = cls.numrgs + 1
 
     def str_qual(self, offset=33):
         return [chr(int(q) + offset) for q in self.qual]
@@ -102,3 +116,10 @@ class ReadData():
 
     def __len__(self):
         return len(self.seq)
+
+
+def bamread_get_quals(read, use_oq=False):
+    """Qualities of an aligned read as an int array: the OQ tag's when use_oq (reference read.py:398-414)."""
+    if use_oq:
+        return compare_reads.bamread_get_oq(read)
+    return np.array(read.query_qualities, dtype=np.int_)

@@ -98,3 +98,43 @@ def test_bam_edge_cases_and_malformed_files(tmp_path):
         (tmp_path / (name + '.bam')).write_bytes(data)
         with pytest.raises(ValueError):
             aln.AlignmentFile(str(tmp_path / (name + '.bam')))
+
+
+SIMPLE_SAM = ("@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:ref\tLN:45\n"
+              "r001\t99\tref\t7\t30\t8M2I4M1D3M\t=\t37\t39\tTTAGATAAAGGATACTG\t==99=?<*+/5:@A99:\n"
+              "r001\t147\tref\t37\t30\t9M\t=\t7\t-39\tCAGCGGCAT\t><>???>>>\tNM:i:1\n")
+
+
+def test_readdata_bam_factories(tmp_path):
+    """The reference's tests/test_read.py:21-43,65-73 (ReadData.from_bamread / load_rgs_from_bamfile), on reads that
+    come out of a BAM file of its SAM-spec example (reference tests/conftest.py:60-81)."""
+    import bamwriter
+    from kbbq import read
+    read.ReadData.rg_to_pu = dict(); read.ReadData.rg_to_int = dict(); read.ReadData.numrgs = 0
+    try:
+        read.ReadData(seq=np.array(['A', 'T', 'G']), qual=np.array([6, 10, 3]), skips=np.array([False, False, True]), name='read01',
+                      rg=0, second=False, errors=np.array([False, True, True]))          # the reference's conftest registers rg 0 first
+        read.ReadData.rg_to_pu = dict(); read.ReadData.rg_to_int = dict(); read.ReadData.numrgs = 0
+        reads = list(aln.AlignmentFile(bamwriter.write_bam(tmp_path / 'simple.bam', SIMPLE_SAM)))
+        bamread = reads[0]
+        want = np.array([ord(c) - 33 for c in '==99=?<*+/5:@A99:'])
+        r = read.ReadData.from_bamread(bamread)
+        assert np.array_equal(r.qual, want) and r.rg is None and not r.second and r.name == 'r001'
+        assert not r.skips.any() and not r.errors.any() and ''.join(r.seq) == 'TTAGATAAAGGATACTG'
+        bamread.set_tag('OQ', '(' * 17)
+        bamread.set_tag('RG', 'foo')
+        r = read.ReadData.from_bamread(bamread, use_oq=True)
+        assert np.array_equal(r.qual, np.array([7] * 17)) and r.rg == 'foo'
+        assert read.ReadData.rg_to_int[None] == 0 and read.ReadData.rg_to_int['foo'] == 1 and read.ReadData.numrgs == 2
+        bamread.is_reverse = True
+        r = read.ReadData.from_bamread(bamread)
+        assert np.array_equal(r.qual, np.flip(want)) and np.array_equal(r.seq, np.array(list('CAGTATCCTTTATCTAA')))
+        r2 = read.ReadData.from_bamread(reads[1])                    # flag 147: reverse strand, second in pair
+        assert r2.second and ''.join(r2.seq) == 'ATGCCGCTG' and list(r2.qual) == [ord(c) - 33 for c in reversed('><>???>>>')]
+        read.ReadData.rg_to_pu = dict(); read.ReadData.rg_to_int = dict(); read.ReadData.numrgs = 0
+        hdr = '@HD\tVN:1.6\n@SQ\tSN:ref\tLN:45\n@RG\tID:FOO\tSM:BAR\tPU:BAZ\n'
+        read.ReadData.load_rgs_from_bamfile(aln.AlignmentFile(bamwriter.write_bam(tmp_path / 'rg.bam', hdr)))
+        assert read.ReadData.rg_to_int['FOO'] == 0 and read.ReadData.rg_to_pu['FOO'] == 'BAZ' and read.ReadData.numrgs == 1
+        assert read.bamread_get_quals(reads[1]).tolist() == [ord(c) - 33 for c in '><>???>>>']
+    finally:
+        read.ReadData.rg_to_pu = dict(); read.ReadData.rg_to_int = dict(); read.ReadData.numrgs = 0
