@@ -212,3 +212,28 @@ def recalibrate_fastq(read, meanq, globaldeltaq, qscoredeltaq, positiondeltaq, d
                                 minscore, N.ptr(a[0]), N.ptr(a[1]), N.ptr(a[2]), N.ptr(a[3]), N.ptr(a[4]),
                                 N.ptr(out)))
     return out[0, :L].astype(np.int_) - 33
+
+
+def tstamp():
+    """'[ YYYY-MM-DD HH:MM:SS ]' (reference compare_reads.py:26-33)."""
+    import datetime
+    return '[ ' + datetime.datetime.today().isoformat(' ', 'seconds') + ' ]'
+
+
+def load_positions(posfile):
+    """{contig: [0-based positions]} covered by the lines of an uncompressed BED file (reference
+    compare_reads.py:35-52)."""
+    d = dict()
+    with open(posfile, 'r') as infh:
+        for line in infh:
+            chrom, pos, end = line.rstrip().split()
+            d.setdefault(chrom, list()).extend(range(int(pos), int(end)))
+    return d
+
+
+def get_var_sites(vcf):
+    """{contig: [0-based positions covered by any record]} of a VCF file (reference compare_reads.py:54-68; the
+    same function as kbbq.benchmark's)."""
+    from . import benchmark
+    return benchmark.get_var_sites(vcf)
+

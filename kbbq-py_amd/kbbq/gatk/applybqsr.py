@@ -1,7 +1,9 @@
 """
 kbbq.gatk.applybqsr -- get_delta_qs is on the hot path (reference
 kbbq/gatk/applybqsr.py:80-103); table_to_vectors (:14-44) turns a stored GATK report back
-into the nine model vectors.
+into the nine model vectors.  The per-read ApplyBQSR emulation on
+aligned reads (:46-78) is host NumPy, one read at a time, as in the reference (it has no batch
+caller there; reads come from kbbq.aln or pysam).
 """
 import numpy as np
 
@@ -89,3 +91,43 @@ def get_delta_qs(meanq, rg_errs, rg_total, q_errs, q_total, pos_errs, pos_total,
                                dinuc_errs, dinuc_total)
     dn_dq = np.concatenate([dn_dq, np.zeros(dn_dq.shape[:-1] + (1,), dtype=dn_dq.dtype)], axis=-1)
     return rg_dq.copy(), q_dq.copy(), pos_dq.copy(), dn_dq.copy()
+
+
+def _oriented_quals(read, use_oq):
+    return utils.bamread_get_oq(read) if use_oq else np.array(read.query_qualities, dtype=np.int_)
+
+
+def bamread_cycle_covariates(read):
+    """Cycle of every base in ALIGNED order: 0..L-1 (first in pair) or -1..-L (second), reversed for a
+    reverse-strand read (reference applybqsr.py:46-50)."""
+    cycle = utils.generic_cycle_covariate(read.query_length, read.is_read2)
+    return np.flip(cycle) if read.is_reverse else cycle
+
+
+def bamread_dinuc_covariates(read, use_oq=True, minscore=6):
+    """Dinucleotide context of every base in aligned order, computed in sequencing orientation (reverse-strand reads
+    reverse-complemented, unknown letters -> N) and flipped back (reference applybqsr.py:52-63)."""
+    seq, quals = read.query_sequence, _oriented_quals(read, use_oq)
+    if read.is_reverse:
+        seq = ''.join(utils.Dinucleotide.complement.get(x, 'N') for x in reversed(seq))
+        quals = np.flip(quals)
+    dinuc = utils.generic_dinuc_covariate(np.array(list(seq), dtype='U1'), quals, minscore)
+    return np.flip(dinuc) if read.is_reverse else dinuc
+
+
+def recalibrate_bamread(read, meanq, globaldeltaq, qscoredeltaq, positiondeltaq, dinucdeltaq, rg_to_int, use_oq=True,
+                        minscore=6):
+    """New qualities of one aligned read (reference applybqsr.py:65-78): bases at or above minscore get
+    meanq + the four deltas of their read group / quality / context / cycle, the others keep their quality.
+    As in the reference the context is always taken from the OQ tag's qualities with minscore 6."""
+    original = _oriented_quals(read, use_oq)
+    out = np.array(original, dtype=np.int_)
+    rg = rg_to_int[read.get_tag('RG')]
+    valid = original >= minscore
+    q = original[valid]
+    cycle = bamread_cycle_covariates(read)[valid]
+    dinuc = bamread_dinuc_covariates(read)[valid]
+    out[valid] = (meanq[rg] + globaldeltaq[rg] + qscoredeltaq[rg, q] + dinucdeltaq[rg, q, dinuc]
+                  + positiondeltaq[rg, q, cycle]).astype(np.int_)
+    return out
+

@@ -123,3 +123,9 @@ def bamread_get_quals(read, use_oq=False):
     if use_oq:
         return compare_reads.bamread_get_oq(read)
     return np.array(read.query_qualities, dtype=np.int_)
+
+
+def bamread_get_oq(read):
+    """The OQ tag's qualities as an int array (reference read.py:385-396; the same function as compare_reads')."""
+    return compare_reads.bamread_get_oq(read)
+

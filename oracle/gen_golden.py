@@ -225,6 +225,13 @@ def run_bqsr_case(name, c, tmp):
                                  else bqsr.bamread_adaptor_boundary(r) for r in reads], dtype=np.int64)
     bam = pysam.AlignmentFile(paths['sam'])
     rep = str(bqsr.bam_to_report(bam, paths['fa'], var_pos))
+    # the per-read ApplyBQSR emulation (gatk/applybqsr.py:46-78) with the model solved from the vectors above
+    from kbbq.gatk import applybqsr
+    dqs = applybqsr.get_delta_qs(*vectors)
+    rg_to_int = {rg: i for i, rg in enumerate(utils.get_rg_to_pu(bam))}
+    arrs['ab_cycle'] = np.concatenate([applybqsr.bamread_cycle_covariates(r) for r in reads]).astype(np.int64)
+    arrs['ab_dinuc'] = np.concatenate([applybqsr.bamread_dinuc_covariates(r) for r in reads]).astype(np.int64)
+    arrs['ab_recal'] = np.concatenate([applybqsr.recalibrate_bamread(r, vectors[0], *dqs, rg_to_int) for r in reads]).astype(np.int64)
     np.savez_compressed(os.path.join(GOLD, name + '.npz'), **arrs)
     with open(os.path.join(GOLD, name + '.json'), 'w') as fh:
         json.dump(dict(case=c, input_sha256=sha, rg_to_pu=utils.get_rg_to_pu(bam),

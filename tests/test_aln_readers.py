@@ -138,3 +138,16 @@ def test_readdata_bam_factories(tmp_path):
         assert read.bamread_get_quals(reads[1]).tolist() == [ord(c) - 33 for c in '><>???>>>']
     finally:
         read.ReadData.rg_to_pu = dict(); read.ReadData.rg_to_int = dict(); read.ReadData.numrgs = 0
+
+
+def test_small_helpers_of_compare_reads(tmp_path):
+    """tstamp / load_positions / get_var_sites (reference compare_reads.py:26-68)."""
+    import re
+    from kbbq import benchmark, compare_reads
+    assert re.fullmatch(r'\[ \d{4}-\d\d-\d\d \d\d:\d\d:\d\d \]', compare_reads.tstamp())
+    bed = tmp_path / 'p.bed'; bed.write_text('ref\t8\t11\nother\t0\t2\nref\t20\t21\n')
+    assert compare_reads.load_positions(str(bed)) == {'ref': [8, 9, 10, 20], 'other': [0, 1]}
+    vcf = tmp_path / 's.vcf'
+    vcf.write_text('##fileformat=VCFv4.2\n##contig=<ID=ref,length=45>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n'
+                   'ref\t10\t.\tG\tT\t30\t.\t.\nref\t20\t.\tACG\tA\t30\t.\t.\n')
+    assert compare_reads.get_var_sites(str(vcf)) == benchmark.get_var_sites(str(vcf)) == {'ref': [9, 19, 20, 21]}

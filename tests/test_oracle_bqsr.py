@@ -242,3 +242,24 @@ def test_native_sam_arrays_match_stand_ins(oracle, tmp_path):
     bam.write_bytes(b'BAM\x01....')
     with pytest.raises(ValueError):
         aln.AlignmentFile(str(bam))
+
+
+@pytest.mark.parametrize('name', ['bqsr_a', 'bqsr_b'])
+def test_per_read_applybqsr_functions_match_the_reference(oracle, name, tmp_path):
+    """kbbq.gatk.applybqsr.bamread_cycle_covariates / bamread_dinuc_covariates / recalibrate_bamread (reference
+    applybqsr.py:46-78) against arrays the UNMODIFIED reference produced on the same alignments (oracle/gen_golden.py),
+    through SAM text and through a BAM file of it."""
+    import bamwriter
+    from kbbq import aln, compare_reads
+    from kbbq.gatk import applybqsr
+    info, gold, paths = _inputs(name, tmp_path, oracle)
+    vectors = [gold[k] for k in VEC]
+    dqs = oracle.get_delta_qs(*vectors)                 # the CPU restatement of the solve (the product's runs on the GPU)
+    for source in (paths['sam'], bamwriter.write_bam(tmp_path / 'a.bam', open(paths['sam']).read())):
+        bam = aln.AlignmentFile(source)
+        rg_to_int = {rg: i for i, rg in enumerate(compare_reads.get_rg_to_pu(bam))}
+        reads = list(bam)
+        assert np.array_equal(np.concatenate([applybqsr.bamread_cycle_covariates(r) for r in reads]), gold['ab_cycle'])
+        assert np.array_equal(np.concatenate([applybqsr.bamread_dinuc_covariates(r) for r in reads]), gold['ab_dinuc'])
+        got = np.concatenate([applybqsr.recalibrate_bamread(r, vectors[0], *dqs, rg_to_int) for r in reads])
+        assert got.dtype == np.int_ and np.array_equal(got, gold['ab_recal'])
