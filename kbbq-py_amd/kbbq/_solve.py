@@ -36,7 +36,7 @@ def model_consts():
     return np.ascontiguousarray(np.concatenate([prior, logp, log1mp]))
 
 
-COMBILN_THREADS = 4
+COMBILN_THREADS = 8
 
 
 def combiln_scipy(numerrs, numtotal):
