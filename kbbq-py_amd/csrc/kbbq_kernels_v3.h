@@ -1039,32 +1039,42 @@ __global__ __launch_bounds__(K5_THREADS) void k5_count_q(K5Params p)
         __syncthreads();
     };
     int since = 0;
+    // the loads of the NEXT chunk are issued before the current one is binned (one step of software prefetch)
+    struct Chunk { uint4 q, e, s; long long r; int nb; };
+    auto fetch = [&](long long ch, Chunk& c) {
+        c.nb = 0; c.r = 0;
+        if (ch >= nchunks) return;
+        c.r = ch / p.cpr;
+        const int j = (int)(ch - c.r * p.cpr);
+        c.nb = (int)p.len[c.r] - 16 * j;
+        if (c.nb <= 0) return;
+        const size_t off = (size_t)c.r * p.pitch + (size_t)16 * j;
+        c.q = *reinterpret_cast<const uint4*>(p.qual + off);
+        c.e = *reinterpret_cast<const uint4*>(p.err + off);
+        c.s = *reinterpret_cast<const uint4*>(p.skip + off);
+    };
     long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    Chunk cur, nxt;
+    fetch(ch, cur);
     for (long long it = 0; it < iters; ++it, ch += stride) {
-        if (ch < nchunks) {
-            const long long r = ch / p.cpr;
-            const int j = (int)(ch - r * p.cpr);
-            const int nb = (int)p.len[r] - 16 * j;
-            if (nb > 0) {
-                const size_t off = (size_t)r * p.pitch + (size_t)16 * j;
-                const uint4 qv = *reinterpret_cast<const uint4*>(p.qual + off);
-                const uint4 ev = *reinterpret_cast<const uint4*>(p.err + off);
-                const uint4 sv = *reinterpret_cast<const uint4*>(p.skip + off);
-                const u32 q[4] = {qv.x, qv.y, qv.z, qv.w}, e[4] = {ev.x, ev.y, ev.z, ev.w}, s[4] = {sv.x, sv.y, sv.z, sv.w};
-                bool negative = false;
+        fetch(ch + stride, nxt);
+        if (cur.nb > 0) {
+            const int nb = cur.nb;
+            const u32 q[4] = {cur.q.x, cur.q.y, cur.q.z, cur.q.w}, e[4] = {cur.e.x, cur.e.y, cur.e.z, cur.e.w}, s[4] = {cur.s.x, cur.s.y, cur.s.z, cur.s.w};
+            bool negative = false;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int sh = 8 * (i & 3);
-                    const int qq = (int)((q[i >> 2] >> sh) & 0xFFu) - p.qoffset;
-                    const bool counted = i < nb && ((s[i >> 2] >> sh) & 0xFFu) == 0u;
-                    negative |= counted && qq < 0;                               // np.bincount rejects negative values: ValueError
-                    const u32 bin = (counted && qq >= 0) ? (u32)qq : 256u;
-                    const u32 inc = ((e[i >> 2] >> sh) & 0xFFu) ? 0x10001u : 1u;
-                    atomicAdd(&h[bin * K5_COPIES + copy], inc);
-                }
-                if (negative) flag(p.status, ST_RANGE, r);
+            for (int i = 0; i < 16; ++i) {
+                const int sh = 8 * (i & 3);
+                const int qq = (int)((q[i >> 2] >> sh) & 0xFFu) - p.qoffset;
+                const bool counted = i < nb && ((s[i >> 2] >> sh) & 0xFFu) == 0u;
+                negative |= counted && qq < 0;                               // np.bincount rejects negative values: ValueError
+                const u32 bin = (counted && qq >= 0) ? (u32)qq : 256u;
+                const u32 inc = ((e[i >> 2] >> sh) & 0xFFu) ? 0x10001u : 1u;
+                atomicAdd(&h[bin * K5_COPIES + copy], inc);
             }
+            if (negative) flag(p.status, ST_RANGE, cur.r);
         }
+        cur = nxt;
         if (++since == K5_FLUSH_ITERS) { flush(); since = 0; }
     }
     flush();
