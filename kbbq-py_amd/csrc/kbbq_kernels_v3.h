@@ -818,6 +818,14 @@ __device__ __forceinline__ u32 complement4(u32 w)
 
 __device__ __forceinline__ bool is_acgt(u32 ch) { return ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'; }
 
+// Work items of a thread: (read block rb, chunk j) with j = j0, j0 + 256, ... inside a row and rb advancing by the
+// grid.  They are software-pipelined two deep -- the per-read fields of item i + 2 and the four 16-byte windows of
+// item i + 1 are in flight while item i is computed and stored -- because the chain  fields -> windows -> stores
+// is what a wave otherwise waits through once per item.
+struct K6Item { long long rb; int j; };
+struct K6Meta { u32 fl, clip, trim; bool valid; };
+struct K6Win { u32 s[4], q[4], e[4], k[4]; int cnt, i0; bool has; };
+
 __global__ __launch_bounds__(256) void k6_canonical_reads(K6Params p)
 {
     const int cpr = p.pitch >> 4;
@@ -825,75 +833,104 @@ __global__ __launch_bounds__(256) void k6_canonical_reads(K6Params p)
     const int slot = cpr <= 256 ? (int)threadIdx.x / cpr : 0;
     const int j0 = (int)threadIdx.x - slot * cpr;
     const long long step = rpb ? rpb : 1;
-    for (long long rb = (long long)blockIdx.x * step; rb < p.nreads; rb += (long long)gridDim.x * step)
-    for (int j = j0; j < cpr; j += 256) {
-        const long long r = rb + slot;
-        if (r >= p.nreads || (rpb && slot >= rpb)) break;
-        const u32 fl = p.flags[r];
-        const bool rev = (fl & 1u) != 0;
-        const int qs = (int)(p.clip[r] & 0xFFFFu), qe = (int)(p.clip[r] >> 16);
-        const int tlo = (int)(p.trim[r] & 0xFFFFu), thi = (int)(p.trim[r] >> 16);
-        const int L = qe - qs;
-        const int c0 = 16 * j;
-        u32 os[4] = {0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu};
-        u32 oc[4] = {0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu};
-        u32 oqv[4] = {0u, 0u, 0u, 0u};
-        const size_t row = (size_t)r * p.pitch;
-        if (j == 0) p.out_meta[r] = (u32)p.S | ((fl >> 16) << 16) | ((fl & 2u) ? 0x80000000u : 0u);
-        if (c0 < L) {
-            // input window [i0, i0 + 16): the chunk's bases in INPUT order occupy its first cnt bytes
-            // (a reverse-strand chunk is byte-reversed afterwards; a partial one then shifted down)
-            const int cnt = L - c0 < 16 ? L - c0 : 16;
-            const int i0 = rev ? (cnt == 16 ? qe - c0 - 16 : qs) : qs + c0;
-            u32 s[4], q[4], e[4], k[4];
-            const long long plane = p.nreads * (long long)p.pitch;
-            load16_upto(p.seq, (long long)row + i0, plane, s);
-            load16_upto(p.oq, (long long)row + i0, plane, q);
-            load16_upto(p.err, (long long)row + i0, plane, e);
-            load16_upto(p.skip, (long long)row + i0, plane, k);
-            bool odd = false;
+    const long long gstep = (long long)gridDim.x * step;
+    const bool idle = (rpb && slot >= rpb) || j0 >= cpr;
+    const long long plane = p.nreads * (long long)p.pitch;
+    auto next = [&](K6Item it) { it.j += 256; if (it.j >= cpr) { it.j = j0; it.rb += gstep; } return it; };
+    auto live = [&](const K6Item& it) { return !idle && it.rb + slot < p.nreads; };
+    auto fetch_meta = [&](const K6Item& it, K6Meta& m) {
+        m.valid = live(it);
+        const long long r = m.valid ? it.rb + slot : 0;
+        m.fl = p.flags[r]; m.clip = p.clip[r]; m.trim = p.trim[r];
+    };
+    auto fetch_win = [&](const K6Item& it, const K6Meta& m, K6Win& w) {
+        w.has = false; w.cnt = 0; w.i0 = 0;
+        if (!m.valid) return;
+        const int qs = (int)(m.clip & 0xFFFFu), qe = (int)(m.clip >> 16);
+        const int L = qe - qs, c0 = 16 * it.j;
+        if (c0 >= L) return;
+        // input window [i0, i0 + 16): the chunk's bases in INPUT order occupy its first cnt bytes
+        // (a reverse-strand chunk is byte-reversed afterwards; a partial one then shifted down)
+        w.has = true;
+        w.cnt = L - c0 < 16 ? L - c0 : 16;
+        w.i0 = (m.fl & 1u) ? (w.cnt == 16 ? qe - c0 - 16 : qs) : qs + c0;
+        const long long at = (it.rb + slot) * (long long)p.pitch + w.i0;
+        load16_upto(p.seq, at, plane, w.s);
+        load16_upto(p.oq, at, plane, w.q);
+        load16_upto(p.err, at, plane, w.e);
+        load16_upto(p.skip, at, plane, w.k);
+    };
+    K6Item it0{(long long)blockIdx.x * step, j0};
+    K6Item it1 = next(it0), it2 = next(it1);
+    K6Meta m0, m1, m2;
+    K6Win w0, w1;
+    fetch_meta(it0, m0); fetch_meta(it1, m1);
+    fetch_win(it0, m0, w0);
+    while (live(it0)) {
+        fetch_meta(it2, m2);
+        fetch_win(it1, m1, w1);
+        {
+            const long long r = it0.rb + slot;
+            const int j = it0.j;
+            const u32 fl = m0.fl;
+            const bool rev = (fl & 1u) != 0;
+            const int tlo = (int)(m0.trim & 0xFFFFu), thi = (int)(m0.trim >> 16);
+            const int c0 = 16 * j;
+            u32 os[4] = {0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu};
+            u32 oc[4] = {0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu};
+            u32 oqv[4] = {0u, 0u, 0u, 0u};
+            const size_t row = (size_t)r * p.pitch;
+            if (j == 0) p.out_meta[r] = (u32)p.S | ((fl >> 16) << 16) | ((fl & 2u) ? 0x80000000u : 0u);
+            if (w0.has) {
+                const int cnt = w0.cnt, i0 = w0.i0;
+                const u32 (&s)[4] = w0.s; const u32 (&q)[4] = w0.q; const u32 (&e)[4] = w0.e; const u32 (&k)[4] = w0.k;
+                bool odd = false;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const u32 below = (~((q[w] | 0x80808080u) - p.qlo * 0x01010101u) >> 7) & 0x01010101u;   // q < minscore
-                const u32 trimmed = range_mask(tlo - i0, thi - i0, w) & 0x01010101u;
-                const u32 isn = nonzero_bytes(s[w] ^ 0x4E4E4E4Eu) ^ 0x01010101u;
-                const u32 sk = (nonzero_bytes(k[w]) | below | trimmed | isn) * 0xFFu;
-                u32 code, code5, expect;
-                decode4x(s[w], code, code5, expect);
-                odd |= ((expect ^ s[w]) & byte_mask(cnt, w)) != 0u;
-                os[w] = rev ? complement4(s[w]) : s[w];
-                oc[w] = os[w] ^ (nonzero_bytes(e[w]) << 7);                    // an error: cseq differs from seq
-                oqv[w] = q[w] & ~sk;
-            }
-            if (odd && !rev) {
-                // the reference's TypeError (compare_reads.py:281-293 via bqsr.py:43-45) is decided on the
-                // ORIGINAL qualities, before any skipping: a looked-up pair with a letter outside ACGT
-                u32 prev = (c0 >= 1) ? p.seq[row + i0 - 1] : 'N';
-                for (int b = 0; b < cnt; ++b) {
-                    const u32 cur = (s[b >> 2] >> (8 * (b & 3))) & 0xFFu, qq = (q[b >> 2] >> (8 * (b & 3))) & 0xFFu;
-                    if (c0 + b >= 1 && qq >= p.dlo && cur != 'N' && prev != 'N' && !(is_acgt(cur) && is_acgt(prev)))
-                        flag(p.status, ST_TYPE, r);
-                    prev = cur;
+                for (int w = 0; w < 4; ++w) {
+                    const u32 below = (~((q[w] | 0x80808080u) - p.qlo * 0x01010101u) >> 7) & 0x01010101u;   // q < minscore
+                    const u32 trimmed = range_mask(tlo - i0, thi - i0, w) & 0x01010101u;
+                    const u32 isn = nonzero_bytes(s[w] ^ 0x4E4E4E4Eu) ^ 0x01010101u;
+                    const u32 sk = (nonzero_bytes(k[w]) | below | trimmed | isn) * 0xFFu;
+                    u32 code, code5, expect;
+                    decode4x(s[w], code, code5, expect);
+                    odd |= ((expect ^ s[w]) & byte_mask(cnt, w)) != 0u;
+                    os[w] = rev ? complement4(s[w]) : s[w];
+                    oc[w] = os[w] ^ (nonzero_bytes(e[w]) << 7);                    // an error: cseq differs from seq
+                    oqv[w] = q[w] & ~sk;
+                }
+                if (odd && !rev) {
+                    // the reference's TypeError (compare_reads.py:281-293 via bqsr.py:43-45) is decided on the
+                    // ORIGINAL qualities, before any skipping: a looked-up pair with a letter outside ACGT
+                    u32 prev = (c0 >= 1) ? p.seq[row + i0 - 1] : 'N';
+                    for (int b = 0; b < cnt; ++b) {
+                        const u32 cur = (s[b >> 2] >> (8 * (b & 3))) & 0xFFu, qq = (q[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+                        if (c0 + b >= 1 && qq >= p.dlo && cur != 'N' && prev != 'N' && !(is_acgt(cur) && is_acgt(prev)))
+                            flag(p.status, ST_TYPE, r);
+                        prev = cur;
+                    }
+                }
+                if (rev) {
+                    reverse16(os); reverse16(oc); reverse16(oqv);
+                    if (cnt < 16) { shr_bytes16(os, 16 - cnt); shr_bytes16(oc, 16 - cnt); shr_bytes16(oqv, 16 - cnt); }
+                }
+                if (cnt < 16) {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {                                  // past the aligned part: uncounted padding
+                        const u32 vm = byte_mask(cnt, w);
+                        os[w] = (os[w] & vm) | (0x4E4E4E4Eu & ~vm);
+                        oc[w] = (oc[w] & vm) | (0x4E4E4E4Eu & ~vm);
+                        oqv[w] &= vm;
+                    }
                 }
             }
-            if (rev) {
-                reverse16(os); reverse16(oc); reverse16(oqv);
-                if (cnt < 16) { shr_bytes16(os, 16 - cnt); shr_bytes16(oc, 16 - cnt); shr_bytes16(oqv, 16 - cnt); }
-            }
-            if (cnt < 16) {
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {                                  // past the aligned part: uncounted padding
-                    const u32 vm = byte_mask(cnt, w);
-                    os[w] = (os[w] & vm) | (0x4E4E4E4Eu & ~vm);
-                    oc[w] = (oc[w] & vm) | (0x4E4E4E4Eu & ~vm);
-                    oqv[w] &= vm;
-                }
-            }
+            const size_t off = row + (size_t)16 * j;
+            *reinterpret_cast<uint4*>(p.out_seq + off) = make_uint4(os[0], os[1], os[2], os[3]);
+            *reinterpret_cast<uint4*>(p.out_cseq + off) = make_uint4(oc[0], oc[1], oc[2], oc[3]);
+            *reinterpret_cast<uint4*>(p.out_qual + off) = make_uint4(oqv[0], oqv[1], oqv[2], oqv[3]);
         }
-        const size_t off = row + (size_t)16 * j;
-        *reinterpret_cast<uint4*>(p.out_seq + off) = make_uint4(os[0], os[1], os[2], os[3]);
-        *reinterpret_cast<uint4*>(p.out_cseq + off) = make_uint4(oc[0], oc[1], oc[2], oc[3]);
-        *reinterpret_cast<uint4*>(p.out_qual + off) = make_uint4(oqv[0], oqv[1], oqv[2], oqv[3]);
+        it0 = it1; m0 = m1; w0 = w1;
+        it1 = it2; m1 = m2;
+        it2 = next(it2);
     }
 }
 
