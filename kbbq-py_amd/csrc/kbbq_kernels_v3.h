@@ -684,6 +684,15 @@ __device__ __forceinline__ void shr_bytes16(u32 v[4], int nb)            // byte
 // and of the site mask (unaligned 16-byte loads), compared
 // byte-parallel.  For reverse-strand reads the OUTPUT is reversed (benchmark.py:70-72): the
 // lane's input positions are then [n-16j-16, n-16j) and its 16 result bytes are byte-reversed.
+// Work items (read block, chunk) of a thread are software-pipelined two deep, as in K6: the per-read fields of item
+// i + 2, then -- for item i + 1 -- the chunk's read bytes, the first CIGAR operation and, SPECULATIVELY, the reference
+// and mask windows the chunk needs if no insertion / deletion precedes it (offset ref_start + in_lo: every chunk of a
+// one-block read, and the chunks before the first indel of any other) are in flight while item i is walked.  The walk
+// uses the speculative windows when an M block asks for exactly that offset and loads its own otherwise.
+struct K4Item { long long rb; int j; };
+struct K4Meta { int n, rl; u32 f, nc; long long g0; const u32* ops; bool valid; };
+struct K4Win { u32 sw[4], gw[4], mw[4]; u32 op0; long long goff; int in_lo, cnt; bool has, spec; };
+
 __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
 {
     // a workgroup takes 256 / cpr whole reads per iteration: (slot, chunk) of a thread are fixed
@@ -692,95 +701,135 @@ __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
     const int slot = cpr <= 256 ? (int)threadIdx.x / cpr : 0;
     const int j0 = (int)threadIdx.x - slot * cpr;
     const long long step = rpb ? rpb : 1;
-    for (long long rb = (long long)blockIdx.x * step; rb < p.nreads; rb += (long long)gridDim.x * step)
-    for (int j = j0; j < cpr; j += 256) {                          // one trip unless a row has more than 256 chunks
-        const long long r = rb + slot;
-        if (r >= p.nreads || (rpb && slot >= rpb)) break;
-        const int n = (int)p.len[r];
-        const int rl = p.ref_len[r];
-        const bool f = p.flip[r] != 0;
-        u32 ev[4] = {0u, 0u, 0u, 0u}, kv[4] = {0u, 0u, 0u, 0u};
-        const int out_lo = 16 * j, out_hi = out_lo + 16 < n ? out_lo + 16 : n;
-        if (out_lo < n) {
-            const int cnt = out_hi - out_lo;
-            const int in_lo = f ? n - out_hi : out_lo;            // input (unflipped) positions [in_lo, in_lo + cnt)
-            const int in_hi = in_lo + cnt;
-            const uint8_t* s = p.seq + (size_t)r * p.pitch;
-            const long long g0 = p.ref_start[r];
-            int readidx = 0, refidx = 0;
-            const u32* ops = p.cigar + p.cig_off[r];
-            const u32 nc = p.cig_n[r];
-            u32 sw[4];
-            load16_any(s, in_lo, sw);                                      // the chunk's read bytes (may run into the next row)
-            for (u32 c = 0; c < nc; ++c) {
-                const int op = (int)(ops[c] & 15u), l = (int)(ops[c] >> 4);
-                if (op == 0 || op == 7 || op == 8) {                       // M = X  (:109-114)
-                    if (refidx + l > rl || readidx + l > n) { flag(p.status, ST_RANGE, r); break; }   // shape mismatch: ValueError
-                    const int a = readidx > in_lo ? readidx : in_lo, b = readidx + l < in_hi ? readidx + l : in_hi;
-                    if (a < b) {
-                        // reference window aligned with the CHUNK start (as if the operation began there):
-                        // bytes [a - in_lo, b - in_lo) of the comparison belong to this operation
-                        const int d = a - in_lo;
-                        const long long goff = g0 + refidx + (a - readidx) - d;
-                        if (goff >= 0) {
-                            u32 gw[4], mw[4];
-                            load16_upto(p.genome, goff, p.genome_len, gw);
-                            load16_upto(p.skipmask, goff, p.genome_len, mw);
+    const long long gstep = (long long)gridDim.x * step;
+    const bool idle = (rpb && slot >= rpb) || j0 >= cpr;
+    auto next = [&](K4Item it) { it.j += 256; if (it.j >= cpr) { it.j = j0; it.rb += gstep; } return it; };
+    auto live = [&](const K4Item& it) { return !idle && it.rb + slot < p.nreads; };
+    auto fetch_meta = [&](const K4Item& it, K4Meta& m) {
+        m.valid = live(it);
+        const long long r = m.valid ? it.rb + slot : 0;
+        m.n = (int)p.len[r]; m.rl = p.ref_len[r]; m.f = p.flip[r]; m.g0 = p.ref_start[r];
+        m.nc = m.valid ? p.cig_n[r] : 0u;
+        m.ops = p.cigar + p.cig_off[r];
+    };
+    auto fetch_win = [&](const K4Item& it, const K4Meta& m, K4Win& w) {
+        w.has = false; w.spec = false; w.cnt = 0; w.in_lo = 0; w.op0 = 0u; w.goff = 0;
+        if (!m.valid) return;
+        const int n = m.n, out_lo = 16 * it.j, out_hi = out_lo + 16 < n ? out_lo + 16 : n;
+        if (out_lo >= n) return;
+        w.has = true;
+        w.cnt = out_hi - out_lo;
+        w.in_lo = m.f ? n - out_hi : out_lo;                       // input (unflipped) positions [in_lo, in_lo + cnt)
+        load16_any(p.seq + (size_t)(it.rb + slot) * p.pitch, w.in_lo, w.sw);   // the chunk's read bytes (may run into the next row)
+        if (m.nc) w.op0 = m.ops[0];
+        w.goff = m.g0 + w.in_lo;
+        w.spec = w.goff >= 0 && w.goff + 16 <= p.genome_len;
+        if (w.spec) { load16_any(p.genome, w.goff, w.gw); load16_any(p.skipmask, w.goff, w.mw); }
+    };
+    K4Item it0{(long long)blockIdx.x * step, j0};
+    K4Item it1 = next(it0), it2 = next(it1);
+    K4Meta m0, m1, m2;
+    K4Win w0, w1;
+    fetch_meta(it0, m0); fetch_meta(it1, m1);
+    fetch_win(it0, m0, w0);
+    while (live(it0)) {
+        fetch_meta(it2, m2);
+        fetch_win(it1, m1, w1);
+        {
+            const long long r = it0.rb + slot;
+            const int j = it0.j;
+            const int n = m0.n, rl = m0.rl;
+            const bool f = m0.f != 0;
+            u32 ev[4] = {0u, 0u, 0u, 0u}, kv[4] = {0u, 0u, 0u, 0u};
+            if (w0.has) {
+                const int cnt = w0.cnt, in_lo = w0.in_lo, in_hi = in_lo + cnt;
+                const uint8_t* s = p.seq + (size_t)r * p.pitch;
+                const long long g0 = m0.g0;
+                int readidx = 0, refidx = 0;
+                const u32* ops = m0.ops;
+                const u32 nc = m0.nc;
+                const u32 (&sw)[4] = w0.sw;
+                for (u32 c = 0; c < nc; ++c) {
+                    const u32 word = c == 0 ? w0.op0 : ops[c];
+                    const int op = (int)(word & 15u), l = (int)(word >> 4);
+                    if (op == 0 || op == 7 || op == 8) {                       // M = X  (:109-114)
+                        if (refidx + l > rl || readidx + l > n) { flag(p.status, ST_RANGE, r); break; }   // shape mismatch: ValueError
+                        const int a = readidx > in_lo ? readidx : in_lo, b = readidx + l < in_hi ? readidx + l : in_hi;
+                        if (a < b) {
+                            // reference window aligned with the CHUNK start (as if the operation began there):
+                            // bytes [a - in_lo, b - in_lo) of the comparison belong to this operation
+                            const int d = a - in_lo;
+                            const long long goff = g0 + refidx + (a - readidx) - d;
+                            if (goff >= 0) {
+                                u32 gw[4], mw[4];
+                                if (w0.spec && goff == w0.goff) {
 #pragma unroll
-                            for (int w = 0; w < 4; ++w) {
-                                const u32 rm = range_mask(d, b - in_lo, w);
-                                ev[w] = (ev[w] & ~rm) | (nonzero_bytes(sw[w] ^ gw[w]) & rm);
-                                kv[w] = (kv[w] & ~rm) | (nonzero_bytes(mw[w]) & rm);
-                            }
-                        } else {                                           // within 15 bytes of the genome's first byte
-                            const long long roff = g0 + refidx + (a - readidx);
-                            for (int q = a; q < b; ++q) {
-                                set_byte(ev, q - in_lo, p.genome[roff + (q - a)] != s[q] ? 1u : 0u);
-                                set_byte(kv, q - in_lo, p.skipmask[roff + (q - a)] != 0 ? 1u : 0u);
+                                    for (int w = 0; w < 4; ++w) { gw[w] = w0.gw[w]; mw[w] = w0.mw[w]; }
+                                } else {
+                                    load16_upto(p.genome, goff, p.genome_len, gw);
+                                    load16_upto(p.skipmask, goff, p.genome_len, mw);
+                                }
+#pragma unroll
+                                for (int w = 0; w < 4; ++w) {
+                                    const u32 rm = range_mask(d, b - in_lo, w);
+                                    ev[w] = (ev[w] & ~rm) | (nonzero_bytes(sw[w] ^ gw[w]) & rm);
+                                    kv[w] = (kv[w] & ~rm) | (nonzero_bytes(mw[w]) & rm);
+                                }
+                            } else {                                           // within 15 bytes of the genome's first byte
+                                const long long roff = g0 + refidx + (a - readidx);
+                                for (int q = a; q < b; ++q) {
+                                    set_byte(ev, q - in_lo, p.genome[roff + (q - a)] != s[q] ? 1u : 0u);
+                                    set_byte(kv, q - in_lo, p.skipmask[roff + (q - a)] != 0 ? 1u : 0u);
+                                }
                             }
                         }
-                    }
-                    readidx += l; refidx += l;
-                } else if (op == 1) {                                      // I      (:115-120)
-                    if (rl == 0 || refidx >= rl) { flag(p.status, ST_INDEX, r); break; }   // subset_variable[refidx]
-                    const int left = refidx - 1 < 0 ? rl - 1 : refidx - 1;               // Python wraps index -1
-                    const u32 both = (p.skipmask[g0 + left] != 0 && p.skipmask[g0 + refidx] != 0) ? 1u : 0u;
-                    const int a = readidx > in_lo ? readidx : in_lo, b = readidx + l < in_hi ? readidx + l : in_hi;
+                        readidx += l; refidx += l;
+                    } else if (op == 1) {                                      // I      (:115-120)
+                        if (rl == 0 || refidx >= rl) { flag(p.status, ST_INDEX, r); break; }   // subset_variable[refidx]
+                        const int a = readidx > in_lo ? readidx : in_lo, b = readidx + l < in_hi ? readidx + l : in_hi;
+                        if (a < b) {                                           // only the chunks the insertion touches look at the mask
+                            const int left = refidx - 1 < 0 ? rl - 1 : refidx - 1;               // Python wraps index -1
+                            const u32 both = (p.skipmask[g0 + left] != 0 && p.skipmask[g0 + refidx] != 0) ? 1u : 0u;
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const u32 rm = range_mask(a - in_lo, b - in_lo, w);
-                        kv[w] = (kv[w] & ~rm) | ((both * 0x01010101u) & rm);
-                    }
-                    readidx += l;
-                } else if (op == 2 || op == 3) {                           // D N    (:121-125)
-                    if (n == 0) { flag(p.status, ST_INDEX, r); break; }
-                    const int at = readidx - 1 < 0 ? n + (readidx - 1) : readidx - 1;    // skips[-1]: the last base
-                    if (at < 0 || at >= n) { flag(p.status, ST_INDEX, r); break; }
-                    if (at >= in_lo && at < in_hi) {
-                        u32 any = 0u;
-                        for (int i = refidx; i < refidx + l && i < rl; ++i) any |= p.skipmask[g0 + i];
-                        set_byte(kv, at - in_lo, get_byte(kv, at - in_lo) | (any ? 1u : 0u));
-                    }
-                    refidx += l;
-                } else if (op == 4) {                                      // S      (:126-129)
-                    const int a = readidx > in_lo ? readidx : in_lo, b = readidx + l < in_hi ? readidx + l : in_hi;
+                            for (int w = 0; w < 4; ++w) {
+                                const u32 rm = range_mask(a - in_lo, b - in_lo, w);
+                                kv[w] = (kv[w] & ~rm) | ((both * 0x01010101u) & rm);
+                            }
+                        }
+                        readidx += l;
+                    } else if (op == 2 || op == 3) {                           // D N    (:121-125)
+                        if (n == 0) { flag(p.status, ST_INDEX, r); break; }
+                        const int at = readidx - 1 < 0 ? n + (readidx - 1) : readidx - 1;    // skips[-1]: the last base
+                        if (at < 0 || at >= n) { flag(p.status, ST_INDEX, r); break; }
+                        if (at >= in_lo && at < in_hi) {
+                            u32 any = 0u;
+                            for (int i = refidx; i < refidx + l && i < rl; ++i) any |= p.skipmask[g0 + i];
+                            set_byte(kv, at - in_lo, get_byte(kv, at - in_lo) | (any ? 1u : 0u));
+                        }
+                        refidx += l;
+                    } else if (op == 4) {                                      // S      (:126-129)
+                        const int a = readidx > in_lo ? readidx : in_lo, b = readidx + l < in_hi ? readidx + l : in_hi;
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const u32 rm = range_mask(a - in_lo, b - in_lo, w);
-                        kv[w] = (kv[w] & ~rm) | (0x01010101u & rm);
-                    }
-                    readidx += l;
-                } else if (op == 5 || op == 6) {                           // H P    (:130-134)
-                } else { flag(p.status, ST_RANGE, r); break; }             // unrecognised operation: ValueError
+                        for (int w = 0; w < 4; ++w) {
+                            const u32 rm = range_mask(a - in_lo, b - in_lo, w);
+                            kv[w] = (kv[w] & ~rm) | (0x01010101u & rm);
+                        }
+                        readidx += l;
+                    } else if (op == 5 || op == 6) {                           // H P    (:130-134)
+                    } else { flag(p.status, ST_RANGE, r); break; }             // unrecognised operation: ValueError
+                }
+                if (f) {                                                       // output byte i = input byte cnt-1-i
+                    reverse16(ev); reverse16(kv);
+                    shr_bytes16(ev, 16 - cnt); shr_bytes16(kv, 16 - cnt);
+                }
             }
-            if (f) {                                                       // output byte i = input byte cnt-1-i
-                reverse16(ev); reverse16(kv);
-                shr_bytes16(ev, 16 - cnt); shr_bytes16(kv, 16 - cnt);
-            }
+            const size_t off = (size_t)r * p.pitch + (size_t)16 * j;
+            *reinterpret_cast<uint4*>(p.err + off) = make_uint4(ev[0], ev[1], ev[2], ev[3]);
+            *reinterpret_cast<uint4*>(p.skip + off) = make_uint4(kv[0], kv[1], kv[2], kv[3]);
         }
-        const size_t off = (size_t)r * p.pitch + (size_t)16 * j;
-        *reinterpret_cast<uint4*>(p.err + off) = make_uint4(ev[0], ev[1], ev[2], ev[3]);
-        *reinterpret_cast<uint4*>(p.skip + off) = make_uint4(kv[0], kv[1], kv[2], kv[3]);
+        it0 = it1; m0 = m1; w0 = w1;
+        it1 = it2; m1 = m2;
+        it2 = next(it2);
     }
 }
 
