@@ -227,6 +227,8 @@ int kbbq_find_errors_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint32_t* d_
                          const uint32_t* d_cig_off, const uint32_t* d_cig_n, const uint32_t* d_cigar,
                          const uint8_t* d_genome, const uint8_t* d_skipmask, int64_t genome_len,
                          const uint8_t* d_flip, uint8_t* d_err, uint8_t* d_skip);
+/* d_skipmask may be NULL: the reference is then FUSED -- bit 7 of every d_genome byte is that site's skip flag, the
+ * low 7 bits its letter (ASCII) -- and a chunk fetches one scattered 16-byte window instead of two. */
 /* kbbq_canonical_reads_dev: first half of gatk.bqsr.bam_to_bqsr_covariates (gatk/bqsr.py:52-123;
  * strand-aware covariates :23-50, skips :86-88).  Rewrites aligned reads into sequencing
  * orientation so that kbbq_accumulate_dev tallies them: per read the aligned part

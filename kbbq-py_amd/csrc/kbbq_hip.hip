@@ -854,7 +854,8 @@ int kbbq_find_errors_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint32_t* d_le
         return fail(KBBQ_E_ARG, "kbbq_find_errors_dev: planes must be 16-byte aligned");
     const int rpb4 = (pitch / 16) <= 256 ? 256 / (pitch / 16) : 1;              // reads per workgroup iteration
     int gx = (int)std::min<int64_t>((nreads + rpb4 - 1) / rpb4, (int64_t)c->cus * 16);
-    hipLaunchKernelGGL(k4_find_errors, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    if (d_skipmask) hipLaunchKernelGGL(k4_find_errors<false>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    else hipLaunchKernelGGL(k4_find_errors<true>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
 }

@@ -610,7 +610,7 @@ struct K4Params {
     const long long* ref_start;      // offset of reference_start in `genome` / `skipmask`
     const int* ref_len;              // reference_end - reference_start (the read's reference window)
     const u32* cig_off; const u32* cig_n; const u32* cigar;   // per read: first op, op count; ops = len << 4 | op
-    const uint8_t* genome; const uint8_t* skipmask; const uint8_t* flip;
+    const uint8_t* genome; const uint8_t* skipmask; const uint8_t* flip;     // skipmask == NULL: bit 7 of a genome byte is its skip flag
     long long genome_len;            // bytes in genome / skipmask
     uint8_t* err; uint8_t* skip; u64* status;
 };
@@ -693,6 +693,7 @@ struct K4Item { long long rb; int j; };
 struct K4Meta { int n, rl; u32 f, nc; long long g0; const u32* ops; bool valid; };
 struct K4Win { u32 sw[4], gw[4], mw[4]; u32 op0; long long goff; int in_lo, cnt; bool has, spec; };
 
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
 {
     // a workgroup takes 256 / cpr whole reads per iteration: (slot, chunk) of a thread are fixed
@@ -703,6 +704,10 @@ __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
     const long long step = rpb ? rpb : 1;
     const long long gstep = (long long)gridDim.x * step;
     const bool idle = (rpb && slot >= rpb) || j0 >= cpr;
+    // fused reference: no separate mask array, bit 7 of every reference byte is the site's skip flag (one scattered
+    // window per chunk instead of two: the windows of a read straddle 2-3 cache lines each, so they are fetched ~1.8x)
+    constexpr bool fused = FUSED;
+    auto mask_at = [&](long long i) -> u32 { return fused ? (u32)(p.genome[i] >> 7) : (u32)(p.skipmask[i] != 0); };
     auto next = [&](K4Item it) { it.j += 256; if (it.j >= cpr) { it.j = j0; it.rb += gstep; } return it; };
     auto live = [&](const K4Item& it) { return !idle && it.rb + slot < p.nreads; };
     auto fetch_meta = [&](const K4Item& it, K4Meta& m) {
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
         if (m.nc) w.op0 = m.ops[0];
         w.goff = m.g0 + w.in_lo;
         w.spec = w.goff >= 0 && w.goff + 16 <= p.genome_len;
-        if (w.spec) { load16_any(p.genome, w.goff, w.gw); load16_any(p.skipmask, w.goff, w.mw); }
+        if (w.spec) { load16_any(p.genome, w.goff, w.gw); if (!fused) load16_any(p.skipmask, w.goff, w.mw); }
     };
     K4Item it0{(long long)blockIdx.x * step, j0};
     K4Item it1 = next(it0), it2 = next(it1);
@@ -767,7 +772,11 @@ __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
                                     for (int w = 0; w < 4; ++w) { gw[w] = w0.gw[w]; mw[w] = w0.mw[w]; }
                                 } else {
                                     load16_upto(p.genome, goff, p.genome_len, gw);
-                                    load16_upto(p.skipmask, goff, p.genome_len, mw);
+                                    if (!fused) load16_upto(p.skipmask, goff, p.genome_len, mw);
+                                }
+                                if (fused) {
+#pragma unroll
+                                    for (int w = 0; w < 4; ++w) { mw[w] = gw[w] & 0x80808080u; gw[w] &= 0x7F7F7F7Fu; }
                                 }
 #pragma unroll
                                 for (int w = 0; w < 4; ++w) {
@@ -778,8 +787,8 @@ __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
                             } else {                                           // within 15 bytes of the genome's first byte
                                 const long long roff = g0 + refidx + (a - readidx);
                                 for (int q = a; q < b; ++q) {
-                                    set_byte(ev, q - in_lo, p.genome[roff + (q - a)] != s[q] ? 1u : 0u);
-                                    set_byte(kv, q - in_lo, p.skipmask[roff + (q - a)] != 0 ? 1u : 0u);
+                                    set_byte(ev, q - in_lo, (u32)(p.genome[roff + (q - a)] & (fused ? 0x7Fu : 0xFFu)) != (u32)s[q] ? 1u : 0u);
+                                    set_byte(kv, q - in_lo, mask_at(roff + (q - a)));
                                 }
                             }
                         }
@@ -789,7 +798,7 @@ __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
                         const int a = readidx > in_lo ? readidx : in_lo, b = readidx + l < in_hi ? readidx + l : in_hi;
                         if (a < b) {                                           // only the chunks the insertion touches look at the mask
                             const int left = refidx - 1 < 0 ? rl - 1 : refidx - 1;               // Python wraps index -1
-                            const u32 both = (p.skipmask[g0 + left] != 0 && p.skipmask[g0 + refidx] != 0) ? 1u : 0u;
+                            const u32 both = mask_at(g0 + left) & mask_at(g0 + refidx);
 #pragma unroll
                             for (int w = 0; w < 4; ++w) {
                                 const u32 rm = range_mask(a - in_lo, b - in_lo, w);
@@ -803,7 +812,7 @@ __global__ __launch_bounds__(256) void k4_find_errors(K4Params p)
                         if (at < 0 || at >= n) { flag(p.status, ST_INDEX, r); break; }
                         if (at >= in_lo && at < in_hi) {
                             u32 any = 0u;
-                            for (int i = refidx; i < refidx + l && i < rl; ++i) any |= p.skipmask[g0 + i];
+                            for (int i = refidx; i < refidx + l && i < rl; ++i) any |= mask_at(g0 + i);
                             set_byte(kv, at - in_lo, get_byte(kv, at - in_lo) | (any ? 1u : 0u));
                         }
                         refidx += l;

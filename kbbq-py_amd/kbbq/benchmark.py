@@ -70,8 +70,16 @@ class _Genome:
             pos += len(arr)
         self.length = pos
         cat = lambda xs: np.concatenate(list(xs)) if xs else np.zeros(0, dtype=np.uint8)
-        self.genome = torch.from_numpy(np.ascontiguousarray(cat(parts))).cuda()
-        self.mask = torch.from_numpy(np.ascontiguousarray(cat(masks))).cuda()
+        letters, flags = cat(parts), cat(masks)
+        import os
+        if os.environ.get('KBBQ_REFERENCE_MASK') != 'separate' and (not len(letters) or int(letters.max()) < 128):
+            # ASCII reference: the skip flag rides in bit 7 of every byte (kbbq_find_errors_dev with a NULL mask) --
+            # one scattered window per chunk instead of two
+            self.genome = torch.from_numpy(np.ascontiguousarray(letters | ((flags != 0).astype(np.uint8) << 7))).cuda()
+            self.mask = None
+        else:
+            self.genome = torch.from_numpy(np.ascontiguousarray(letters)).cuda()
+            self.mask = torch.from_numpy(np.ascontiguousarray(flags)).cuda()
         self.sizes = {c: len(a) for c, a in refdict.items()}
 
 

@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, 'kbbq-py_amd'))
 ap = argparse.ArgumentParser(); ap.add_argument('--reads', type=int, default=4_000_000); ap.add_argument('--len', type=int, default=150)
 ap.add_argument('--genome', type=int, default=200_000_000)
 ap.add_argument('--sorted', action='store_true', help='reads in coordinate order (a sorted BAM) instead of random order')
+ap.add_argument('--separate', action='store_true', help='reference and site mask as two arrays (default: mask in bit 7 of the reference bytes)')
 ap.add_argument('--ins', type=float, default=0.2, help='fraction of reads with a 2-base insertion (3 CIGAR operations)')
 ap.add_argument('--flip', type=float, default=0.5, help='fraction of reverse-strand reads')
 a = ap.parse_args()
@@ -42,9 +43,11 @@ err = torch.zeros((n, pitch), dtype=torch.uint8, device='cuda'); skip = torch.ze
 qual = torch.randint(2, 42, (n, pitch), dtype=torch.uint8, device='cuda')
 counts = torch.zeros(512, dtype=torch.int64, device='cuda')
 ctx = dev.context(); lib = N.load()
+fused = genome | (mask << 7)
+gptr, mptr = (N.ptr(genome), N.ptr(mask)) if a.separate else (N.ptr(fused), None)
 def k4():
     N.check(lib.kbbq_find_errors_dev(ctx.handle, N.ptr(seq), N.ptr(lens), n, pitch, N.ptr(start), N.ptr(ref_len),
-                                     N.ptr(cig_off), N.ptr(cig_n), N.ptr(cigar), N.ptr(genome), N.ptr(mask), G, N.ptr(flip),
+                                     N.ptr(cig_off), N.ptr(cig_n), N.ptr(cigar), gptr, mptr, G, N.ptr(flip),
                                      N.ptr(err), N.ptr(skip)))
 def k5():
     N.check(lib.kbbq_count_q_dev(ctx.handle, N.ptr(qual), N.ptr(err), N.ptr(skip), N.ptr(lens), n, pitch, 0, N.ptr(counts)))
@@ -62,7 +65,7 @@ batch = dev.ReadBatch(n, pitch, with_corrected=True)
 tables = dev.Tables(1, 2 * L)
 def k4n():
     N.check(lib.kbbq_find_errors_dev(ctx.handle, N.ptr(seq), N.ptr(lens), n, pitch, N.ptr(start), N.ptr(ref_len),
-                                     N.ptr(cig_off), N.ptr(cig_n), N.ptr(cigar), N.ptr(genome), N.ptr(mask), G, N.ptr(noflip),
+                                     N.ptr(cig_off), N.ptr(cig_n), N.ptr(cigar), gptr, mptr, G, N.ptr(noflip),
                                      N.ptr(err), N.ptr(skip)))
 def k6():
     N.check(lib.kbbq_canonical_reads_dev(ctx.handle, N.ptr(seq), N.ptr(oq), N.ptr(err), N.ptr(skip), N.ptr(lens),

@@ -190,3 +190,29 @@ def test_bam_input_prints_the_reference_tables(bm, OB, name, tmp_path, capfd):
     got = bqsr.bam_to_bqsr_covariates(aln.AlignmentFile(bbam), bpaths['fa'], bm.get_var_sites(bpaths['vcf']))
     for k, g in zip(VEC, got):
         assert np.array_equal(g, bgold[k]), k
+
+
+def test_separate_mask_array_gives_the_same_flags(bm, OB, tmp_path, monkeypatch):
+    """kbbq_find_errors_dev with the site mask as its own array (the C ABI's general form; the Python layer normally
+    fuses it into bit 7 of the reference bytes): same flags, same counts."""
+    import _shim
+    from kbbq import aln
+    paths = OB.synth_truthset(str(tmp_path), seed=77, npairs=600)
+    ref, var = bm.get_ref_dict(paths['fa']), bm.get_var_sites(paths['vcf'])
+    with open(paths['bed']) as fh:
+        full = bm.get_full_skips(ref, var, fh)
+    fused = bm.get_error_dict(aln.AlignmentFile(paths['sam']), ref, full)
+    want = OB.get_error_dict(list(_shim.AlignmentFile(paths['sam'])), OB.get_ref_dict(paths['fa']), full)
+    monkeypatch.setenv('KBBQ_REFERENCE_MASK', 'separate')
+    g = bm._Genome(ref, full)
+    assert g.mask is not None
+    separate = bm.get_error_dict(aln.AlignmentFile(paths['sam']), ref, full)
+    assert list(separate) == list(fused) == list(want)
+    for k in want:
+        for got in (separate[k], fused[k]):
+            assert np.array_equal(got[0], want[k][0]) and np.array_equal(got[1], want[k][1]), k
+    a, t = bm.benchmark_bam(aln.AlignmentFile(paths['sam']), ref, var, bedfh=open(paths['bed']))
+    monkeypatch.delenv('KBBQ_REFERENCE_MASK')
+    assert bm._Genome(ref, full).mask is None
+    a2, t2 = bm.benchmark_bam(aln.AlignmentFile(paths['sam']), ref, var, bedfh=open(paths['bed']))
+    assert np.array_equal(a, a2) and np.array_equal(t, t2)
