@@ -36,7 +36,7 @@ def model_consts():
     return np.ascontiguousarray(np.concatenate([prior, logp, log1mp]))
 
 
-COMBILN_THREADS = 8
+COMBILN_THREADS = None          # None: one thread per ~1700 cells, at most 16 (8 for a one-read-group model); an int fixes it
 
 
 def combiln_scipy(numerrs, numtotal):
@@ -61,7 +61,8 @@ def combiln(numerrs, numtotal):
     t = np.ascontiguousarray(np.asarray(numtotal), dtype=np.int64)
     assert e.shape == t.shape
     out = np.empty(e.shape, dtype=np.float64)
-    N.check(N.load().kbbq_combiln_host(N.ptr(e), N.ptr(t), e.size, N.ptr(out), COMBILN_THREADS))
+    threads = COMBILN_THREADS if COMBILN_THREADS else max(1, min(16, e.size // 1700))
+    N.check(N.load().kbbq_combiln_host(N.ptr(e), N.ptr(t), e.size, N.ptr(out), threads))
     return out
 
 
