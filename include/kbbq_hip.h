@@ -334,6 +334,13 @@ int kbbq_sam_text(const kbbq_sam* f, int what, int64_t i, const char** p, int64_
 typedef struct kbbq_fastq kbbq_fastq;
 int         kbbq_fastq_open(const char* path, kbbq_fastq** out);
 int         kbbq_fastq_close(kbbq_fastq* f);
+/* multi-GPU ingest: rank 0 opens and scans the whole file, the other ranks index only their shard's byte range
+ * [byte_lo, byte_hi) (record starts from kbbq_fastq_record_offset; byte_hi < 0: to the end; uncompressed files only,
+ * kbbq_fastq_is_plain) and take the file-wide read-group names from rank 0 (count NUL-terminated strings). */
+int         kbbq_fastq_open_range(const char* path, int64_t byte_lo, int64_t byte_hi, kbbq_fastq** out);
+int64_t     kbbq_fastq_record_offset(const kbbq_fastq* f, int64_t i);
+int         kbbq_fastq_is_plain(const kbbq_fastq* f);
+int         kbbq_fastq_set_rg_names(kbbq_fastq* f, const char* names, int count);
 int64_t     kbbq_fastq_count(const kbbq_fastq* f);
 int         kbbq_fastq_name(const kbbq_fastq* f, int64_t i, const char** name, int* len);
 int         kbbq_fastq_rg_count(const kbbq_fastq* f);

@@ -46,6 +46,7 @@ template <typename T> using raw_vector = std::vector<T, raw_alloc<T>>;
 
 struct kbbq_fastq {
     const uint8_t* buf = nullptr; size_t size = 0; bool mapped = false;
+    size_t range_end = 0;                  // end of the indexed byte range (the file size for a whole-file reader)
     raw_vector<uint64_t> h0, s0, q0;       // start offsets of header / sequence / quality lines
     raw_vector<uint32_t> hlen, slen;       // header line length (without '@', up to whitespace = name), sequence length
     std::vector<std::string> rg_names;     // first-appearance order (filled by scan / fill with infer_rg)
@@ -68,7 +69,8 @@ template <typename F> static void parallel_for(int64_t n, unsigned nt, F f)
 
 extern "C" {
 
-int kbbq_fastq_open(const char* path, kbbq_fastq** out)
+// byte range [range_lo, range_hi) of the file (range_hi < 0: to the end): only the records inside it are indexed
+static int open_impl(const char* path, int64_t range_lo, int64_t range_hi, kbbq_fastq** out)
 {
     if (!path || !out) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_open: NULL argument");
     *out = nullptr;
@@ -106,17 +108,24 @@ int kbbq_fastq_open(const char* path, kbbq_fastq** out)
         }
         close(fd);
     }
+    const bool whole = range_lo == 0 && range_hi < 0;
+    if (!whole && !f->mapped && f->size) { delete f; return kbbq_set_error_(KBBQ_E_ARG, "a byte range of a compressed FASTQ file cannot be opened"); }
+    const size_t r0 = (size_t)std::min<int64_t>(std::max<int64_t>(range_lo, 0), (int64_t)f->size);
+    const size_t r1 = range_hi < 0 ? f->size : (size_t)std::min<int64_t>(std::max<int64_t>(range_hi, (int64_t)r0), (int64_t)f->size);
+    if ((r0 > 0 && f->buf[r0 - 1] != '\n') || (r1 < f->size && r1 > r0 && f->buf[r1 - 1] != '\n')) {
+        delete f; return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": the byte range does not start / end at a line end").c_str());
+    }
     // Line index, in parallel and without a merged list of line ends: (1) every thread collects the '\n' offsets of
     // its byte range; (2) a prefix sum of the counts numbers the lines; (3) every thread turns ITS line ends into
     // record fields -- line g is field g % 4 of record g / 4, and starts after the previous line end, which is the
     // previous entry of the same list or the last entry of an earlier thread's.
-    const unsigned nt = nthreads_for(f->size);
+    const unsigned nt = nthreads_for(r1 - r0);
     std::vector<raw_vector<uint64_t>> parts(nt);
-    const size_t per = (f->size + nt - 1) / nt;
+    const size_t per = (r1 - r0 + nt - 1) / nt;
     {
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; ++t) {
-            const size_t lo = std::min(f->size, t * per), hi = std::min(f->size, lo + per);
+            const size_t lo = std::min(r1, r0 + t * per), hi = std::min(r1, lo + per);
             th.emplace_back([f, lo, hi, &parts, t]() {
                 auto& v = parts[t];
                 v.reserve((hi - lo) / 64 + 16);
@@ -131,10 +140,10 @@ int kbbq_fastq_open(const char* path, kbbq_fastq** out)
         }
         for (auto& t : th) t.join();
     }
-    if (f->size && f->buf[f->size - 1] != '\n') parts[nt - 1].push_back(f->size);   // last line without '\n'
+    if (r1 == f->size && r1 > r0 && f->buf[f->size - 1] != '\n') parts[nt - 1].push_back(f->size);   // last line without '\n'
     std::vector<uint64_t> base(nt + 1, 0), before(nt, 0);      // first line number of a part; line end before its first
     {
-        uint64_t last_end = (uint64_t)-1;                       // "line end" before offset 0
+        uint64_t last_end = (uint64_t)r0 - 1;                   // "line end" before the range (before offset 0: -1)
         for (unsigned t = 0; t < nt; ++t) {
             base[t + 1] = base[t] + parts[t].size();
             before[t] = last_end;
@@ -144,6 +153,7 @@ int kbbq_fastq_open(const char* path, kbbq_fastq** out)
     const uint64_t nlines = base[nt];
     if (nlines % 4 != 0) { delete f; return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": not a 4-line-per-record FASTQ file").c_str()); }
     const int64_t n = (int64_t)(nlines / 4);
+    f->range_end = r1;
     f->h0.resize(n); f->s0.resize(n); f->q0.resize(n); f->hlen.resize(n); f->slen.resize(n);
     raw_vector<uint32_t> qlen((size_t)n);
     std::atomic<int> bad(0);
@@ -190,6 +200,37 @@ int kbbq_fastq_open(const char* path, kbbq_fastq** out)
                                           : b == 2 ? "sequence and quality lengths differ" : "read longer than 65535 bases");
     }
     *out = f;
+    return KBBQ_OK;
+}
+
+int kbbq_fastq_open(const char* path, kbbq_fastq** out) { return open_impl(path, 0, -1, out); }
+
+// Only the records inside the byte range [byte_lo, byte_hi) of an uncompressed file (both must be record starts, as
+// kbbq_fastq_record_offset gives them; byte_hi < 0: to the end): what one rank of a multi-GPU run needs once rank 0
+// has indexed the whole file.  Record i of this reader is record first + i of the file, `first` being the caller's.
+int kbbq_fastq_open_range(const char* path, int64_t byte_lo, int64_t byte_hi, kbbq_fastq** out)
+{
+    if (byte_lo < 0) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_open_range: negative offset");
+    return open_impl(path, byte_lo, byte_hi, out);
+}
+
+// byte offset of record i's '@' (i == number of records: the end of the indexed range)
+int64_t kbbq_fastq_record_offset(const kbbq_fastq* f, int64_t i)
+{
+    if (!f || i < 0 || i > (int64_t)f->h0.size()) { kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_record_offset: bad index"); return -1; }
+    if (i < (int64_t)f->h0.size()) return (int64_t)f->h0[i] - 1;
+    return f->h0.empty() ? 0 : (int64_t)f->range_end;
+}
+
+int kbbq_fastq_is_plain(const kbbq_fastq* f) { return f && (f->mapped || f->size == 0) ? 1 : 0; }
+
+// install the read-group names (first-appearance order of the WHOLE file, from the rank that scanned it) that
+// kbbq_fastq_fill_range maps names to: `names` holds `count` NUL-terminated strings back to back
+int kbbq_fastq_set_rg_names(kbbq_fastq* f, const char* names, int count)
+{
+    if (!f || count < 0 || (count > 0 && !names)) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_set_rg_names: bad argument");
+    f->rg_names.clear();
+    for (int i = 0; i < count; ++i) { f->rg_names.emplace_back(names); names += f->rg_names.back().size() + 1; }
     return KBBQ_OK;
 }
 

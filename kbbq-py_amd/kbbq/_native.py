@@ -87,6 +87,10 @@ PROTOTYPES = {
     'kbbq_canonical_reads_dev': (_i, [_vp] * 9 + [_i64, _i, _i, _i, _i] + [_vp] * 4),
     'kbbq_fastq_open': (_i, [_c.c_char_p, _c.POINTER(_vp)]),
     'kbbq_fastq_close': (_i, [_vp]),
+    'kbbq_fastq_open_range': (_i, [_c.c_char_p, _i64, _i64, _c.POINTER(_vp)]),
+    'kbbq_fastq_record_offset': (_i64, [_vp, _i64]),
+    'kbbq_fastq_is_plain': (_i, [_vp]),
+    'kbbq_fastq_set_rg_names': (_i, [_vp, _c.c_char_p, _i]),
     'kbbq_fastq_count': (_i64, [_vp]),
     'kbbq_fastq_name': (_i, [_vp, _i64, _c.POINTER(_vp), _c.POINTER(_i)]),
     'kbbq_fastq_rg_count': (_i, [_vp]),

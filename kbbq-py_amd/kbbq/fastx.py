@@ -251,6 +251,31 @@ class NativeFastq:
         if _handle is None:
             _N.check(_N.load().kbbq_fastq_open(str(path).encode(), _ct.byref(self._h)))
         self.n = int(_N.load().kbbq_fastq_count(self._h))
+        # a reader of one byte range of the file (open_range) holds records [first, first + n) of `total`; every method
+        # below takes FILE-WIDE record numbers
+        self.first, self.total = 0, self.n
+
+    @classmethod
+    def open_range(cls, path, byte_lo, byte_hi, first, total, rg_names=()):
+        """Only the records in the byte range [byte_lo, byte_hi) of an uncompressed file -- records first, first + 1,
+        ... of its `total` -- with the file-wide read-group names of the rank that scanned all of it."""
+        h = _ct.c_void_p()
+        _N.check(_N.load().kbbq_fastq_open_range(str(path).encode(), int(byte_lo), int(byte_hi), _ct.byref(h)))
+        f = cls(None, _handle=h)
+        f.first, f.total = int(first), int(total)
+        blob = b''.join(str(x).encode('ascii') + b'\0' for x in rg_names)
+        _N.check(_N.load().kbbq_fastq_set_rg_names(h, blob, len(rg_names)))
+        return f
+
+    def record_offset(self, i):
+        """Byte offset of record i's '@' (i = first + n: the end of the indexed range)."""
+        off = int(_N.load().kbbq_fastq_record_offset(self._h, i - self.first))
+        if off < 0:
+            _N.check(_N.KBBQ_E_ARG)
+        return off
+
+    def is_plain(self):
+        return bool(_N.load().kbbq_fastq_is_plain(self._h))
 
     def close(self):
         if getattr(self, '_h', None):
@@ -265,11 +290,11 @@ class NativeFastq:
 
     def name(self, i):
         p, ln = _ct.c_void_p(), _ct.c_int(0)
-        _N.check(_N.load().kbbq_fastq_name(self._h, i, _ct.byref(p), _ct.byref(ln)))
+        _N.check(_N.load().kbbq_fastq_name(self._h, i - self.first, _ct.byref(p), _ct.byref(ln)))
         return _ct.string_at(p, ln.value).decode('ascii')
 
     def names(self):
-        return [self.name(i) for i in range(self.n)]
+        return [self.name(self.first + i) for i in range(self.n)]
 
     def rg_names(self):
         lib = _N.load()
@@ -281,18 +306,20 @@ class NativeFastq:
                                            1 if infer_rg_flag else 0, _N.ptr(info)))
         return [int(x) for x in info]
 
-    def lengths(self, first=0, n=None):
-        n = self.n - first if n is None else n
+    def lengths(self, first=None, n=None):
+        first = self.first if first is None else first
+        n = self.first + self.n - first if n is None else n
         out = np.zeros(max(n, 1), dtype=np.uint32)
-        _N.check(_N.load().kbbq_fastq_lengths(self._h, first, n, _N.ptr(out)))
+        _N.check(_N.load().kbbq_fastq_lengths(self._h, first - self.first, n, _N.ptr(out)))
         return out[:n]
 
-    def length_bands(self, first=0, n=None, max_bands=16):
-        """length_bands (below) of reads [first, first + n), computed by the reader."""
-        n = self.n - first if n is None else n
+    def length_bands(self, first=None, n=None, max_bands=16):
+        """length_bands (below) of reads [first, first + n), computed by the reader (lo / hi relative to first)."""
+        first = self.first if first is None else first
+        n = self.first + self.n - first if n is None else n
         classes = np.asarray(BAND_CLASSES, dtype=np.uint32)
         out = np.zeros((max_bands, 4), dtype=np.int64)
-        runs = _N.load().kbbq_fastq_length_runs(self._h, first, n, _N.ptr(classes), len(classes), max_bands, _N.ptr(out))
+        runs = _N.load().kbbq_fastq_length_runs(self._h, first - self.first, n, _N.ptr(classes), len(classes), max_bands, _N.ptr(out))
         if runs < 0:
             _N.check(runs)
         return [tuple(int(x) for x in row) for row in out[:runs]]
@@ -312,8 +339,10 @@ class NativeFastq:
         for a, shape in ((seq, (n, pitch)), (qual, (n, pitch)), (cseq, (n, pitch)), (meta, (n,))):
             if a is not None and (tuple(a.shape) != shape or not a.flags['C_CONTIGUOUS']):
                 raise ValueError('fill_into: array of shape %s, expected C-contiguous %s' % (a.shape, shape))
+        if other is not None and other.first != self.first:
+            raise ValueError('the two readers of a pair must start at the same record')
         _N.check(_N.load().kbbq_fastq_fill_range(self._h, other._h if other is not None else None,
-                                                 1 if infer_rg_flag else 0, first, n, pitch, _N.ptr(seq),
+                                                 1 if infer_rg_flag else 0, first - self.first, n, pitch, _N.ptr(seq),
                                                  _N.ptr(cseq), _N.ptr(qual), _N.ptr(meta)))
 
     def format_array(self, first, n, newqual, out=None):
@@ -323,9 +352,10 @@ class NativeFastq:
         newqual = np.ascontiguousarray(newqual)
         pitch = newqual.shape[1]
         lib = _N.load()
-        need = int(-lib.kbbq_fastq_format(self._h, first, n, pitch, _N.ptr(newqual), None, 0))
+        local = first - self.first
+        need = int(-lib.kbbq_fastq_format(self._h, local, n, pitch, _N.ptr(newqual), None, 0))
         buf = np.empty(max(need, 1), dtype=np.uint8) if out is None else out(max(need, 1))
-        got = lib.kbbq_fastq_format(self._h, first, n, pitch, _N.ptr(newqual), _N.ptr(buf), need)
+        got = lib.kbbq_fastq_format(self._h, local, n, pitch, _N.ptr(newqual), _N.ptr(buf), need)
         assert got == need
         return buf[:need]
 
@@ -437,17 +467,65 @@ class PairScan:
             pass
 
 
-def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None, to_device=False):
+def _shard_plan(A, B, scanned, world):
+    """What rank 0 tells the others after it has indexed and scanned the pair: the scan's result, the file-wide
+    read-group names and, per rank, its records [lo, hi) with the byte ranges that hold them in either file."""
+    total, S, R, kind, idx = scanned
+    ranges = []
+    for r in range(world):
+        lo, hi = _shard(total, (r, world))
+        ranges.append((lo, hi, A.record_offset(lo), A.record_offset(hi), B.record_offset(lo), B.record_offset(hi)))
+    return dict(scanned=[total, S, R, kind, idx], rgs=A.rg_names(), n_text=A.total, ranges=ranges,
+                plain=A.is_plain() and B.is_plain())
+
+
+def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None, to_device=False, exchange=None):
     """Pass-1 input (recalibrate.py:56-57) through the C++ packer; same dictionary as pack_pair_py
     except that `text` is the NativeFastq of file A and `names` is filled lazily by callers.
-    shard = (rank, world): every rank scans the whole pair (so read-group ids, the longest read and
-    the first host-detectable error are global) and packs only its own records [first, first + n);
-    `total` is the global number of usable reads.  bands=True: instead of one set of planes at the widest pitch,
-    `bands` holds the reads packed by length band (length_bands), each at its own pitch.  scan: a PairScan of the
-    same arguments started earlier.  to_device (with bands): the bands are filled straight onto the device (_fill_bands)."""
+    shard = (rank, world): the rank packs only its own records [first, first + n); `total` is the global number of
+    usable reads.  Read-group ids, the longest read and the first host-detectable error are file-wide facts:
+    without `exchange` every rank opens and scans the whole pair itself; with it (a function that returns rank 0's
+    object on every rank: parallel.broadcast_object) only rank 0 does, and the others index just the byte ranges of
+    their shard (uncompressed files; compressed ones fall back to everybody reading everything).
+    bands=True: instead of one set of planes at the widest pitch, `bands` holds the reads packed by length band
+    (length_bands), each at its own pitch.  scan: a PairScan of the same arguments started earlier.  to_device (with
+    bands): the bands are filled straight onto the device (_fill_bands)."""
     from ._trace import stage
-    with stage('open+index+scan (wait)'):
-        A, B, (total, S, R, kind, idx) = (scan or PairScan(path_a, path_b, infer_rg_flag)).result()
+    rank, world = shard if shard is not None else (0, 1)
+    planned = exchange is not None and world > 1
+    A = B = scanned = None
+    failure = None
+    if not planned or rank == 0:
+        try:
+            with stage('open+index+scan (wait)'):
+                A, B, scanned = (scan or PairScan(path_a, path_b, infer_rg_flag)).result()
+        except Exception as e:               # noqa: BLE001 -- with a plan to hand out, the other ranks must hear of it
+            if not planned:
+                raise
+            failure = e
+    if planned:
+        if rank == 0:
+            plan = exchange(dict(error=(type(failure).__name__, str(failure))) if failure else _shard_plan(A, B, scanned, world))
+        else:
+            plan = exchange(None)
+        if failure is not None:
+            raise failure
+        if 'error' in plan:                                      # rank 0 could not read the files: everybody stops
+            import builtins
+            raise getattr(builtins, plan['error'][0], RuntimeError)(plan['error'][1])
+        if rank != 0 and plan['plain']:
+            scanned = plan['scanned']
+            lo, hi, a_lo, a_hi, b_lo, b_hi = plan['ranges'][rank]
+            with stage('open+index (shard)'):
+                A = NativeFastq.open_range(path_a, a_lo, a_hi, lo, plan['n_text'], plan['rgs'])
+                B = NativeFastq.open_range(path_b, b_lo, b_hi, lo, plan['n_text'], plan['rgs'])
+            if (A.n, B.n) != (hi - lo, hi - lo):
+                raise ValueError('the shard of rank %d holds %d / %d records, %d expected: the files changed while '
+                                 'being read' % (rank, A.n, B.n, hi - lo))
+        elif rank != 0:                                          # compressed input: every rank reads all of it
+            with stage('open+index+scan (wait)'):
+                A, B, scanned = PairScan(path_a, path_b, infer_rg_flag).result()
+    total, S, R, kind, idx = scanned
     pending = (idx, _SCAN_ERRORS[kind](idx), kind == 5) if kind else None
     pitch = pitch_for(S)
     lo, hi = _shard(total, shard)

@@ -55,6 +55,16 @@ def merge_rg_maps(local_names):
     return list(order), np.array([order[nm] for nm in local_names], dtype=np.int64)
 
 
+def broadcast_object(obj, src=0):
+    """`obj` of rank `src` on every rank (any picklable Python object); without a process group: obj itself."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return obj
+    box = [obj if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
 def world_rank():
     """(world size, rank) of the initialised process group, (1, 0) without one."""
     dist = _dist()

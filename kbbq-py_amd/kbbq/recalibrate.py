@@ -122,10 +122,12 @@ def _warm_up():
 
 def _pack_and_tally(fastq, infer_rg, minscore, maxscore):
     world, rank = parallel.world_rank()
-    scan = fastx.PairScan(fastq[0], fastq[1], infer_rg)       # the reader's own threads: no interpreter lock needed
+    # rank 0 (or the only process) opens and scans the pair on the reader's own threads -- no interpreter lock needed --
+    # while the device warms up; the other ranks then index only the byte ranges of their shards (fastx.pack_pair)
+    scan = fastx.PairScan(fastq[0], fastq[1], infer_rg) if rank == 0 else None
     _warm_up()
     packed = fastx.pack_pair(fastq[0], fastq[1], infer_rg, shard=(rank, world) if world > 1 else None, bands=True,
-                             scan=scan, to_device=True)
+                             scan=scan, to_device=True, exchange=parallel.broadcast_object if world > 1 else None)
     err = packed.get('pending_error')
     if err is not None:
         # the reference fails at the FIRST offending read: let the kernel look at the reads
@@ -210,7 +212,7 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
     else:
         packed, tables = _pack_and_tally(fastq, infer_rg, 6, 42)
         text = packed['text']
-        if text.n == 0:
+        if text.total == 0:
             return
         if tables is None:
             raise IndexError('index 0 is out of bounds for axis 0 with size 0')   # no read was tallied
@@ -221,7 +223,7 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
     with stage('solve', sync=True):
         lut, shape, _, _ = dev.solve(tables)
     R = shape[0]
-    if packed is not None and packed['total'] == text.n:
+    if packed is not None and packed['total'] == text.total:
         # pass 2 walks the same reads with the same first-appearance read groups (:141-148):
         # the planes of pass 1 are still on the device
         single = packed
@@ -229,6 +231,8 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
         # file B was shorter (zip truncation), or the model came from a report: pass 2 covers
         # all of file A with its own first-appearance read groups
         if single is None:
+            if text.n != text.total:
+                text = fastx.NativeFastq(fastq[0])                 # a shard's reader: pass 2 needs all of file A
             single = fastx.pack_single(text, infer_rg, shard, bands=True, to_device=True)
         for band in single['bands']:
             band['laid'] = _lay_out(band['batch'], R, band['S'])

@@ -3,6 +3,8 @@ GPU tests (-m gpu) of the mate-pair row layout (include/kbbq_hip.h "mate-pair ro
 rows that hold a read pair each.  Everything must equal the one-read-per-row path, which the other GPU tests
 pin to the oracle and the reference's goldens; the oracle is consulted directly as well.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -422,3 +424,23 @@ def test_planes_streamed_from_the_reader_equal_the_host_packed_ones(dev, oracle,
                 assert np.array_equal(g[:m].cpu().numpy(), w), (first, m, slab)
     assert not [k for k in dev._pinned if k[0] == 'ingest']          # released for the next user
     assert any(k[0] == '' for k in dev._pinned)
+
+
+def test_two_ranks_when_pass_2_covers_more_than_pass_1(dev, oracle, tmp_path):
+    """File B shorter than file A (the reference's zip() truncation: pass 1 stops, pass 2 prints all of A) and the
+    -g model file (saved by one run, loaded by the next, file B not read): 2 ranks print what 1 rank prints.  Pass 1's
+    shard readers hold only their byte ranges, so pass 2 has to open file A again."""
+    from conftest import load_golden
+    from test_gpu_parity import _files
+    info, _ = load_golden('c1_10k_1rg')
+    fa, fb = _files(oracle, info, tmp_path)
+    lines = open(fb).read().split('\n')
+    short = str(tmp_path / 'b_short.fq')
+    open(short, 'w').write('\n'.join(lines[:4 * 3001]) + '\n')
+    model = str(tmp_path / 'model.txt')
+    for argv in (['recalibrate', '-f', fa, short], ['recalibrate', '-f', fa, fb, '-g', model], ['recalibrate', '-f', fa, fb, '-g', model]):
+        one = _run_ranks(1, argv)
+        two = _run_ranks(2, argv)
+        assert one.returncode == 0 and two.returncode == 0, (one.stderr.decode()[-1500:], two.stderr.decode()[-1500:])
+        assert len(one.stdout) > 1000 and two.stdout == one.stdout, argv
+    assert os.path.getsize(model) > 1000

@@ -554,3 +554,52 @@ def test_pair_scan_job_matches_the_step_by_step_reader(tmp_path):
     fastx.PairScan(fa, fb, True)             # never waited for: joined and freed by the wrapper's destructor
     import gc
     gc.collect()
+
+
+def test_planned_sharding_reads_each_byte_range_once(oracle, tmp_path):
+    """Multi-GPU ingest: rank 0 opens and scans the pair and hands out a plan (scan result, read-group names, byte
+    ranges); the other ranks index only their shard (NativeFastq.open_range).  Emulated here with a mailbox instead of
+    a broadcast: the shards concatenate to the whole, a shard's reader answers with file-wide record numbers, a
+    compressed pair falls back to every rank reading everything, rank 0's failure reaches the others."""
+    import gzip
+    n = 5001
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 4, 36, 151, 3)
+    names = oracle.synth_names(0, n, 3, with_rg=True)
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, names, cseq, qual, meta)
+    whole = fastx.pack_pair(fa, fb, True)
+    box = {}
+    ex = {0: lambda obj: box.setdefault('plan', obj)}
+    for world in (2, 3, 7):
+        box.clear()
+        parts = [fastx.pack_pair(fa, fb, True, shard=(r, world), exchange=ex.get(r, lambda obj: box['plan'])) for r in range(world)]
+        for k in ('seq', 'cseq', 'qual', 'meta'):
+            assert np.array_equal(np.concatenate([p[k] for p in parts]), whole[k]), (world, k)
+        assert all(p['rg_to_int'] == whole['rg_to_int'] and (p['S'], p['R'], p['total']) == (whole['S'], whole['R'], n) for p in parts)
+        assert [p['text'].n for p in parts] == [n] + [p['n'] for p in parts[1:]] and all(p['text'].total == n for p in parts)
+        last = parts[-1]
+        t, i = last['text'], last['first'] + 3
+        assert t.first == last['first'] and t.name(i) == whole['text'].name(i)
+        assert t.format(i, 2, last['qual'][3:5]) == whole['text'].format(i, 2, last['qual'][3:5])
+        assert t.length_bands(last['first'], last['n']) == whole['text'].length_bands(last['first'], last['n'])
+        with pytest.raises(ValueError):
+            t.name(0)                                            # not this shard's record
+    # compressed input: no byte ranges, every rank reads all of it (same planes)
+    ga, gb = str(tmp_path / 'a.fq.gz'), str(tmp_path / 'b.fq.gz')
+    for src, dst in ((fa, ga), (fb, gb)):
+        with open(src, 'rb') as i, gzip.open(dst, 'wb') as o:
+            o.write(i.read())
+    box.clear()
+    parts = [fastx.pack_pair(ga, gb, True, shard=(r, 2), exchange=ex.get(r, lambda obj: box['plan'])) for r in range(2)]
+    assert np.array_equal(np.concatenate([p['seq'] for p in parts]), whole['seq']) and parts[1]['text'].n == n
+    # a pending error is part of the plan; a file rank 0 cannot open stops every rank with the same exception
+    bad = _write(tmp_path, 'bad.fq', [('x', 'ACGT', 'IIII'), ('y', 'ACG', 'III')])
+    good = _write(tmp_path, 'good.fq', [('x', 'ACGT', 'IIII'), ('y', 'ACGT', 'IIII')])
+    box.clear()
+    parts = [fastx.pack_pair(good, bad, False, shard=(r, 2), exchange=ex.get(r, lambda obj: box['plan'])) for r in range(2)]
+    assert all(p['pending_error'][0] == 1 and isinstance(p['pending_error'][1], ValueError) for p in parts)
+    box.clear()
+    for r in range(2):
+        with pytest.raises(ValueError, match='missing'):
+            fastx.pack_pair(str(tmp_path / 'missing.fq'), good, False, shard=(r, 2), exchange=ex.get(r, lambda obj: box['plan']))

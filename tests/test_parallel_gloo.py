@@ -138,3 +138,50 @@ def test_error_agreement_and_rank_order():
         assert res[rank][0] == ('index', 'read 70')
         assert res[rank][1] == ('TypeError', 'read 5')
         assert res[rank][2] == ('world', (2, rank))
+
+
+def _pack_worker(rank, world, port, fa, fb, q):
+    import sys
+    for p in (os.path.join(ROOT, 'kbbq-py_amd'), os.path.join(ROOT, 'oracle')):
+        sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from kbbq import fastx, parallel
+        p = fastx.pack_pair(fa, fb, True, shard=(rank, world), exchange=parallel.broadcast_object)
+        t = p['text']
+        q.put((rank, p['first'], p['n'], t.n, t.first, t.total, p['S'], p['R'], list(p['rg_to_int']),
+               p['seq'].tobytes(), p['cseq'].tobytes(), p['qual'].tobytes(), p['meta'].tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_index_only_their_shard_after_rank_0_scanned(tmp_path):
+    """fastx.pack_pair with parallel.broadcast_object as the exchange, 3 gloo ranks: rank 0 scans the pair and hands
+    out the plan, ranks 1 and 2 hold readers of their shard only; the shards concatenate to the single-process pack."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import oracle as O
+    from kbbq import fastx
+    n, world = 4000, 3
+    seq, cseq, qual, meta = O.synth(0, n, n, 9, 50, 120, 4)
+    names = O.synth_names(0, n, 4, with_rg=True)
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    O.write_fastq(fa, names, seq, qual, meta)
+    O.write_fastq(fb, names, cseq, qual, meta)
+    whole = fastx.pack_pair(fa, fb, True)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pack_worker, args=(r, world, port, fa, fb, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[3] for g in got] == [n] + [g[2] for g in got[1:]]          # rank 0 indexed everything, the others their shard
+    assert all(g[4] == (0 if g[0] == 0 else g[1]) and g[5] == n for g in got)
+    assert all((g[6], g[7], g[8]) == (whole['S'], whole['R'], list(whole['rg_to_int'])) for g in got)
+    for k, name in ((9, 'seq'), (10, 'cseq'), (11, 'qual'), (12, 'meta')):
+        assert b''.join(g[k] for g in got) == whole[name].tobytes(), name
