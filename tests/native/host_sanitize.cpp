@@ -51,6 +51,22 @@ static int run_pair(const char* pa, const char* pb, int infer)
         const int64_t got = kbbq_fastq_format(a, first, m, pitch, qual.data(), out.data(), need);
         printf("range first=%lld rc=%d bytes=%lld/%lld\n", (long long)first, rc, (long long)got, (long long)need);
     }
+    if (n >= 3 && kbbq_fastq_is_plain(a) && (!b || kbbq_fastq_is_plain(b))) {
+        // a shard's byte-range readers (multi-GPU ingest): records [n / 3, 2 n / 3) through kbbq_fastq_open_range
+        const int64_t lo = n / 3, hi = 2 * n / 3, m = hi - lo;
+        kbbq_fastq *ra = nullptr, *rb = nullptr;
+        int rrc = kbbq_fastq_open_range(pa, kbbq_fastq_record_offset(a, lo), kbbq_fastq_record_offset(a, hi), &ra);
+        if (!rrc && b) rrc = kbbq_fastq_open_range(pb, kbbq_fastq_record_offset(b, lo), kbbq_fastq_record_offset(b, hi), &rb);
+        std::string names;
+        for (int i = 0; i < kbbq_fastq_rg_count(a); ++i) { names += kbbq_fastq_rg_name(a, i); names.push_back('\0'); }
+        if (!rrc) rrc = kbbq_fastq_set_rg_names(ra, names.data(), kbbq_fastq_rg_count(a));
+        if (!rrc) rrc = kbbq_fastq_fill_range(ra, rb, infer, 0, m, pitch, seq.data(), rb ? cseq.data() : nullptr, qual.data(), meta.data());
+        printf("shard rc=%d records=%lld/%lld\n", rrc, (long long)(ra ? kbbq_fastq_count(ra) : -1), (long long)m);
+        kbbq_fastq *bad = nullptr;                                   // a range that does not start at a line start
+        printf("misaligned rc=%d\n", kbbq_fastq_open_range(pa, kbbq_fastq_record_offset(a, lo) + 1, -1, &bad));
+        if (ra) kbbq_fastq_close(ra);
+        if (rb) kbbq_fastq_close(rb);
+    }
     for (int i = 0; i < kbbq_fastq_rg_count(a); ++i) printf("rg %d = %s\n", i, kbbq_fastq_rg_name(a, i));
     const char* nm; int nl;
     if (kbbq_fastq_count(a) > 0 && kbbq_fastq_name(a, kbbq_fastq_count(a) - 1, &nm, &nl) == 0) printf("last name %.*s\n", nl, nm);

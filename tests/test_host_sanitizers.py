@@ -47,6 +47,7 @@ def test_wellformed_pairs(harness, oracle, tmp_path):
     oracle.write_fastq(fb, names, cseq, qual, meta)
     out = harness('pair', fa, fb, '1')
     assert 'scan rc=0 n=%d' % n in out and 'fill rc=0' in out and out.count('rc=0 bytes=') == 2
+    assert 'shard rc=0 records=%d/%d' % (2 * n // 3 - n // 3, 2 * n // 3 - n // 3) in out and 'misaligned rc=-4' in out
     assert 'job rc=0 n=%d' % n in out and out.split('job ')[1].split('\n')[0].split(' ', 1)[1].startswith(out.split('scan ')[1].split('\n')[0].split(' ', 1)[1])
     out = harness('pair', fa, '-', '0')
     assert 'scan rc=0' in out
