@@ -16,7 +16,7 @@ import os
 
 import numpy as np
 
-from . import compare_reads as utils
+from . import compare_reads as utils        # noqa: F401  (module attribute of the reference: recalibrate.utils)
 from . import fastx
 from . import _device as dev
 from . import _solve
