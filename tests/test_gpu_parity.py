@@ -519,3 +519,26 @@ def test_full_size_properties(dev):
     torch.cuda.empty_cache()
     out_pairs = pb.unpack(dev.apply(pb, lut, shape))
     assert torch.equal(out_pairs[:n], out[:n])
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields(dev):
+    """bench.py's contract with the driver: exactly one JSON line on stdout, the metric / config of BASELINE.json, the
+    roofline and cpu_baseline objects; a small run (the default sizes are the driver's business)."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+                        '--reads', '400000', '--cpu-sample', '20000'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.split('\n') if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
+    assert d['metric'].split(' (')[0] in base['metric'] and d['unit'] == 'bases/s'
+    assert (d['n_gpus'], d['steps'], d['warmup'], d['higher_is_better'], d['scaling'], d['vs_baseline']) == (1, 2, 1, True, 'weak', None)
+    assert d['dtype'] == 'u8' and 'synthetic' in d['data'] and 'workload' in d['config'] and 'model' not in d['config']
+    assert d['value'] > 1e9 and abs(d['value'] - 400000 * 150 / (d['ms_per_step'] / 1e3)) / d['value'] < 1e-6
+    roof = d['roofline']
+    assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-9 and 0 < roof['frac'] < 1 and roof['traffic'] > 0
+    cpu = d['cpu_baseline']
+    assert cpu['kind'] in ('port', 'reference') and cpu['cores'] >= 1 and cpu['value'] > 1e6 and cpu['unit'] == 'bases/s' and cpu['sample']
