@@ -126,8 +126,13 @@ def _pack_and_tally(fastq, infer_rg, minscore, maxscore):
     # while the device warms up; the other ranks then index only the byte ranges of their shards (fastx.pack_pair)
     scan = fastx.PairScan(fastq[0], fastq[1], infer_rg) if rank == 0 else None
     _warm_up()
-    packed = fastx.pack_pair(fastq[0], fastq[1], infer_rg, shard=(rank, world) if world > 1 else None, bands=True,
-                             scan=scan, to_device=True, exchange=parallel.broadcast_object if world > 1 else None)
+    failure, packed = None, None
+    try:
+        packed = fastx.pack_pair(fastq[0], fastq[1], infer_rg, shard=(rank, world) if world > 1 else None, bands=True,
+                                 scan=scan, to_device=True, exchange=parallel.broadcast_object if world > 1 else None)
+    except Exception as e:                   # noqa: BLE001 -- one rank's failure (its shard unreadable, out of memory) stops them all
+        failure = e
+    parallel.raise_first_error(failure, 0)
     err = packed.get('pending_error')
     if err is not None:
         # the reference fails at the FIRST offending read: let the kernel look at the reads
