@@ -269,16 +269,25 @@ class AlignmentFile:
 
 
 class FastaFile:
+    """A FASTA file read whole (plain or gzip / bgzip-compressed): {name: sequence}; the name is the header line's
+    first word.  Records are cut and their line ends removed by bytes operations (a genome is tens of millions of
+    lines: a Python loop over them takes half a minute per GB)."""
+
     def __init__(self, path):
-        seqs, name = {}, None
-        with _open(path) as fh:
-            for line in fh:
-                line = line.rstrip('\r\n')
-                if line.startswith('>'):
-                    name = line[1:].split()[0]; seqs[name] = []
-                elif name is not None:
-                    seqs[name].append(line)
-        self._seqs = {k: ''.join(v) for k, v in seqs.items()}
+        with (gzip.open(path, 'rb') if str(path).endswith('.gz') else open(path, 'rb')) as fh:
+            data = fh.read()
+        self._seqs = {}
+        at = 0 if data.startswith(b'>') else data.find(b'\n>') + 1          # text before the first header is ignored
+        while 0 <= at < len(data) and data[at:at + 1] == b'>':
+            nxt = data.find(b'\n>', at)
+            end = len(data) if nxt < 0 else nxt
+            eol = data.find(b'\n', at, end)
+            head = data[at + 1:end if eol < 0 else eol]
+            body = b'' if eol < 0 else data[eol + 1:end]
+            words = head.split()
+            name = words[0].decode('latin-1') if words else ''
+            self._seqs[name] = body.replace(b'\n', b'').replace(b'\r', b'').decode('latin-1')
+            at = end + 1
         self.references = list(self._seqs)
 
     def fetch(self, reference=None):

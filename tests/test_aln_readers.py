@@ -151,3 +151,18 @@ def test_small_helpers_of_compare_reads(tmp_path):
     vcf.write_text('##fileformat=VCFv4.2\n##contig=<ID=ref,length=45>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n'
                    'ref\t10\t.\tG\tT\t30\t.\t.\nref\t20\t.\tACG\tA\t30\t.\t.\n')
     assert compare_reads.get_var_sites(str(vcf)) == benchmark.get_var_sites(str(vcf)) == {'ref': [9, 19, 20, 21]}
+
+
+def test_fasta_reader_layouts(tmp_path):
+    """aln.FastaFile on odd but legal layouts: text before the first header, '>' inside a header's description,
+    blank lines, CRLF, an empty record, no trailing newline; plain and gzip-compressed."""
+    import gzip
+    cases = (('junk before\n>c1 some >desc\nACGT\nAC\n\n>c2\r\nGG\r\nTT\r\n>empty\n>c3\nA', {'c1': 'ACGTAC', 'c2': 'GGTT', 'empty': '', 'c3': 'A'}),
+             ('>only', {'only': ''}), ('', {}), ('no header\nACGT\n', {}), ('>a b\n>c\nT\n', {'a': '', 'c': 'T'}))
+    for k, (text, want) in enumerate(cases):
+        p = tmp_path / ('f%d.fa' % k); p.write_text(text)
+        f = aln.FastaFile(str(p))
+        assert f.references == list(want) and {r: f.fetch(r) for r in f.references} == want
+        with gzip.open(str(p) + '.gz', 'wt') as fh:
+            fh.write(text)
+        assert aln.FastaFile(str(p) + '.gz')._seqs == want
