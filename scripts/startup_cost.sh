@@ -12,7 +12,7 @@ t python -c "import kbbq.main"
 t python -c "import torch; torch.cuda.init(); torch.zeros(1, device='cuda')"
 t python -c "from kbbq import _device as d; d.context()"
 t python -c "import torch, time; from kbbq import _device as d; d.context(); import os; os._exit(0)"
-python scripts/e2e_cli.py --reads 8000000 --reps 1 --keep 2>&1 | grep -v amdgpu.ids
+python tests/tools/e2e_cli.py --reads 8000000 --reps 1 --keep 2>&1 | grep -v amdgpu.ids
 KBBQ_TIMING=1 python - <<'PY' 2>&1 | grep -v amdgpu.ids
 import time, sys, os
 t0 = time.perf_counter()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """kbbq recalibrate -f A B > out, as a user runs it, on a synthetic pair: wall time by stage (KBBQ_TIMING=1)."""
 import argparse, os, subprocess, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 ap = argparse.ArgumentParser(); ap.add_argument('--reads', type=int, default=4_000_000); ap.add_argument('--dir', default='/tmp')
 ap.add_argument('--reps', type=int, default=2); ap.add_argument('--keep', action='store_true')

@@ -2,7 +2,7 @@
 """End-to-end file timing of kbbq.recalibrate.recalibrate_fastq (FASTQ text in -> FASTQ text out),
 stage by stage.  Synthetic pair written with the oracle's generator (test infrastructure)."""
 import argparse, contextlib, io, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'kbbq-py_amd')); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 ap = argparse.ArgumentParser(); ap.add_argument('--reads', type=int, default=2_000_000); ap.add_argument('--dir', default='/tmp')
 a = ap.parse_args()

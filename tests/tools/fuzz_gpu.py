@@ -3,7 +3,7 @@
 bands with and without the shortest-read promise) against the CPU oracle, for --seconds of random shapes.  Prints one
 line per 50 cases and every mismatch; exit code 1 if there was one.  Test infrastructure (uses oracle/)."""
 import argparse, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'kbbq-py_amd')); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 ap = argparse.ArgumentParser(); ap.add_argument('--seconds', type=float, default=300); ap.add_argument('--seed', type=int, default=1)
 a = ap.parse_args()

@@ -3,7 +3,7 @@
 sets: truth-set benchmark (K4 flags, K5 counts; SAM text and a BAM image of it) and the BAM-sourced tally (K4 -> K6 ->
 K1).  Exit code 1 on any mismatch.  Test infrastructure (uses oracle/ and tests/bamwriter.py)."""
 import argparse, os, shutil, sys, tempfile, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for d in ('kbbq-py_amd', 'oracle', 'tests'):
     sys.path.insert(0, os.path.join(ROOT, d))
 ap = argparse.ArgumentParser(); ap.add_argument('--seconds', type=float, default=300); ap.add_argument('--seed', type=int, default=1)

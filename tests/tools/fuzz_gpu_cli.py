@@ -4,7 +4,7 @@ groups with and without --infer-rg, corrected file sometimes shorter, sometimes 
 kbbq.recalibrate.recalibrate_fastq (C++ reader, slab-wise fill, K1 / K3 / K2 in whatever layouts the path picks, output
 pipeline) against the CPU oracle's text.  Exit code 1 on any difference.  Test infrastructure (uses oracle/)."""
 import argparse, gzip, os, shutil, sys, tempfile, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'kbbq-py_amd')); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 ap = argparse.ArgumentParser(); ap.add_argument('--seconds', type=float, default=300); ap.add_argument('--seed', type=int, default=1)
 a = ap.parse_args()

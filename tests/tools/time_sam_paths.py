@@ -2,7 +2,7 @@
 """End-to-end timing of the SAM-fed paths (truth-set benchmark, BAM-sourced tally) on a synthetic alignment file:
 native SAM reader -> arrays -> K4 (-> K5 | K6 -> K1).  The generator is test infrastructure (oracle/)."""
 import argparse, os, sys, tempfile, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'kbbq-py_amd')); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 ap = argparse.ArgumentParser(); ap.add_argument('--pairs', type=int, default=50000); ap.add_argument('--len', type=int, default=150)
 a = ap.parse_args()
