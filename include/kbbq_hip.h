@@ -294,11 +294,12 @@ int    kbbq_apply_grouped_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t
                               int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
                               const void* d_lut_blob, const void* d_pair_lut, const int64_t* d_seg, uint8_t* d_out);
 
-/* ---- host SAM text reader (no GPU) -----------------------------------------------------------
+/* ---- host SAM / BAM reader (no GPU) ----------------------------------------------------------
  * Replaces, for the truth-set benchmark and the BAM-sourced tally, what the reference gets from
  * pysam.AlignmentFile / AlignedSegment (benchmark.py:57-74,102-143; gatk/bqsr.py:23-123): per alignment
  * the flag, contig, position, CIGAR, mate position, template length, sequence, qualities and the RG / OQ
- * tags, as arrays (the kernels take whole batches).  SAM text only; mapped, indexed and parsed in parallel.
+ * tags, as arrays (the kernels take whole batches).  SAM text, gzip-compressed SAM or BAM (the reference's own input);
+ * mapped, inflated where needed, indexed and parsed in parallel.
  * kbbq_sam_info: { alignments, CIGAR operations, longest SEQ, contigs seen, @RG lines, header lines }.
  * kbbq_sam_fields (any pointer may be NULL): flag; contig = index into the first-appearance list of RNAME;
  * pos / pnext 0-based; tlen; qlen = len(SEQ) (0 for '*'); ref_span = reference_end - reference_start;
