@@ -13,6 +13,7 @@
 // it (and at it, for kind 5) before raising.
 #include "../../include/kbbq_hip.h"
 #include "host_threads.h"
+#include "bam_host.h"
 
 #include <algorithm>
 #include <atomic>
@@ -50,7 +51,8 @@ struct kbbq_fastq {
     raw_vector<uint64_t> h0, s0, q0;       // start offsets of header / sequence / quality lines
     raw_vector<uint32_t> hlen, slen;       // header line length (without '@', up to whitespace = name), sequence length
     std::vector<std::string> rg_names;     // first-appearance order (filled by scan / fill with infer_rg)
-    ~kbbq_fastq() { if (mapped && buf) munmap((void*)buf, size); else free((void*)buf); }
+    std::vector<uint8_t> owned;            // the inflated text of a compressed file
+    ~kbbq_fastq() { if (mapped && buf) munmap((void*)buf, size); }
 };
 
 static unsigned nthreads_for(size_t work) { return kbbq_threads_for(work); }
@@ -83,22 +85,16 @@ static int open_impl(const char* path, int64_t range_lo, int64_t range_hi, kbbq_
     unsigned char magic[2] = {0, 0};
     const bool gz = f->size >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
     if (gz) {
-        // gzip / bgzip (what pysam.FastxFile reads transparently): inflate all members into memory
-        gzFile g = gzdopen(fd, "rb");
-        if (!g) { close(fd); delete f; return kbbq_set_error_(KBBQ_E_ARG, "gzdopen failed"); }
-        gzbuffer(g, 1 << 20);
-        size_t cap = std::max<size_t>(f->size * 4, 1 << 20), used = 0;
-        uint8_t* mem = (uint8_t*)malloc(cap);
-        for (;;) {
-            if (!mem) { gzclose(g); delete f; return kbbq_set_error_(KBBQ_E_ARG, "out of memory while inflating"); }
-            const int got = gzread(g, mem + used, (unsigned)std::min<size_t>(cap - used, 1u << 30));
-            if (got < 0) { free(mem); gzclose(g); f->size = 0; delete f; return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": corrupt gzip stream").c_str()); }
-            if (got == 0) break;
-            used += (size_t)got;
-            if (used == cap) { cap *= 2; mem = (uint8_t*)realloc(mem, cap); }
-        }
-        gzclose(g);                                  // closes fd
-        f->buf = mem; f->size = used; f->mapped = false;
+        // gzip / bgzip (what pysam.FastxFile reads transparently): inflate all members into memory -- bgzip's
+        // independent blocks in parallel (bam_host.cpp), plain gzip on one thread
+        void* m = mmap(nullptr, f->size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { delete f; return kbbq_set_error_(KBBQ_E_ARG, "mmap failed"); }
+        std::string err;
+        const bool ok = kbbq_inflate_all((const uint8_t*)m, f->size, f->owned, err);
+        munmap(m, f->size);
+        if (!ok) { f->size = 0; delete f; return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": " + err).c_str()); }
+        f->buf = f->owned.data(); f->size = f->owned.size(); f->mapped = false;
     } else {
         if (f->size) {
             void* m = mmap(nullptr, f->size, PROT_READ, MAP_PRIVATE, fd, 0);

@@ -603,3 +603,28 @@ def test_planned_sharding_reads_each_byte_range_once(oracle, tmp_path):
     for r in range(2):
         with pytest.raises(ValueError, match='missing'):
             fastx.pack_pair(str(tmp_path / 'missing.fq'), good, False, shard=(r, 2), exchange=ex.get(r, lambda obj: box['plan']))
+
+
+def test_bgzip_fastq_is_inflated_block_parallel(oracle, tmp_path):
+    """A bgzip (BGZF) FASTQ -- many independent gzip members with their sizes in the header -- reads like the plain
+    file (blocks inflated in parallel by the library); a damaged block is an error, not a crash."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import bamwriter
+    n = 3000
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 3, 40, 100, 2)
+    names = oracle.synth_names(0, n, 2, with_rg=True)
+    fa = str(tmp_path / 'a.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    raw = open(fa, 'rb').read()
+    bz = tmp_path / 'a.fq.gz'
+    bz.write_bytes(bamwriter.bgzf(raw, block=20000))
+    plain, comp = fastx.NativeFastq(fa), fastx.NativeFastq(str(bz))
+    assert comp.n == plain.n == n and not comp.is_plain() and plain.is_plain()
+    assert comp.scan(None, True) == plain.scan(None, True)
+    a, b = plain.fill(None, True, n, 112), comp.fill(None, True, n, 112)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b) if x is not None)
+    bad = bytearray(bz.read_bytes()); bad[len(bad) // 2] ^= 0x55
+    (tmp_path / 'bad.fq.gz').write_bytes(bytes(bad))
+    with pytest.raises(ValueError):
+        fastx.NativeFastq(str(tmp_path / 'bad.fq.gz'))
