@@ -93,14 +93,17 @@ class Tables:
         return (b[:npos].view(R, NQ, S2), b[npos:2 * npos].view(R, NQ, S2),
                 b[2 * npos:2 * npos + ndn].view(R, NQ, 16), b[2 * npos + ndn:].view(R, NQ, 16))
 
-    def to_host(self):
-        """(pos_errs, pos_total, dinuc_errs, dinuc_total) as fresh int64 numpy arrays."""
+    def host_views(self):
+        """(pos_errs, pos_total, dinuc_errs, dinuc_total) as views of ONE host copy of the buffer (read-only use)."""
         h = self.buf.cpu().numpy()
         R, S2 = self.R, self.S2
         npos, ndn = R * NQ * S2, R * NQ * 16
-        return (h[:npos].reshape(R, NQ, S2).copy(), h[npos:2 * npos].reshape(R, NQ, S2).copy(),
-                h[2 * npos:2 * npos + ndn].reshape(R, NQ, 16).copy(),
-                h[2 * npos + ndn:].reshape(R, NQ, 16).copy())
+        return (h[:npos].reshape(R, NQ, S2), h[npos:2 * npos].reshape(R, NQ, S2),
+                h[2 * npos:2 * npos + ndn].reshape(R, NQ, 16), h[2 * npos + ndn:].reshape(R, NQ, 16))
+
+    def to_host(self):
+        """(pos_errs, pos_total, dinuc_errs, dinuc_total) as fresh int64 numpy arrays."""
+        return tuple(a.copy() for a in self.host_views())
 
 
 _pinned = {}
@@ -466,7 +469,7 @@ def solve(tables, want_dq=False, minscore=MINSCORE):
     from . import _solve
     torch = _torch()
     R, S2 = tables.R, tables.S2
-    vectors = _solve.vectors_from_tables(*tables.to_host())
+    vectors = _solve.vectors_from_tables(*tables.host_views())
     meanq, rg_e, rg_t, q_e, q_t, p_e, p_t, d_e, d_t = vectors
     # the gammaln terms of all four levels in ONE call (elementwise: one wake-up of the library's parked threads)
     aux = _solve.combiln(np.concatenate([rg_e.ravel(), q_e.ravel(), p_e.ravel(), d_e.ravel()]),
