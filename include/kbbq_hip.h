@@ -199,6 +199,10 @@ int    kbbq_posterior_q_dev(kbbq_ctx* ctx, const double* d_prior_q, const int64_
  * arguments, NaN for cells outside the distribution's support, which the solve ignores), on `threads`
  * threads; kbbq_gammaln_host exposes the gammaln itself for the tests.                              */
 int    kbbq_combiln_host(const int64_t* errs, const int64_t* total, int64_t ncells, double* comb, int threads);
+/* The host half of one solve in one threaded pass over the count tables as they come off the device (layout of
+ * kbbq_accumulate_dev's d_tables): marg = [q_errs R*43 | q_total R*43 | rg_errs R | rg_total R] (recalibrate.py:112-115)
+ * and aux = the gammaln term of every cell in kbbq_solve_dev's order [rg R | q R*43 | pos R*43*S2 | dinuc R*43*16]. */
+int kbbq_solve_prep_host(const int64_t* tables, int R, int S2, double* aux, int64_t* marg, int threads);
 int    kbbq_gammaln_host(const double* x, int64_t n, double* out);
 size_t kbbq_solve_aux_count(int R, int S2);
 size_t kbbq_solve_dq_count(int R, int S2);

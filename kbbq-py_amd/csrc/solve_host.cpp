@@ -20,6 +20,7 @@
 #include <condition_variable>
 #include <limits>
 #include <mutex>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -95,7 +96,7 @@ struct Pool {
     std::mutex m;
     std::condition_variable wake, done;
     std::vector<std::thread> workers;
-    const int64_t* errs = nullptr; const int64_t* total = nullptr; double* out = nullptr;
+    std::function<void(int64_t, int64_t)> job;      // [lo, hi) of the current job's items
     int64_t n = 0, per = 0;
     int parts = 0;            // slices of the current job (slice 0 is the caller's)
     uint64_t generation = 0;
@@ -112,17 +113,16 @@ struct Pool {
             seen = generation;
             const bool mine = id < parts;
             const int64_t lo = std::min<int64_t>(n, (int64_t)id * per), hi = std::min<int64_t>(n, lo + per);
-            const int64_t *e = errs, *t = total; double* o = out;
             lk.unlock();
             if (mine) {
-                combiln_range(e, t, lo, hi, o);
+                job(lo, hi);                 // `job` is not reassigned before every slice has reported (pending == 0)
                 lk.lock();
                 if (--pending == 0) done.notify_one();
             }
         }
     }
 
-    void run(const int64_t* e, const int64_t* t, int64_t count, double* o, int threads)
+    void run(std::function<void(int64_t, int64_t)> f, int64_t count, int threads)
     {
         std::unique_lock<std::mutex> lk(m);
         while ((int)workers.size() < threads - 1) {
@@ -130,18 +130,22 @@ struct Pool {
             workers.emplace_back([this, id] { worker(id); });
             workers.back().detach();
         }
-        errs = e; total = t; out = o; n = count; parts = threads;
+        job = std::move(f); n = count; parts = threads;
         per = (count + threads - 1) / threads;
         pending = threads - 1;
         ++generation;
         lk.unlock();
         wake.notify_all();
-        combiln_range(e, t, 0, std::min<int64_t>(count, per), o);
+        job(0, std::min<int64_t>(count, per));
         lk.lock();
         done.wait(lk, [&] { return pending == 0; });
     }
 
 };
+
+// workers are started on first use and parked on a condition variable; the pool is never torn down
+// (detached threads, no work at process exit: nothing to interleave with the HIP runtime's own shutdown)
+Pool& pool() { static Pool* p = new Pool; return *p; }
 
 }  // namespace
 
@@ -155,16 +159,49 @@ int kbbq_gammaln_host(const double* x, int64_t n, double* out)
     return KBBQ_OK;
 }
 
+// The host half of one model solve in ONE pass over the count tables as they come off the device
+// ([pos_errs R x 43 x S2 | pos_total | dinuc_errs R x 43 x 16 | dinuc_total], int64): the marginals the reference takes
+// (recalibrate.py:112-115: q_* = sum over cycles, rg_* = sum over qualities) and the candidate-independent gammaln
+// term of every cell, in the order kbbq_solve_dev reads them ([rg R | q R x 43 | pos R x 43 x S2 | dinuc R x 43 x 16]).
+// marg = [q_errs R x 43 | q_total R x 43 | rg_errs R | rg_total R].  Rows (read group, quality) are spread over threads.
+int kbbq_solve_prep_host(const int64_t* tables, int R, int S2, double* aux, int64_t* marg, int threads)
+{
+    if (!tables || !aux || !marg || R <= 0 || S2 <= 0) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_solve_prep_host: bad argument");
+    const int Q = 43;
+    const int64_t npos = (int64_t)R * Q * S2, ndn = (int64_t)R * Q * 16, rows = (int64_t)R * Q;
+    const int64_t *pe = tables, *pt = tables + npos, *de = tables + 2 * npos, *dt = de + ndn;
+    double* aux_rg = aux; double* aux_q = aux + R; double* aux_pos = aux_q + rows; double* aux_dn = aux_pos + npos;
+    int64_t *q_errs = marg, *q_total = marg + rows, *rg_errs = marg + 2 * rows, *rg_total = rg_errs + R;
+    auto do_rows = [&](int64_t lo, int64_t hi) {
+        for (int64_t row = lo; row < hi; ++row) {
+            const int64_t* e = pe + row * S2; const int64_t* t = pt + row * S2;
+            int64_t se = 0, st = 0;
+            for (int c = 0; c < S2; ++c) { se += e[c]; st += t[c]; }
+            q_errs[row] = se; q_total[row] = st;
+            combiln_range(e, t, 0, S2, aux_pos + row * S2);
+            combiln_range(de + row * 16, dt + row * 16, 0, 16, aux_dn + row * 16);
+        }
+    };
+    threads = std::max(1, std::min<int>(threads, (int)std::min<int64_t>(rows, Pool::MAX)));
+    if (threads == 1) do_rows(0, rows);
+    else pool().run(do_rows, rows, threads);
+    for (int r = 0; r < R; ++r) {
+        int64_t se = 0, st = 0;
+        for (int q = 0; q < Q; ++q) { se += q_errs[(int64_t)r * Q + q]; st += q_total[(int64_t)r * Q + q]; }
+        rg_errs[r] = se; rg_total[r] = st;
+    }
+    combiln_range(q_errs, q_total, 0, rows, aux_q);
+    combiln_range(rg_errs, rg_total, 0, R, aux_rg);
+    return KBBQ_OK;
+}
+
 int kbbq_combiln_host(const int64_t* errs, const int64_t* total, int64_t n, double* out, int threads)
 {
     if (n < 0 || (n > 0 && (!errs || !total || !out))) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_combiln_host: bad argument");
     if (threads < 1) threads = 1;
     if (threads > Pool::MAX) threads = Pool::MAX;
     if (n < 4096 || threads == 1) { combiln_range(errs, total, 0, n, out); return KBBQ_OK; }
-    // workers are started on first use and parked on a condition variable; the pool is never torn down
-    // (detached threads, no work at process exit: nothing to interleave with the HIP runtime's own shutdown)
-    static Pool* pool = new Pool;
-    pool->run(errs, total, n, out, threads);
+    pool().run([=](int64_t lo, int64_t hi) { combiln_range(errs, total, lo, hi, out); }, n, threads);
     return KBBQ_OK;
 }
 

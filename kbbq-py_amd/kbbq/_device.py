@@ -469,11 +469,15 @@ def solve(tables, want_dq=False, minscore=MINSCORE):
     from . import _solve
     torch = _torch()
     R, S2 = tables.R, tables.S2
-    vectors = _solve.vectors_from_tables(*tables.host_views())
-    meanq, rg_e, rg_t, q_e, q_t, p_e, p_t, d_e, d_t = vectors
-    # the gammaln terms of all four levels in ONE call (elementwise: one wake-up of the library's parked threads)
-    aux = _solve.combiln(np.concatenate([rg_e.ravel(), q_e.ravel(), p_e.ravel(), d_e.ravel()]),
-                         np.concatenate([rg_t.ravel(), q_t.ravel(), p_t.ravel(), d_t.ravel()]))
+    # host half in one native pass over the buffer as it comes off the device: marginals (recalibrate.py:112-115) and the
+    # gammaln term of every cell; meanq (longdouble, 43 terms per read group) stays NumPy
+    h = tables.buf.cpu().numpy()
+    aux, q_e, q_t, rg_e, rg_t = _solve.solve_prep(h, R, S2)
+    npos, ndn = R * NQ * S2, R * NQ * 16
+    p_e, p_t = h[:npos].reshape(R, NQ, S2), h[npos:2 * npos].reshape(R, NQ, S2)
+    d_e, d_t = h[2 * npos:2 * npos + ndn].reshape(R, NQ, 16), h[2 * npos + ndn:].reshape(R, NQ, 16)
+    meanq = _solve.meanq_from_q_total(q_t)
+    vectors = (meanq, rg_e, rg_t, q_e, q_t, p_e, p_t, d_e, d_t)
     lib = N.load()
     assert aux.size == lib.kbbq_solve_aux_count(R, S2)
     dev = tables.buf.device

@@ -60,6 +60,7 @@ PROTOTYPES = {
                         _vp, _vp, _vp, _vp, _vp, _vp]),
     'kbbq_delta_q_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'kbbq_combiln_host': (_i, [_vp, _vp, _i64, _vp, _i]),
+    'kbbq_solve_prep_host': (_i, [_vp, _i, _i, _vp, _vp, _i]),
     'kbbq_gammaln_host': (_i, [_vp, _i64, _vp]),
     'kbbq_posterior_q_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'kbbq_solve_aux_count': (_sz, [_i, _i]),

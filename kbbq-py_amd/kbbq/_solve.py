@@ -124,12 +124,10 @@ def sequential_constant_sum(p, n):
     return np.ldexp(np.longdouble(S), E)
 
 
-def vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore=42):
-    """The reference's 9-tuple from the four 3-d count arrays: q_* and rg_* are marginals of
-    pos_* (every counted base has exactly one cycle); meanq = p_to_q(sum_q q_total * 10^(-q/10)
-    / rg_total) in longdouble (recalibrate.py:111,120; SURVEY.md H4)."""
-    q_errs, q_total = pos_errs.sum(axis=2), pos_total.sum(axis=2)
-    rg_errs, rg_total = q_errs.sum(axis=1), q_total.sum(axis=1)
+def meanq_from_q_total(q_total, maxscore=42):
+    """meanq = p_to_q(sum_q q_total * 10^(-q/10) / rg_total) in longdouble (recalibrate.py:111,120)."""
+    q_total = np.asarray(q_total)
+    rg_total = q_total.sum(axis=1)
     p = utils.q_to_p(np.arange(maxscore + 1))
     expected = (q_total.astype(np.longdouble) * p).sum(axis=1)
     for r in range(q_total.shape[0]):
@@ -137,5 +135,29 @@ def vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore=4
         if nz.size == 1:      # one quality value only: reproduce the reference's add-by-add rounding
             expected[r] = sequential_constant_sum(np.float64(p[nz[0]]), int(q_total[r, nz[0]]))
     with np.errstate(divide='ignore', invalid='ignore'):
-        meanq = utils.p_to_q(expected / rg_total, maxscore)
+        return utils.p_to_q(expected / rg_total, maxscore)
+
+
+def solve_prep(flat_tables, R, S2):
+    """The host half of one solve from the flat int64 table buffer as it comes off the device, in one threaded native
+    pass (csrc/solve_host.cpp kbbq_solve_prep_host): (aux, q_errs, q_total, rg_errs, rg_total) -- aux = the gammaln
+    term of every cell in kbbq_solve_dev's order, the others the reference's marginals (recalibrate.py:112-115)."""
+    from . import _native as N
+    flat = np.ascontiguousarray(flat_tables, dtype=np.int64)
+    rows = R * NQ
+    assert flat.size == 2 * rows * S2 + 2 * rows * 16
+    aux = np.empty(R + rows + rows * S2 + rows * 16, dtype=np.float64)
+    marg = np.empty(2 * rows + 2 * R, dtype=np.int64)
+    threads = COMBILN_THREADS if COMBILN_THREADS else max(1, min(16, aux.size // 1700))
+    N.check(N.load().kbbq_solve_prep_host(N.ptr(flat), R, S2, N.ptr(aux), N.ptr(marg), threads))
+    return (aux, marg[:rows].reshape(R, NQ), marg[rows:2 * rows].reshape(R, NQ), marg[2 * rows:2 * rows + R], marg[2 * rows + R:])
+
+
+def vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore=42):
+    """The reference's 9-tuple from the four 3-d count arrays: q_* and rg_* are marginals of
+    pos_* (every counted base has exactly one cycle); meanq = p_to_q(sum_q q_total * 10^(-q/10)
+    / rg_total) in longdouble (recalibrate.py:111,120; SURVEY.md H4)."""
+    q_errs, q_total = pos_errs.sum(axis=2), pos_total.sum(axis=2)
+    rg_errs, rg_total = q_errs.sum(axis=1), q_total.sum(axis=1)
+    meanq = meanq_from_q_total(q_total, maxscore)
     return meanq, rg_errs, rg_total, q_errs, q_total, pos_errs, pos_total, dinuc_errs, dinuc_total

@@ -124,3 +124,30 @@ def test_solve_core_float_prior(solver, oracle):
     got = solver(pq, err, t)
     want = oracle.gatk_delta_q(pq, err, t)
     assert got.dtype == np.float64 and np.array_equal(got, want)
+
+
+def test_fused_solve_prep_matches_the_numpy_route():
+    """kbbq_solve_prep_host (marginals + the gammaln term of every cell, one threaded pass over the flat table buffer)
+    against vectors_from_tables + combiln on random tables, several read-group counts and thread counts."""
+    rng = np.random.default_rng(9)
+    for R, S2 in ((1, 300), (3, 64), (8, 302), (2, 2)):
+        npos, ndn = R * 43 * S2, R * 43 * 16
+        tot = rng.integers(0, 5_000_000, 2 * npos + 2 * ndn).astype(np.int64)
+        flat = tot.copy()
+        flat[:npos] = (tot[npos:2 * npos] * rng.random(npos) * 0.2).astype(np.int64)                  # errs <= total
+        flat[2 * npos:2 * npos + ndn] = (tot[2 * npos + ndn:] * rng.random(ndn) * 0.2).astype(np.int64)
+        flat[rng.random(flat.size) < 0.1] = 0
+        p_e, p_t = flat[:npos].reshape(R, 43, S2), flat[npos:2 * npos].reshape(R, 43, S2)
+        d_e, d_t = flat[2 * npos:2 * npos + ndn].reshape(R, 43, 16), flat[2 * npos + ndn:].reshape(R, 43, 16)
+        p_e = np.minimum(p_e, p_t); d_e = np.minimum(d_e, d_t)
+        flat = np.concatenate([p_e.ravel(), p_t.ravel(), d_e.ravel(), d_t.ravel()])
+        want = _solve.vectors_from_tables(p_e, p_t, d_e, d_t)
+        want_aux = np.concatenate([_solve.combiln(e, t).ravel() for e, t in ((want[1], want[2]), (want[3], want[4]), (p_e, p_t), (d_e, d_t))])
+        for threads in (1, 5, None):
+            _solve.COMBILN_THREADS = threads
+            aux, q_e, q_t, rg_e, rg_t = _solve.solve_prep(flat, R, S2)
+            assert np.array_equal(aux.view(np.int64), want_aux.view(np.int64)), (R, S2, threads)
+            for got, w in ((rg_e, want[1]), (rg_t, want[2]), (q_e, want[3]), (q_t, want[4])):
+                assert np.array_equal(got, w)
+            assert np.array_equal(_solve.meanq_from_q_total(q_t), want[0])
+    _solve.COMBILN_THREADS = None
