@@ -118,6 +118,12 @@ int main(int argc, char** argv)
         std::vector<double> x = {0.5, 1, 2, 12.5, 13, 999, 1e8, 1e300, -1, 0};
         std::vector<double> g(x.size());
         printf("gammaln rc=%d %.6f\n", kbbq_gammaln_host(x.data(), (int64_t)x.size(), g.data()), g[3]);
+        // the fused solve prep over a table buffer of 3 read groups x 43 x 150 cycles (+ 16 contexts), on the pool
+        const int R = 3, S2 = 150; const int64_t npos = (int64_t)R * 43 * S2, ndn = (int64_t)R * 43 * 16;
+        std::vector<int64_t> tab((size_t)(2 * npos + 2 * ndn));
+        for (size_t i = 0; i < tab.size(); ++i) tab[i] = (int64_t)((i * 2654435761u) % 100000);
+        std::vector<double> aux((size_t)(R + R * 43 + npos + ndn)); std::vector<int64_t> marg((size_t)(2 * R * 43 + 2 * R));
+        for (int th : {1, 6, 16, 2}) { int rc = kbbq_solve_prep_host(tab.data(), R, S2, aux.data(), marg.data(), th); printf("prep threads=%d rc=%d %lld\n", th, rc, (long long)marg[5]); }
         return 0;
     }
     return 2;

@@ -91,7 +91,7 @@ def test_malformed_inputs_do_not_touch_memory_they_do_not_own(harness, tmp_path)
 
 def test_gammaln_pool(harness):
     out = harness('combiln')
-    assert out.count('rc=0') == 5
+    assert out.count('rc=0') == 9
 
 
 def test_sam_reader(harness, oracle, tmp_path):
