@@ -3,19 +3,32 @@
 bench.py -- bases/s recalibrated (covariate accumulate + delta-Q solve + apply) on
 synthetic 2x150 bp reads, device-resident, at N GPUs of one node.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process.  N > 1 without a launcher's environment: this process -- before it imports
+anything that could touch a GPU -- starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py ...` as a CHILD and relays its one JSON line; launched
+by torch.distributed.run itself (RANK set) it is one rank of the job.  On a box with fewer GPUs than
+ranks the ranks share the devices and talk over gloo: a functional rehearsal, flagged as such in `data`.
 
 A "step" is one pass of the hot path over the rank's whole batch:
   K1 accumulate -> (N > 1: RCCL sum-allreduce of the count tables) -> delta-Q solve -> K2 apply.
 Workload at N = 1: BASELINE.json configs[1] (50 M reads, 1 read group, Q0-41); weak scaling:
 every rank holds --reads reads (configs[3] at N = 8).  Inputs are generated on the device and
 are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+The line's `extra` object (N = 1 only, --no-extra skips it) carries the numbers of the other
+configurations and of the rows next to the path, each measured in this same process after the timed
+region: BASELINE config 3 (8 read groups) with its layout passes, the one-read-per-row layout, the
+kernels of the truth-set / aligned-read rows (K4, K5, K6), the in-process FASTQ file path, and the CPU
+figures (the reference's own measured rate from the committed golden, the oracle port on 1 and on all
+host cores).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,9 +37,60 @@ sys.path.insert(0, os.path.join(ROOT, 'kbbq-py_amd'))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 READ_LEN = 150
+KERNEL_SOURCES = ('kbbq_kernels.h', 'kbbq_kernels_v3.h', 'kbbq_kernels_v4.h', 'kbbq_hip.hip')
 
 
-def cpu_baseline(sample_reads):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--reads', type=int, default=50_000_000, help='reads per GPU')
+    ap.add_argument('--rgs', type=int, default=1)
+    ap.add_argument('--cpu-sample', type=int, default=6_000_000, help='reads in the CPU baseline sample (0 = skip)')
+    ap.add_argument('--layout', choices=('packed', 'pairs', 'reads'), default='packed',
+                    help='device layout of the resident batch: mate-pair rows with 4-bit sequence planes, mate-pair rows '
+                         '(304 B per 2 x 150 bp), or one read per row (2 x 160 B)')
+    ap.add_argument('--no-extra', action='store_true', help='skip the `extra` object (other configurations, N = 1 only)')
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------- launcher (N > 1 from a plain command line)
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def child_command(args, port):
+    """The torch.distributed.run command line of the N-rank job (one rank per GPU)."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__),
+           '--gpus', str(args.gpus), '--steps', str(args.steps), '--warmup', str(args.warmup),
+           '--reads', str(args.reads), '--rgs', str(args.rgs), '--cpu-sample', str(args.cpu_sample),
+           '--layout', args.layout]
+    if args.no_extra:
+        cmd.append('--no-extra')
+    return cmd
+
+
+def launch_children(args):
+    """Parent of an N > 1 run started without a launcher: nothing GPU-side has been imported or initialised here;
+    the job runs as a child process (never exec) and its single JSON line is relayed."""
+    assert 'torch' not in sys.modules
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    proc = subprocess.run(child_command(args, free_port()), env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in proc.stdout.decode(errors='replace').splitlines() if ln.startswith('{')]
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode if proc.returncode else (0 if lines else 1)
+
+
+# ---------------------------------------------------------------- CPU figures
+def cpu_port_one_core(sample_reads):
     """The CPU oracle (oracle/, a scalar C port of the reference's algorithm) on a bounded
     sample of the same workload, 1 core.  Reported beside the GPU number; not the target."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
@@ -45,38 +109,406 @@ def cpu_baseline(sample_reads):
                       'solve %.2fs + apply %.2fs' % (sample_reads, bases, t1 - t0, t2 - t1, t3 - t2)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--reads', type=int, default=50_000_000, help='reads per GPU')
-    ap.add_argument('--rgs', type=int, default=1)
-    ap.add_argument('--cpu-sample', type=int, default=6_000_000, help='reads in the CPU baseline sample (0 = skip)')
-    ap.add_argument('--layout', choices=('pairs', 'reads'), default='pairs',
-                    help='device layout of the resident batch: mate-pair rows (304 B per 2 x 150 bp) or one read per row (2 x 160 B)')
-    args = ap.parse_args()
+def _port_worker(job):
+    first, n, total = job
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import oracle as O
+    seq, cseq, qual, meta = O.synth(first, n, total, 1)
+    t0 = time.perf_counter()
+    vectors = O.accumulate(seq, cseq, qual, meta, 1, READ_LEN)
+    t1 = time.perf_counter()
+    return [v.tolist() for v in vectors[5:9]], t1 - t0, first, n
 
+
+def _apply_worker(job):
+    first, n, total, meanq, dqs = job
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import numpy as np
+    import oracle as O
+    seq, cseq, qual, meta = O.synth(first, n, total, 1)
+    t0 = time.perf_counter()
+    O.apply(seq, qual, meta, np.asarray(meanq), *[np.asarray(d) for d in dqs])
+    return time.perf_counter() - t0
+
+
+def host_cores():
+    """CPUs this process may use: the cgroup quota when there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_port_all_cores(sample_reads):
+    """The same port on every host core: reads are independent, the tables add (the reference itself is
+    single-threaded; this is BASELINE.md's "restatement on all host cores" figure).  Shards are tallied in
+    worker processes, the tables summed, solved once, and the shards applied in the same workers; the time
+    is wall time of the two parallel phases plus the solve, generation excluded."""
+    import multiprocessing as mp
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import oracle as O
+    cores = host_cores()
+    per = sample_reads // cores // 2 * 2
+    jobs = [(k * per, per, cores * per) for k in range(cores)]
+    with mp.get_context('fork').Pool(cores) as pool:
+        t0 = time.perf_counter()
+        parts = pool.map(_port_worker, jobs)
+        t1 = time.perf_counter()
+        tabs = [sum(np.asarray(p[0][i], dtype=np.int64) for p in parts) for i in range(4)]
+        from kbbq import _solve                       # marginals + meanq of the summed tables (host NumPy)
+        vectors = _solve.vectors_from_tables(*tabs)
+        dqs = O.get_delta_qs(*vectors)
+        t2 = time.perf_counter()
+        ajobs = [(f, n, tot, vectors[0].tolist(), [d.tolist() for d in dqs]) for f, n, tot in jobs]
+        t3 = time.perf_counter()
+        ts = pool.map(_apply_worker, ajobs)
+        t4 = time.perf_counter()
+    gen = (t1 - t0) - max(p[1] for p in parts)          # workers generate their shard before the timed tally
+    bases = cores * per * READ_LEN
+    wall = max(p[1] for p in parts) + (t2 - t1) + max(ts)
+    return {'value': bases / wall, 'unit': 'bases/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d synthetic 2x150 reads in %d worker processes: slowest tally %.2fs + solve %.2fs + slowest '
+                      'apply %.2fs (generation %.1fs not counted)' % (cores * per, cores, max(p[1] for p in parts), t2 - t1, max(ts), gen)}
+
+
+def reference_figure():
+    """What the UNMODIFIED reference measured on BASELINE config 1 in the build container (it cannot travel to the GPU
+    box): timing fields of tests/golden/c1_10k_1rg.json, written by oracle/gen_golden.py."""
+    try:
+        with open(os.path.join(ROOT, 'tests', 'golden', 'c1_10k_1rg.json')) as fh:
+            t = json.load(fh)['reference_timing']
+        return t
+    except Exception:
+        return None
+
+
+# ---------------------------------------------------------------- helpers
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        p = os.path.join(ROOT, 'kbbq-py_amd', 'csrc', name)
+        if os.path.exists(p):
+            with open(p, 'rb') as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(layout_key, kernel):
+    """HBM bytes per base of `kernel` from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE x 2 + WRITE_SIZE, separate passes) -- only when they were taken on THIS kernel source (sha of
+    csrc/*kernels*.h + kbbq_hip.hip); otherwise None."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
+            pmc = json.load(fh)
+        if pmc.get('kernel_source_sha') != kernel_source_sha():
+            return None
+        return pmc[layout_key][kernel]['hbm_bytes_per_base']
+    except Exception:
+        return None
+
+
+def gbs(nbytes, ms):
+    return nbytes / (ms * 1e-3) / 1e9
+
+
+class Resident:
+    """A device-resident synthetic batch in the layout the product would pick, with the cost of the layout passes."""
+
+    def __init__(self, dev, torch, rank, n, world, R, layout):
+        S = READ_LEN
+        self.dev, self.torch, self.R, self.S, self.n = dev, torch, R, S, n
+        batch = dev.ReadBatch.synthetic(rank * n, n, world * n, seed=1, nrg=R)
+        self.rows = batch                    # one read per row, input order: what the packer hands over
+        self.layout_ms = {}
+        self.name = 'one read per row, pitch %d' % batch.pitch
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        if layout != 'reads':
+            a, b = ev(), ev()
+            a.record()
+            batch = dev.lay_out(batch, R, S, packed=(layout == 'packed'))
+            b.record()
+            torch.cuda.synchronize()
+            self.layout_ms['lay_out'] = a.elapsed_time(b)
+            self.name = batch.describe()
+        elif R > 1:
+            a, b = ev(), ev()
+            a.record()
+            batch = dev.group_by_rg(batch, R)
+            b.record()
+            torch.cuda.synchronize()
+            self.layout_ms['lay_out'] = a.elapsed_time(b)
+            self.name += ', rows grouped by read group'
+        self.batch = batch
+        self.out = torch.empty_like(batch.qual)
+        self.tables = dev.Tables(R, 2 * S)
+
+    def free_rows(self):
+        self.rows = None
+        self.torch.cuda.synchronize()
+        self.torch.cuda.empty_cache()
+
+
+def timed_steps(torch, dist, use_dist, dev, parallel, res, steps, warmup, rehearse, restore_order=False):
+    ctx = dev.context()
+    ar_events = []
+
+    def step(timed):
+        res.tables.buf.zero_()
+        dev.accumulate(res.batch, res.tables, check=False)
+        if use_dist:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            parallel.allreduce_tables(res.tables.buf)
+            b.record()
+            if timed:
+                ar_events.append((a, b))
+        lut, shape = dev.solve_lut(res.tables)
+        dev.apply(res.batch, lut, shape, out=res.out, check=False, restore_order=restore_order)
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step(False)
+    ctx.status()                       # raises if a kernel flagged bad input
+    ctx.kernel_ms(0, reset=True); ctx.kernel_ms(1, reset=True)
+    ctx.timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.timing(False)
+    ctx.status()
+    k1_ms, k1_n = ctx.kernel_ms(0)
+    k2_ms, k2_n = ctx.kernel_ms(1)
+    ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1) if ar_events and not rehearse else None
+    return elapsed, k1_ms / max(k1_n, 1), k2_ms / max(k2_n, 1), k1_n, k2_n, ar_ms
+
+
+def kernel_entry(avg_ms, launches, bases, bytes_per_base=3):
+    rate = gbs(bytes_per_base * bases, avg_ms)
+    return {'avg_ms': avg_ms, 'launches': launches, 'GB/s': rate, 'frac': rate / HBM_PEAK_GBS, 'bytes_per_base': bytes_per_base}
+
+
+# ---------------------------------------------------------------- the `extra` object (N = 1)
+def extra_config3(torch, dev, parallel, n, steps, warmup):
+    """BASELINE config 3: n reads, 8 read groups.  `value` as the headline (layout pass outside the step, like the
+    generation: in the file path the packer writes this layout itself); `layout_inclusive` is the figure for a caller
+    who hands over input-order rows on the device: the one native pass into the layout (read-group counting sort +
+    k7_lay_out: pairs packed, rows gathered by read-group segment, sequences as nibbles) plus a step whose K2 stores
+    through the permutation, straight back into input order (no pass afterwards)."""
+    res = Resident(dev, torch, 0, n, 1, 8, 'packed')
+    res.free_rows()
+    elapsed, k1, k2, n1, n2, _ = timed_steps(torch, None, False, dev, parallel, res, steps, warmup, False)
+    elapsed_r, k1r, k2r, _, n2r, _ = timed_steps(torch, None, False, dev, parallel, res, steps, 1, False, restore_order=True)
+    bases = n * READ_LEN
+    step_ms, step_r_ms = elapsed / steps * 1e3, elapsed_r / steps * 1e3
+    lay = res.layout_ms.get('lay_out', 0.0)
+    return {'workload': '%d synthetic 2x150 bp reads, 8 read groups (BASELINE config 3)' % n, 'layout': res.name,
+            'value': bases * steps / elapsed, 'unit': 'bases/s', 'ms_per_step': step_ms,
+            'k1_accumulate': kernel_entry(k1, n1, bases), 'k2_apply': kernel_entry(k2, n2, bases),
+            'host_solve_and_sync_ms': step_ms - k1 - k2,
+            'lay_out_ms': lay, 'k2_apply_storing_through_perm': kernel_entry(k2r, n2r, bases),
+            'layout_inclusive': {'value': bases / ((step_r_ms + lay) * 1e-3), 'unit': 'bases/s', 'ms': step_r_ms + lay,
+                                 'note': 'input-order rows on the device -> layout pass (%.2f ms) + one step whose K2 stores '
+                                         'back in input order (%.2f ms)' % (lay, step_r_ms)}}
+
+
+def extra_layout(torch, dev, parallel, n, steps, warmup, layout):
+    res = Resident(dev, torch, 0, n, 1, 1, layout)
+    res.free_rows()
+    elapsed, k1, k2, n1, n2, _ = timed_steps(torch, None, False, dev, parallel, res, steps, warmup, False)
+    bases = n * READ_LEN
+    return {'workload': '%d synthetic 2x150 bp reads, 1 read group' % n, 'layout': res.name,
+            'value': bases * steps / elapsed, 'unit': 'bases/s', 'ms_per_step': elapsed / steps * 1e3,
+            'k1_accumulate': kernel_entry(k1, n1, bases), 'k2_apply': kernel_entry(k2, n2, bases)}
+
+
+def extra_aligned(torch, dev, n=4_000_000, L=150, G=200_000_000, ins=0.05, reps=5):
+    """K4 find_errors / K5 count_q / K6 canonical_reads on synthetic aligned reads built as arrays: n reads x L bases
+    against a random genome, `ins` of the reads with a 2-base insertion (3 CIGAR operations), half of them on the
+    reverse strand.  Algorithmic bytes per base: K4 3 read + 2 written, K5 3 read, K6 4 + 3."""
+    from kbbq import _native as N
+    pitch = (L + 15) // 16 * 16
+    g = torch.randint(0, 4, (G,), dtype=torch.uint8, device='cuda')
+    genome = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device='cuda')[g.long()]
+    del g
+    mask = (torch.rand(G, device='cuda') < 0.01).to(torch.uint8)
+    fused = genome | (mask << 7)
+    del mask
+    start = torch.randint(0, G - L, (n,), dtype=torch.int64, device='cuda')
+    start[:64] = G - L
+    idx = (start[:, None] + torch.arange(pitch, device='cuda')[None, :]).clamp_(max=G - 1)
+    seq = genome[idx]
+    del idx, genome
+    seq = torch.where(torch.rand((n, pitch), device='cuda') < 0.01, torch.tensor(65, dtype=torch.uint8, device='cuda'), seq)
+    lens = torch.full((n,), L, dtype=torch.int32, device='cuda')
+    has_ins = torch.rand(n, device='cuda') < ins
+    ref_len = torch.where(has_ins, L - 2, L).to(torch.int32)
+    cig_n = torch.where(has_ins, 3, 1).to(torch.int32)
+    cig_off = torch.cumsum(cig_n, 0).to(torch.int32) - cig_n
+    cigar = torch.zeros(int(cig_n.sum()), dtype=torch.int32, device='cuda')
+    o = cig_off.long()
+    cigar[o[~has_ins]] = (L << 4) | 0
+    cigar[o[has_ins]] = (50 << 4) | 0
+    cigar[o[has_ins] + 1] = (2 << 4) | 1
+    cigar[o[has_ins] + 2] = ((L - 52) << 4) | 0
+    flip = (torch.rand(n, device='cuda') < 0.5).to(torch.uint8)
+    err = torch.zeros((n, pitch), dtype=torch.uint8, device='cuda')
+    skip = torch.zeros_like(err)
+    qual = torch.randint(2, 42, (n, pitch), dtype=torch.uint8, device='cuda')
+    counts = torch.zeros(512, dtype=torch.int64, device='cuda')
+    oq = qual + 33
+    noflip = torch.zeros_like(flip)
+    clip = torch.full((n,), L << 16, dtype=torch.int32, device='cuda')
+    clip[torch.rand(n, device='cuda') < 0.2] = 5 | ((L - 5) << 16)
+    trim = torch.zeros(n, dtype=torch.int32, device='cuda')
+    trim[torch.rand(n, device='cuda') < 0.05] = (L - 20) | (L << 16)
+    flags = torch.randint(0, 4, (n,), device='cuda', dtype=torch.int32)
+    batch = dev.ReadBatch(n, pitch, with_corrected=True)
+    tables = dev.Tables(1, 2 * L)
+    ctx, lib = dev.context(), N.load()
+    aux = dev.cigar_prefix(cig_off, cig_n, cigar) if hasattr(dev, 'cigar_prefix') else None
+
+    def k4(fl):
+        N.check(lib.kbbq_find_errors_dev(ctx.handle, N.ptr(seq), N.ptr(lens), n, pitch, N.ptr(start), N.ptr(ref_len),
+                                         N.ptr(cig_off), N.ptr(cig_n), N.ptr(cigar), N.ptr(fused), None, G, N.ptr(fl),
+                                         N.ptr(err), N.ptr(skip)))
+
+    def k5():
+        N.check(lib.kbbq_count_q_dev(ctx.handle, N.ptr(qual), N.ptr(err), N.ptr(skip), N.ptr(lens), n, pitch, 0, N.ptr(counts)))
+
+    def k6():
+        N.check(lib.kbbq_canonical_reads_dev(ctx.handle, N.ptr(seq), N.ptr(oq), N.ptr(err), N.ptr(skip), N.ptr(lens),
+                                             N.ptr(clip), N.ptr(trim), N.ptr(flags), n, pitch, L, 6, 6,
+                                             N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual), N.ptr(batch.meta)))
+
+    def k1():
+        dev.accumulate(batch, tables, 6, check=False, dinuc_minscore=6)
+
+    out = {'workload': '%d aligned reads x %d bp, %d Mb random genome, %.0f %% of the reads with a 2-base insertion, half '
+                       'reverse-strand; HIP events on the launch stream, %d launches each' % (n, L, G // 1000000, ins * 100, reps)}
+    bases = n * L
+    for name, fn, bpb in (('k4_find_errors', lambda: k4(flip), 5), ('k5_count_q', k5, 3),
+                          ('k4_find_errors_tally', lambda: k4(noflip), 5), ('k6_canonical_reads', k6, 7),
+                          ('k1_on_canonical_reads', k1, 3)):
+        fn()
+        torch.cuda.synchronize()
+        evs = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in evs) / reps
+        out[name] = kernel_entry(ms, reps, bases, bpb)
+    ctx.status()
+    return out
+
+
+def extra_file_path(torch, dev, n=8_000_000):
+    """FASTQ text in -> FASTQ text out, in this (warm) process: kbbq.recalibrate.recalibrate_fastq on a synthetic
+    2x150 bp pair written to the box's /tmp, output into a file; stage times from the path's own KBBQ_TIMING trace."""
+    import numpy as np
+    from kbbq import recalibrate, _trace
+    tmp = os.environ.get('TMPDIR', '/tmp')
+    fa, fb, fo = (os.path.join(tmp, 'kbbq_bench_%d_%s.fq' % (os.getpid(), x)) for x in 'abo')
+    batch = dev.ReadBatch.synthetic(0, n, n, seed=1)
+    seq, cseq, qual = (getattr(batch, p)[:n, :READ_LEN].cpu().numpy() for p in ('seq', 'cseq', 'qual'))
+    del batch
+    t0 = time.perf_counter()
+    try:
+        for path, plane in ((fa, seq), (fb, cseq)):
+            rec = np.empty((n, 1 + 12 + 1 + 150 + 3 + 150 + 1), dtype=np.uint8)     # fixed-width names r%09d/1
+            ids = np.arange(n)
+            digits = ((ids >> 1)[:, None] // 10 ** np.arange(8, -1, -1)[None, :] % 10 + 48).astype(np.uint8)
+            rec[:, 0] = ord('@'); rec[:, 1] = ord('r'); rec[:, 2:11] = digits; rec[:, 11] = ord('/')
+            rec[:, 12] = 49 + (ids & 1); rec[:, 13] = 10
+            rec[:, 14:164] = plane; rec[:, 164] = 10; rec[:, 165] = ord('+'); rec[:, 166] = 10
+            rec[:, 167:317] = qual; rec[:, 317] = 10
+            rec.tofile(path)
+            del rec
+        write_s = time.perf_counter() - t0
+        sys.stdout.flush()
+        saved = os.dup(1)
+        fd = os.open(fo, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+        os.dup2(fd, 1)
+        _trace.collect(True)
+        try:
+            t0 = time.perf_counter()
+            recalibrate.recalibrate_fastq([fa, fb])
+            sys.stdout.flush()
+            wall = time.perf_counter() - t0
+        finally:
+            stages = _trace.collect(False)
+            os.dup2(saved, 1)
+            os.close(fd)
+            os.close(saved)
+        size = os.path.getsize(fo)
+    finally:
+        for p in (fa, fb, fo):
+            if os.path.exists(p):
+                os.remove(p)
+    bases = n * READ_LEN
+    return {'workload': '%d synthetic 2x150 bp reads as two FASTQ files (%.1f GB each) -> recalibrated FASTQ file (%.1f GB), '
+                        'in-process, device warm' % (n, n * 318 / 1e9, size / 1e9),
+            'value': bases / wall, 'unit': 'bases/s', 'wall_s': wall, 'stages_s': stages,
+            'input_written_in_s': write_s}
+
+
+def build_extra(torch, dev, parallel, args, headline_layout):
+    extra, n = {}, args.reads
+    small = max(args.steps // 2, 3)
+    for key, fn in (('config3_8rg', lambda: extra_config3(torch, dev, parallel, n, small, 1)),
+                    ('layout_pairs', lambda: extra_layout(torch, dev, parallel, n, small, 1, 'pairs')),
+                    ('layout_reads', lambda: extra_layout(torch, dev, parallel, n, small, 1, 'reads')),
+                    ('aligned_read_kernels', lambda: extra_aligned(torch, dev)),
+                    ('file_path', lambda: extra_file_path(torch, dev))):
+        if key == 'layout_' + headline_layout:
+            continue
+        t0 = time.perf_counter()
+        try:
+            extra[key] = fn()
+        except Exception as e:                # noqa: BLE001 -- an extra never takes the headline down
+            extra[key] = {'error': '%s: %s' % (type(e).__name__, e)}
+        extra[key]['took_s'] = round(time.perf_counter() - t0, 2)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return extra
+
+
+# ---------------------------------------------------------------- one rank
+def run_rank(args):
     # stdout carries exactly ONE JSON line: library banners (RCCL prints its version to stdout under
     # NCCL_DEBUG=VERSION) are sent to stderr until the result is printed
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    import numpy as np
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-    # KBBQ_BENCH_REHEARSE=gloo: every rank on the devices that exist (local % count), gloo instead of RCCL --
-    # a functional rehearsal of the N > 1 path on a one-GPU box; its numbers mean nothing
-    rehearse = os.environ.get('KBBQ_BENCH_REHEARSE', '') == 'gloo'
-    if rehearse:
-        local = local % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d ranks' % (args.gpus, world))
     use_dist = 'RANK' in os.environ                 # launched by torch.distributed.run (any N, also 1)
+    # fewer devices than ranks (a one-GPU box): every rank on the devices that exist, gloo instead of RCCL --
+    # a functional rehearsal of the N > 1 path; its numbers mean nothing (KBBQ_BENCH_REHEARSE=gloo forces it)
+    ndev = max(torch.cuda.device_count(), 1)
+    rehearse = use_dist and (os.environ.get('KBBQ_BENCH_REHEARSE', '') == 'gloo' or ndev < world)
+    if rehearse:
+        local = local % ndev
+    torch.cuda.set_device(local)
     if use_dist:
         if rehearse:
             dist.init_process_group('gloo')
@@ -84,110 +516,94 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     from kbbq import _device as dev
-    from kbbq import parallel, recalibrate
-    from kbbq.gatk import applybqsr
+    from kbbq import parallel
 
-    n = args.reads
-    R, S = args.rgs, READ_LEN
-    batch = dev.ReadBatch.synthetic(rank * n, n, world * n, seed=1, nrg=R)
-    layout = 'one read per row, pitch %d' % batch.pitch
-    if args.layout == 'pairs' and dev.PairBatch.worthwhile(S, batch.pitch):
-        # the product's device format for paired reads of one length: set up before the timed region, like the
-        # generation itself (inputs are resident in HBM when timing starts)
-        batch = dev.PairBatch.from_reads(batch)
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
-        layout = 'mate-pair rows, pitch %d per pair' % batch.pitch
-    if R > 1:
-        # many read groups: rows ordered by read group (set up once, like the layout above), so that every K1 / K2
-        # slice walks only its own rows
-        batch = dev.group_by_rg(batch, R)
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
-        layout += ', rows grouped by read group'
-    out = torch.empty_like(batch.qual)
-    tables = dev.Tables(R, 2 * S)
-    ctx = dev.context()
-
-    def step():
-        tables.buf.zero_()
-        dev.accumulate(batch, tables, check=False)
-        parallel.allreduce_tables(tables.buf)
-        lut, shape, _, _ = dev.solve(tables)
-        dev.apply(batch, lut, shape, out=out, check=False)
-
-    def fence():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    ctx.status()                       # raises if a kernel flagged bad input
-    ctx.kernel_ms(0, reset=True); ctx.kernel_ms(1, reset=True)
-    ctx.timing(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    ctx.timing(False)
-    ctx.status()
-    k1_ms, k1_n = ctx.kernel_ms(0)
-    k2_ms, k2_n = ctx.kernel_ms(1)
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if rehearse else 'cuda')
+    n, R, S = args.reads, args.rgs, READ_LEN
+    res = Resident(dev, torch, rank, n, world, R, args.layout)
+    res.free_rows()
+    elapsed, k1_avg, k2_avg, k1_n, k2_n, ar_ms = timed_steps(torch, dist, use_dist, dev, parallel, res, args.steps,
+                                                              args.warmup, rehearse)
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if rehearse or not use_dist else 'cuda')
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    ranks_seen = dist.get_world_size() if use_dist else 1
+    backend = dist.get_backend() if use_dist else None
+    layout_name = res.name
+    layout_key = res.batch.layout_key() if hasattr(res.batch, 'layout_key') else ('reads' if args.layout == 'reads' else 'pairs')
+    del res
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
 
     if rank == 0:
         bases_per_rank = n * S
         total_bases = bases_per_rank * world * args.steps
-        k1_avg = k1_ms / max(k1_n, 1) * 1e-3
-        k2_avg = k2_ms / max(k2_n, 1) * 1e-3
         # algorithmic bytes per launch: K1 reads seq+cseq+qual = 3 B/base;
         # K2 reads seq+qual and writes qual = 3 B/base
-        k1_gbs = 3.0 * bases_per_rank / k1_avg / 1e9
-        k2_gbs = 3.0 * bases_per_rank / k2_avg / 1e9
-        dom, dom_gbs = ('k1_accumulate', k1_gbs) if k1_avg >= k2_avg else ('k2_apply', k2_gbs)
-        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE,
-        # collected separately with rocprofv3 --pmc; see profiles/pmc_traffic.json) scaled to this launch
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
-                pmc = json.load(fh)
-                traffic = (pmc['pairs'] if layout.startswith('mate-pair') else pmc)[dom]['hbm_bytes_per_base'] * bases_per_rank
-        except Exception:
-            pass
-        res = {
+        k1 = kernel_entry(k1_avg, k1_n, bases_per_rank)
+        k2 = kernel_entry(k2_avg, k2_n, bases_per_rank)
+        dom, domk = ('k1_accumulate', k1) if k1_avg >= k2_avg else ('k2_apply', k2)
+        per_base = pmc_traffic(layout_key, dom)
+        for name, k in (('k1_accumulate', k1), ('k2_apply', k2)):
+            pb = pmc_traffic(layout_key, name)
+            k['hbm_bytes_per_base_pmc'] = pb
+            k['hbm_GB/s_pmc'] = None if pb is None else gbs(pb * bases_per_rank, k['avg_ms'])
+        step_ms = elapsed / args.steps * 1e3
+        res_line = {
             'metric': 'bases/sec recalibrated (2x150 bp)', 'value': total_bases / elapsed,
             'unit': 'bases/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic' + (' (gloo rehearsal, not a measurement)' if rehearse else ''),
+            'ms_per_step': step_ms, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic' + (' (gloo rehearsal on shared devices, not a measurement)' if rehearse else ''),
             'config': {'workload': '%d synthetic 2x150 bp reads per GPU, %d read group(s), Q0-41, '
                                    'accumulate + solve + apply end-to-end, device-resident' % (n, R),
-                       'reads_per_gpu': n, 'read_len': S, 'read_groups': R, 'layout': layout,
+                       'reads_per_gpu': n, 'read_len': S, 'read_groups': R, 'layout': layout_name,
                        'parallelism': 'reads sharded x%d, 1 allreduce of count tables' % world},
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': dom_gbs, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': dom_gbs / HBM_PEAK_GBS, 'traffic': traffic},
-            'kernels': {'k1_accumulate': {'avg_ms': k1_avg * 1e3, 'launches': k1_n, 'GB/s': k1_gbs,
-                                          'frac': k1_gbs / HBM_PEAK_GBS, 'bytes_per_base': 3},
-                        'k2_apply': {'avg_ms': k2_avg * 1e3, 'launches': k2_n, 'GB/s': k2_gbs,
-                                     'frac': k2_gbs / HBM_PEAK_GBS, 'bytes_per_base': 3},
-                        'host_solve_and_sync_ms': elapsed / args.steps * 1e3 - (k1_avg + k2_avg) * 1e3},
+            'ranks_seen': ranks_seen, 'backend': backend,
+            'allreduce_ms_per_step': ar_ms,
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': domk['GB/s'], 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': domk['frac'],
+                         'traffic': None if per_base is None else per_base * bases_per_rank,
+                         'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate '
+                                           'passes, 20 M reads, scaled per base; null when taken on another kernel source)',
+                         'kernel_source_sha': kernel_source_sha()},
+            'kernels': {'k1_accumulate': k1, 'k2_apply': k2,
+                        'host_solve_and_sync_ms': step_ms - k1_avg - k2_avg},
         }
         if world == 1 and args.cpu_sample > 0:
-            res['cpu_baseline'] = cpu_baseline(args.cpu_sample)
+            base = cpu_port_one_core(args.cpu_sample)
+            ref = reference_figure()
+            if ref is not None:
+                base['reference_bases_per_s'] = ref.get('end_to_end_bases_per_s')
+                base['reference_pass1_bases_per_s'] = ref.get('pass1_bases_per_s')
+                base['reference_cores'] = ref.get('cores_used', 1)
+                base['reference_note'] = ('the unmodified reference (Python / NumPy, single-threaded) on BASELINE config 1, measured in '
+                                          'the build container (%s host cores there) by oracle/gen_golden.py: tests/golden/c1_10k_1rg.json'
+                                          % ref.get('host_cores', '8'))
+            base['host_cores'] = host_cores()
+            if not args.no_extra:
+                try:
+                    base['all_cores'] = cpu_port_all_cores(args.cpu_sample * 2)
+                except Exception as e:        # noqa: BLE001
+                    base['all_cores'] = {'error': '%s: %s' % (type(e).__name__, e)}
+            res_line['cpu_baseline'] = base
+        if world == 1 and not args.no_extra:
+            res_line['extra'] = build_extra(torch, dev, parallel, args, args.layout)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res_line), flush=True)
         os.dup2(2, 1)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        return launch_children(args)
+    return run_rank(args)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -298,6 +298,44 @@ int    kbbq_apply_grouped_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t
                               int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
                               const void* d_lut_blob, const void* d_pair_lut, const int64_t* d_seg, uint8_t* d_out);
 
+/* ---- layouts in one interface: flags, 4-bit sequence planes, the layout pass -----------------
+ * KBBQ_ROWS_PAIRS   the rows are mate-pair rows (above; pitch = kbbq_pair_pitch(S2)).
+ * KBBQ_ROWS_NIBBLES the seq / cseq planes hold one NIBBLE per base instead of one character: the nucleotide
+ *                   code of compare_reads.py:199 (A0 T1 G2 C3; 4 = N, separator, padding), row stride pitch / 2,
+ *                   8 bytes per 16-base chunk; word w (0, 1) of a chunk holds bases 8w..8w+3 in the low nibbles of
+ *                   its bytes and bases 8w+4..8w+7 in the high nibbles.  Only batches whose seq AND cseq are
+ *                   entirely ACGTN have such planes (kbbq_lay_out_dev reports KBBQ_E_LUT otherwise: keep byte
+ *                   planes, which carry the reference's TypeError semantics); find_corrected_sites
+ *                   (recalibrate.py:13-20) then compares codes.  K1 reads 2 B/base instead of 3, K2 2.5 instead of 3.
+ * kbbq_accumulate_rows_dev / kbbq_apply_rows_dev: K1 / K2 on any combination (d_seg NULL: rows not grouped).
+ * d_perm (apply, optional, with d_seg): row i of the batch is STORED as row d_perm[i] of d_out -- the rows go
+ * straight back into the order they had before kbbq_group_rows_dev, no separate pass.
+ * kbbq_meta_stats_dev: one pass over the sidecars (synchronises): h_stats8[0] shortest non-empty read, [1] longest
+ * read, [2] largest read-group id, [3] violations of the mate-pair preconditions (0 = uniform first / second pairs
+ * of one length and read group), [4] empty reads.
+ * kbbq_group_rows_dev: stable counting sort of the rows (pairs != 0: of the PAIRS, by the first mate's sidecar)
+ * by read group, R <= 256: d_perm[nrows] (row i of the grouped order is row d_perm[i]) and d_seg[R + 1];
+ * d_work: kbbq_group_rows_work_bytes(nrows, R) bytes.  A sidecar with read group >= R -> KBBQ_E_RANGE (status).
+ * kbbq_lay_out_dev: input-order rows [nreads, pitch] -> the destination layout in ONE pass (pair packing, gather by
+ * d_perm (may be NULL), nibble packing fused): destination planes [nrows, dpitch] (seq / cseq: dpitch / 2 with
+ * KBBQ_ROWS_NIBBLES), nrows = nreads / 2 and dpitch = kbbq_pair_pitch(S2) with KBBQ_ROWS_PAIRS, else nreads and pitch.  */
+#define KBBQ_ROWS_PAIRS    1
+#define KBBQ_ROWS_NIBBLES  2
+int    kbbq_accumulate_rows_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
+                                const uint32_t* d_meta, int64_t nrows, int pitch, int flags, int R, int S2, int S_band,
+                                int S_min, int minscore, int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables);
+int    kbbq_apply_rows_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta, int64_t nrows,
+                           int pitch, int flags, int R, int S2, int minscore, const void* d_lut_blob, const void* d_pair_lut,
+                           const int64_t* d_seg, const int64_t* d_perm, uint8_t* d_out);
+int    kbbq_meta_stats_dev(kbbq_ctx* ctx, const uint32_t* d_meta, int64_t nreads, int32_t* h_stats8);
+size_t kbbq_group_rows_work_bytes(int64_t nrows, int R);
+int    kbbq_group_rows_dev(kbbq_ctx* ctx, const uint32_t* d_meta, int64_t nrows, int pairs, int R, void* d_work,
+                           int64_t* d_perm, int64_t* d_seg);
+int    kbbq_lay_out_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
+                        const uint32_t* d_meta, int64_t nreads, int pitch, int flags, int S2, const int64_t* d_perm,
+                        uint8_t* d_lseq, uint8_t* d_lcseq, uint8_t* d_lqual, uint32_t* d_lmeta);
+int    kbbq_unpack_nibbles_dev(kbbq_ctx* ctx, const uint8_t* d_nib, int64_t nbases, uint8_t* d_chars);
+
 /* ---- host SAM / BAM reader (no GPU) ----------------------------------------------------------
  * Replaces, for the truth-set benchmark and the BAM-sourced tally, what the reference gets from
  * pysam.AlignmentFile / AlignedSegment (benchmark.py:57-74,102-143; gatk/bqsr.py:23-123): per alignment

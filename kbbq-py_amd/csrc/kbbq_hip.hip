@@ -3,6 +3,7 @@
 #include "kbbq_kernels.h"
 #include "kbbq_kernels_v3.h"
 #include "kbbq_solve_kernels.h"
+#include "kbbq_layout_kernels.h"
 #include "../../include/kbbq_hip.h"
 
 #include <algorithm>
@@ -43,6 +44,7 @@ struct kbbq_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     u64* d_status = nullptr;          // [4]
+    int* d_stats = nullptr;           // [K7_NSTATS] scratch of kbbq_meta_stats_dev
     bool timing = false;
     // per-kernel event pairs recorded while timing is on
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
@@ -93,7 +95,14 @@ int kbbq_ctx_create(int device, kbbq_ctx** out)
     (void)hipFuncSetAttribute((const void*)k1_accumulate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k1v3_accumulate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k1v3_accumulate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)k2v3_apply, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<false, K1V3_DNREP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<true, K1V3_DNREP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<true, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k2v3_apply<false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k2v3_apply<true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2_apply<int16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2_apply<int8_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipGetLastError();
@@ -108,6 +117,7 @@ int kbbq_ctx_destroy(kbbq_ctx* c)
     for (int w = 0; w < 2; ++w)
         for (auto& pr : c->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->d_status) (void)hipFree(c->d_status);
+    if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return KBBQ_OK;
@@ -289,7 +299,7 @@ int kbbq_accumulate_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq
 
 static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                            const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
-                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band = 0, int S_min = 0);
+                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band = 0, int S_min = 0, int nib = 0);
 
 int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq,
                            const uint8_t* d_qual, const uint32_t* d_meta,
@@ -451,7 +461,7 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
         q.full = reinterpret_cast<const int8_t*>(d_lut) + lut_full_offset(R, Qt, S2);
         q.full_bytes = (int)full_bytes;
         q.rb = (u32)full_lut_row_bytes(S2); q.W = (u32)full_lut_width(S2); q.ctx_off = 2u * q.W;
-        q.maxlen = S2; q.pairs = 0; q.seg = nullptr; q.rpb = 64;
+        q.maxlen = S2; q.pairs = 0; q.seg = nullptr; q.rpb = 64; q.perm = nullptr;
         q.out = d_out; q.status = c->d_status;
 #ifdef K2V3_PER_CU
         int per_cu = K2V3_PER_CU;
@@ -463,7 +473,7 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
         int gx = (int)std::min<int64_t>(want, (int64_t)c->cus * per_cu);
         {
             Timed t(c, 1);
-            hipLaunchKernelGGL(k2v3_apply, dim3((unsigned)std::max(gx, 1)), dim3(K2V3_THREADS), full_bytes, c->stream, q);
+            hipLaunchKernelGGL(k2v3_apply<false>, dim3((unsigned)std::max(gx, 1)), dim3(K2V3_THREADS), full_bytes, c->stream, q);
         }
         HIPCHK(hipGetLastError());
         return KBBQ_OK;
@@ -665,7 +675,7 @@ int kbbq_unpack_pairs_dev(kbbq_ctx* c, const uint8_t* d_pplane, int64_t npairs, 
 // K1 (table-driven kernel) on one-read-per-row or mate-pair rows, optionally grouped by read group
 static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                            const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
-                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band, int S_min)
+                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band, int S_min, int nib)
 {
     if (fits) *fits = true;
     if (S_band < 0 || S_band > S2 / 2 || (pairs && S_band)) return fail(KBBQ_E_ARG, "%s: S_band out of range (%d)", who, S_band);
@@ -717,7 +727,15 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     dim3 grid((unsigned)gx, (unsigned)R, 1), block(K1V3_THREADS, 1, 1);
     {
         Timed t(c, 0);
-        if (dn == K1V3_DNREP) {
+        if (nib) {
+            if (dn == K1V3_DNREP) {
+                if (split) hipLaunchKernelGGL((k1v3_accumulate<true, K1V3_DNREP, true>), grid, block, lds3, c->stream, q);
+                else hipLaunchKernelGGL((k1v3_accumulate<false, K1V3_DNREP, true>), grid, block, lds3, c->stream, q);
+            } else {
+                if (split) hipLaunchKernelGGL((k1v3_accumulate<true, 8, true>), grid, block, lds3, c->stream, q);
+                else hipLaunchKernelGGL((k1v3_accumulate<false, 8, true>), grid, block, lds3, c->stream, q);
+            }
+        } else if (dn == K1V3_DNREP) {
             if (split) hipLaunchKernelGGL((k1v3_accumulate<true, K1V3_DNREP>), grid, block, lds3, c->stream, q);
             else hipLaunchKernelGGL((k1v3_accumulate<false, K1V3_DNREP>), grid, block, lds3, c->stream, q);
         } else {
@@ -769,7 +787,7 @@ int kbbq_pair_lut_dev(kbbq_ctx* c, const void* d_lut_blob, int R, int S2, int mi
 // K2 (table-driven kernel) on one-read-per-row or mate-pair rows, optionally grouped by read group
 static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta,
                       int64_t nrows, int pitch, int pairs, int R, int S2, int minscore, const void* d_lut_blob,
-                      const void* d_pair_lut, const int64_t* d_seg, uint8_t* d_out)
+                      const void* d_pair_lut, const int64_t* d_seg, uint8_t* d_out, int nib = 0, const int64_t* d_perm = nullptr)
 {
     int rc = check_planes(who, nrows, pitch, d_seq, d_qual, d_out);
     if (rc) return rc;
@@ -796,6 +814,7 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
     if (pairs) { q.W = 0u; q.ctx_off = (u32)pair_pitch(S2); q.maxlen = S2 + 1; }
     else { q.W = (u32)full_lut_width(S2); q.ctx_off = 2u * q.W; q.maxlen = S2; }
     q.pairs = pairs; q.seg = reinterpret_cast<const long long*>(d_seg);
+    q.perm = reinterpret_cast<const long long*>(d_perm);
     q.out = d_out; q.status = c->d_status;
     int per_cu = std::max(1, std::min<int>((int)(c->lds_bytes / lds), (K2V3_WAVES * 4 * 64) / K2V3_THREADS));
     q.rpb = 64;      // smaller wave blocks / short-lived workgroups were measured slower (profiles/r01_traversal_microbench.md)
@@ -806,7 +825,8 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
 
     {
         Timed t(c, 1);
-        hipLaunchKernelGGL(k2v3_apply, dim3((unsigned)std::max(gx, 1), (unsigned)slices, 1), dim3(K2V3_THREADS), lds, c->stream, q);
+        if (nib) hipLaunchKernelGGL(k2v3_apply<true>, dim3((unsigned)std::max(gx, 1), (unsigned)slices, 1), dim3(K2V3_THREADS), lds, c->stream, q);
+        else hipLaunchKernelGGL(k2v3_apply<false>, dim3((unsigned)std::max(gx, 1), (unsigned)slices, 1), dim3(K2V3_THREADS), lds, c->stream, q);
     }
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
@@ -831,6 +851,134 @@ int kbbq_apply_grouped_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_q
     if (!d_seg) return fail(KBBQ_E_ARG, "kbbq_apply_grouped_dev: d_seg is NULL");
     return apply_rows(c, "kbbq_apply_grouped_dev", d_seq, d_qual, d_meta, nrows, pitch, pairs ? 1 : 0, R, S2, minscore,
                       d_lut_blob, d_pair_lut, d_seg, d_out);
+}
+
+
+// ---- layouts: rows as handed over -> what K1 / K2 run fastest on ------------
+static int layout_flags_ok(const char* who, int flags)
+{
+    if (flags & ~(KBBQ_ROWS_PAIRS | KBBQ_ROWS_NIBBLES)) return fail(KBBQ_E_ARG, "%s: unknown layout flags 0x%x", who, flags);
+    return KBBQ_OK;
+}
+
+int kbbq_accumulate_rows_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
+                             const uint32_t* d_meta, int64_t nrows, int pitch, int flags, int R, int S2, int S_band,
+                             int S_min, int minscore, int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    int rc = layout_flags_ok("kbbq_accumulate_rows_dev", flags);
+    if (rc) return rc;
+    const int pairs = (flags & KBBQ_ROWS_PAIRS) ? 1 : 0;
+    if (pairs) { rc = check_pairs("kbbq_accumulate_rows_dev", nrows, S2); if (rc) return rc; }
+    return accumulate_rows(c, "kbbq_accumulate_rows_dev", d_seq, d_cseq, d_qual, d_meta, nrows, pitch, pairs, R, S2, minscore,
+                           dinuc_minscore, d_seg, d_tables, nullptr, pairs ? 0 : S_band, pairs ? 0 : S_min,
+                           (flags & KBBQ_ROWS_NIBBLES) ? 1 : 0);
+}
+
+int kbbq_apply_rows_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta, int64_t nrows,
+                        int pitch, int flags, int R, int S2, int minscore, const void* d_lut_blob, const void* d_pair_lut,
+                        const int64_t* d_seg, const int64_t* d_perm, uint8_t* d_out)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    int rc = layout_flags_ok("kbbq_apply_rows_dev", flags);
+    if (rc) return rc;
+    const int pairs = (flags & KBBQ_ROWS_PAIRS) ? 1 : 0;
+    if (pairs) { rc = check_pairs("kbbq_apply_rows_dev", nrows, S2); if (rc) return rc; }
+    return apply_rows(c, "kbbq_apply_rows_dev", d_seq, d_qual, d_meta, nrows, pitch, pairs, R, S2, minscore, d_lut_blob,
+                      d_pair_lut, d_seg, d_out, (flags & KBBQ_ROWS_NIBBLES) ? 1 : 0, d_perm);
+}
+
+int kbbq_meta_stats_dev(kbbq_ctx* c, const uint32_t* d_meta, int64_t nreads, int32_t* h_stats8)
+{
+    if (!c || !h_stats8) return fail(KBBQ_E_ARG, "kbbq_meta_stats_dev: NULL argument");
+    if (nreads < 0) return fail(KBBQ_E_ARG, "kbbq_meta_stats_dev: nreads < 0");
+    static const int init[K7_NSTATS] = {0x7FFFFFFF, 0, 0, 0, 0, 0, 0, 0};
+    memcpy(h_stats8, init, sizeof init);
+    if (nreads == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->d_stats) HIPCHK(hipMalloc((void**)&c->d_stats, sizeof init));
+    HIPCHK(hipMemcpyAsync(c->d_stats, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    MetaStatsParams p; p.meta = d_meta; p.n = nreads; p.stats = c->d_stats;
+    const int64_t npairs = (nreads + 1) / 2;
+    int gx = (int)std::min<int64_t>((npairs + 255) / 256, (int64_t)c->cus * 8);
+    hipLaunchKernelGGL(k7_meta_stats, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_stats8, c->d_stats, sizeof init, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KBBQ_OK;
+}
+
+size_t kbbq_group_rows_work_bytes(int64_t nrows, int R)
+{
+    const int64_t nblocks = (nrows + K7_SORT_ROWS - 1) / K7_SORT_ROWS;
+    return (size_t)std::max<int64_t>(nblocks, 1) * (size_t)std::max(R, 1) * sizeof(u32);
+}
+
+int kbbq_group_rows_dev(kbbq_ctx* c, const uint32_t* d_meta, int64_t nrows, int pairs, int R, void* d_work,
+                        int64_t* d_perm, int64_t* d_seg)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (nrows < 0 || nrows >= (1ll << 32)) return fail(KBBQ_E_ARG, "kbbq_group_rows_dev: nrows out of range");
+    if (R <= 0 || R > K7_SORT_MAXR) return fail(KBBQ_E_ARG, "kbbq_group_rows_dev: 1 <= R <= %d (got %d)", K7_SORT_MAXR, R);
+    if (!d_meta || !d_work || !d_perm || !d_seg) return fail(KBBQ_E_ARG, "kbbq_group_rows_dev: NULL pointer");
+    HIPCHK(hipSetDevice(c->device));
+    if (nrows == 0) { HIPCHK(hipMemsetAsync(d_seg, 0, (size_t)(R + 1) * 8, c->stream)); return KBBQ_OK; }
+    RgSortParams p;
+    p.meta = d_meta; p.nrows = nrows; p.pairs = pairs ? 1 : 0; p.R = R;
+    p.nblocks = (nrows + K7_SORT_ROWS - 1) / K7_SORT_ROWS;
+    p.hist = reinterpret_cast<u32*>(d_work); p.perm = reinterpret_cast<long long*>(d_perm); p.status = c->d_status;
+    hipLaunchKernelGGL(k7_rg_sort<false>, dim3((unsigned)p.nblocks), dim3(K7_SORT_THREADS), 0, c->stream, p);
+    RgScanParams s;
+    s.hist = p.hist; s.count = p.nblocks * R; s.nblocks = p.nblocks; s.R = R; s.nrows = nrows; s.seg = reinterpret_cast<long long*>(d_seg);
+    hipLaunchKernelGGL(k7_rg_scan, dim3(1), dim3(1024), 0, c->stream, s);
+    hipLaunchKernelGGL(k7_rg_sort<true>, dim3((unsigned)p.nblocks), dim3(K7_SORT_THREADS), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+int kbbq_lay_out_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual, const uint32_t* d_meta,
+                     int64_t nreads, int pitch, int flags, int S2, const int64_t* d_perm,
+                     uint8_t* d_lseq, uint8_t* d_lcseq, uint8_t* d_lqual, uint32_t* d_lmeta)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    int rc = layout_flags_ok("kbbq_lay_out_dev", flags);
+    if (rc) return rc;
+    const int pairs = (flags & KBBQ_ROWS_PAIRS) ? 1 : 0, nib = (flags & KBBQ_ROWS_NIBBLES) ? 1 : 0;
+    rc = check_planes("kbbq_lay_out_dev", nreads, pitch, d_seq, d_cseq, d_qual);
+    if (rc) return rc;
+    if (!d_seq || !d_qual || !d_meta || !d_lseq || !d_lqual || !d_lmeta || (d_cseq && !d_lcseq)) return fail(KBBQ_E_ARG, "kbbq_lay_out_dev: NULL pointer");
+    if (((uintptr_t)d_lseq | (uintptr_t)d_lcseq | (uintptr_t)d_lqual) & 15) return fail(KBBQ_E_ARG, "kbbq_lay_out_dev: planes must be 16-byte aligned");
+    if (pairs) {
+        rc = check_pairs("kbbq_lay_out_dev", nreads / 2, S2);
+        if (rc) return rc;
+        if (nreads & 1) return fail(KBBQ_E_ARG, "kbbq_lay_out_dev: mate-pair rows need an even number of reads");
+        if (pitch < S2 / 2) return fail(KBBQ_E_ARG, "kbbq_lay_out_dev: pitch %d < read length %d", pitch, S2 / 2);
+    }
+    if (nreads == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    LayOutParams p;
+    p.src[0] = d_seq; p.src[1] = d_cseq; p.src[2] = d_qual; p.dst[0] = d_lseq; p.dst[1] = d_lcseq; p.dst[2] = d_lqual;
+    p.meta = d_meta; p.dmeta = d_lmeta; p.perm = reinterpret_cast<const long long*>(d_perm);
+    p.nrows = pairs ? nreads / 2 : nreads; p.pitch = pitch; p.dpitch = pairs ? pair_pitch(S2) : pitch; p.S = pairs ? S2 / 2 : 0;
+    p.pairs = pairs; p.nib = nib; p.status = c->d_status;
+    const int64_t nchunks = p.nrows * (p.dpitch / 16);
+    int gx = (int)std::min<int64_t>((nchunks + 255) / 256, (int64_t)c->cus * 16);
+    hipLaunchKernelGGL(k7_lay_out, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+int kbbq_unpack_nibbles_dev(kbbq_ctx* c, const uint8_t* d_nib, int64_t nbases, uint8_t* d_chars)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (nbases < 0 || (nbases & 15) || ((uintptr_t)d_nib & 7) || ((uintptr_t)d_chars & 15)) return fail(KBBQ_E_ARG, "kbbq_unpack_nibbles_dev: bad size or alignment");
+    if (nbases == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    UnNibParams p; p.src = d_nib; p.dst = d_chars; p.nchunks = nbases / 16;
+    int gx = (int)std::min<int64_t>((p.nchunks + 255) / 256, (int64_t)c->cus * 16);
+    hipLaunchKernelGGL(k7_unpack_nibbles, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
 }
 
 // ---- K4 / K5: benchmark path --------------------------------------------

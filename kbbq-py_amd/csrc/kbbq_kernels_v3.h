@@ -80,6 +80,31 @@ __device__ __forceinline__ u32 k1_increment(u32 xw, u32 zero, u32 both)
     return inc;
 }
 
+
+// ---- 4-bit sequence planes ("packed" layouts) ------------------------------------------------
+// A seq / cseq plane may hold one NIBBLE per base instead of one character: the nucleotide code itself
+// (A0 T1 G2 C3, compare_reads.py:199; 4 = N, the separator and the padding), 8 bytes per 16-base chunk, row
+// stride pitch / 2.  Word w of a chunk (w = 0, 1) carries bases 8w .. 8w+3 in the LOW nibbles of its four bytes and
+// bases 8w+4 .. 8w+7 in the HIGH nibbles, so that `w & 0x0F0F0F0F` and `(w >> 4) & 0x0F0F0F0F` are the codes of four
+// consecutive bases as bytes -- the form the per-base code below (and the quality words) use.  Only reads whose
+// seq AND cseq are entirely ACGTN can be packed (k7_lay_out reports anything else and the caller keeps the
+// byte planes, which carry the reference's exact TypeError semantics); the comparison of A1
+// (recalibrate.py:13-20) is then a comparison of codes.  HBM traffic: K1 2 B/base instead of 3, K2 2.5 instead of 3.
+#define NIBM 0x0F0F0F0Fu
+__device__ __forceinline__ u32 nib_lo(u32 w) { return w & NIBM; }
+__device__ __forceinline__ u32 nib_hi(u32 w) { return (w >> 4) & NIBM; }
+// some nibble of w is not a code (>= 5)
+__device__ __forceinline__ u32 nib_invalid(u32 w) { return (((w & 0x77777777u) + 0x33333333u) | w) & 0x88888888u; }
+// 4 characters -> 4 codes as bytes (0..4), and whether all four are in ACGTN
+__device__ __forceinline__ u32 chars_to_codes(u32 w, u32& bad)
+{
+    const u32 h = (w >> 1) & 0x07070707u;
+    bad |= __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, h) ^ w;
+    return __builtin_amdgcn_perm(0x04040404u, 0x02010300u, h);
+}
+// 4 codes as bytes -> their characters
+__device__ __forceinline__ u32 codes_to_chars(u32 c) { return __builtin_amdgcn_perm(0x4E4E4E4Eu, 0x43475441u, c & 0x07070707u); }
+
 typedef __attribute__((address_space(3))) u32 lds_u32;
 
 struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int k; int j; int nb; };
@@ -95,7 +120,7 @@ struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int k; int j; int nb; };
 //      rows are ordered by the INVERTED quality byte (row = 42 - q, one v_min clamps every
 //      uncounted byte onto the trash row, which is last); bytes past the end of a short read
 //      (quality 0 -> trash) can index beyond the trash row's end: `slack_bytes` absorb that.
-template <bool SPLIT, int DN = K1V3_DNREP>
+template <bool SPLIT, int DN = K1V3_DNREP, bool NIB = false>
 __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -188,8 +213,8 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                 cm = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)(match ? m : 0u));
                 coff = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)(match ? (u32)lane : 0u));
             }
-            const uint8_t* bseq = p.seq + (size_t)read0 * p.pitch;
-            const uint8_t* bcseq = p.cseq + (size_t)read0 * p.pitch;
+            const uint8_t* bseq = p.seq + (size_t)read0 * (NIB ? p.pitch >> 1 : p.pitch);
+            const uint8_t* bcseq = p.cseq + (size_t)read0 * (NIB ? p.pitch >> 1 : p.pitch);
             const uint8_t* bqual = p.qual + (size_t)read0 * p.pitch;
             const int total = n * p.cpr;
             u32 carry_code = 20u, carry_char = 0u;      // 5 * code of the previous chunk's last base
@@ -215,11 +240,17 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
 #else
                 const u32 rowoff = (u32)lane * 16u;      // timing only: every step re-reads the same cached KiB
 #endif
-                const uint4 sv = *reinterpret_cast<const uint4*>(bseq + rowoff);
-                const uint4 cv = *reinterpret_cast<const uint4*>(bcseq + rowoff);
+                if constexpr (NIB) {
+                    const uint2 sv = *reinterpret_cast<const uint2*>(bseq + (rowoff >> 1));
+                    const uint2 cv = *reinterpret_cast<const uint2*>(bcseq + (rowoff >> 1));
+                    ch.s[0] = sv.x; ch.s[1] = sv.y; ch.c[0] = cv.x; ch.c[1] = cv.y;
+                } else {
+                    const uint4 sv = *reinterpret_cast<const uint4*>(bseq + rowoff);
+                    const uint4 cv = *reinterpret_cast<const uint4*>(bcseq + rowoff);
+                    ch.s[0] = sv.x; ch.s[1] = sv.y; ch.s[2] = sv.z; ch.s[3] = sv.w;
+                    ch.c[0] = cv.x; ch.c[1] = cv.y; ch.c[2] = cv.z; ch.c[3] = cv.w;
+                }
                 const uint4 qv = *reinterpret_cast<const uint4*>(bqual + rowoff);
-                ch.s[0] = sv.x; ch.s[1] = sv.y; ch.s[2] = sv.z; ch.s[3] = sv.w;
-                ch.c[0] = cv.x; ch.c[1] = cv.y; ch.c[2] = cv.z; ch.c[3] = cv.w;
                 ch.q[0] = qv.x; ch.q[1] = qv.y; ch.q[2] = qv.z; ch.q[3] = qv.w;
             };
             auto process = [&](const K1Chunk& ch) {
@@ -231,30 +262,48 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                 // byte-parallel decode; alphabet and q-range screening (no byte masks: bytes past
                 // the read are 'N' in seq/cseq and 0 in qual by the layout contract; anything else
                 // only costs a visit to the exact checker)
-                u32 code[4], code5[4], badbits = 0u, hiq = 0u;
+                u32 code[4], code5[4], xw[4], badbits = 0u, hiq = 0u;
+                if constexpr (NIB) {
+                    code[0] = nib_lo(ch.s[0]); code[1] = nib_hi(ch.s[0]); code[2] = nib_lo(ch.s[1]); code[3] = nib_hi(ch.s[1]);
+                    const u32 x0 = ch.s[0] ^ ch.c[0], x1 = ch.s[1] ^ ch.c[1];        // recalibrate.py:13-20 on codes
+                    xw[0] = nib_lo(x0); xw[1] = nib_hi(x0); xw[2] = nib_lo(x1); xw[3] = nib_hi(x1);
+                    badbits = nib_invalid(ch.s[0]) | nib_invalid(ch.s[1]);          // not a plane k7_lay_out wrote
+                }
 #pragma unroll
                 for (int wd = 0; wd < 4; ++wd) {
-                    u32 expect;
-                    decode4x(ch.s[wd], code[wd], code5[wd], expect);
-                    badbits |= expect ^ ch.s[wd];
+                    if constexpr (NIB) {
+                        code5[wd] = (code[wd] << 2) + code[wd];
+                    } else {
+                        u32 expect;
+                        decode4x(ch.s[wd], code[wd], code5[wd], expect);
+                        badbits |= expect ^ ch.s[wd];
+                        xw[wd] = ch.s[wd] ^ ch.c[wd];
+                    }
                     hiq |= (ch.q[wd] + 0x34343434u) | ch.q[wd];                      // bit 7 of a byte: q > 42
                 }
                 hiq &= 0x80808080u;
                 const u32 last_code5 = code5[3] >> 24;
-                const u32 last_char = ch.s[3] >> 24;
                 u32 prev_code5 = wave_shr1(last_code5, carry_code);
-                u32 prev_char = wave_shr1(last_char, carry_char);
                 carry_code = (u32)__builtin_amdgcn_readlane((int)last_code5, 63);
-                carry_char = (u32)__builtin_amdgcn_readlane((int)last_char, 63);
+                u32 prev_char = 0u;
+                if constexpr (!NIB) {
+                    const u32 last_char = ch.s[3] >> 24;
+                    prev_char = wave_shr1(last_char, carry_char);
+                    carry_char = (u32)__builtin_amdgcn_readlane((int)last_char, 63);
+                }
                 if (j == 0) { prev_code5 = 20u; prev_char = 0u; }                    // dinuc[0] = -1
                 if (act) {
                     const long long read = read0 + ch.off;
                     const bool fits_tables = (u32)(len - p.minlen) <= (u32)(p.maxlen - p.minlen);
                     if (hiq || !fits_tables) flag(p.status, ST_INDEX, read);         // recalibrate.py:114-115; read longer (shorter) than the tables
-                    if (badbits && chunk_type_error(ch.s[0], ch.s[1], ch.s[2], ch.s[3], ch.q[0], ch.q[1], ch.q[2], ch.q[3],
-                                                    prev_char, nb, pos0, p.type_minscore))
-                        flag(p.status, ST_TYPE, read);                               // compare_reads.py:224,292
-                    if (!hiq && fits_tables) {
+                    if constexpr (NIB) {
+                        if (badbits) flag(p.status, ST_LUT, 0);                      // the caller must use byte planes
+                    } else {
+                        if (badbits && chunk_type_error(ch.s[0], ch.s[1], ch.s[2], ch.s[3], ch.q[0], ch.q[1], ch.q[2], ch.q[3],
+                                                        prev_char, nb, pos0, p.type_minscore))
+                            flag(p.status, ST_TYPE, read);                           // compare_reads.py:224,292
+                    }
+                    if (!hiq && fits_tables && !(NIB && badbits)) {
                         // A: pos address less the row term; both mates ascend with the base index
                         const u32 half = second ? (u32)(S + 2 * (S - len)) : 0u;     // column 2*len-1-pos
                         const u32 A = pos_base + (half + (u32)pos0) * 4u;
@@ -264,7 +313,7 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                             const u32 pw5 = __builtin_amdgcn_alignbyte(code5[wd], pc5, 3);
                             const u32 d5 = pw5 + code[wd];                            // 5*prev + cur per byte, <= 24
                             pc5 = code5[wd];
-                            const u32 xw = ch.s[wd] ^ ch.c[wd];
+                            const u32 xwd = xw[wd];
                             const u32 qn = ~ch.q[wd];
                             const u32 zero = 0u, both = 0x10001u;
                             auto one_base = [&](auto bsel) {
@@ -272,9 +321,9 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                                 const u32 qi = (qn >> (8 * b)) & 0xFFu;                 // 255 - quality byte
                                 const u32 tq = qi < tclamp ? qi : tclamp;              // below minscore (and padding): trash row
 #ifndef KBBQ_K1_PLAIN_INC
-                                const u32 inc = k1_increment<b>(xw, zero, both);       // recalibrate.py:13-20: errs << 16 | total
+                                const u32 inc = k1_increment<b>(xwd, zero, both);      // recalibrate.py:13-20: errs << 16 | total
 #else
-                                const u32 inc = ((xw >> (8 * b)) & 0xFFu) != 0u ? 0x10001u : 1u;
+                                const u32 inc = ((xwd >> (8 * b)) & 0xFFu) != 0u ? 0x10001u : 1u;
 #endif
                                 const u32 a = __umul24(tq, row_bytes) + A + (u32)(4 * (4 * wd + b));
 #ifndef KBBQ_ABL_NOPOS
@@ -349,7 +398,7 @@ __host__ __device__ __forceinline__ int full_lut_row_bytes(int S2)
     return rb;
 }
 
-struct K2Chunk { u32 s[4], q[4]; u32 mk; int kk; int k; int j; int nb; bool act0; };
+struct K2Chunk { u32 s[4], q[4]; u32 mk; u32 dlo, dhi; int kk; int k; int j; int nb; bool act0; };
 
 struct K2v3Params {
     const uint8_t* seq; const uint8_t* qual; const u32* meta;
@@ -364,9 +413,11 @@ struct K2v3Params {
     int pairs;                 // mate-pair rows: rows the fast path cannot serve are reported (KBBQ_E_LUT), not emulated
     const long long* seg;      // rows grouped by read group: slice blockIdx.y stages only its group's LUT rows; NULL: all groups
     int rpb;                   // rows per wave block (<= 64): a wave's contiguous footprint is rpb * pitch bytes per plane
+    const long long* perm;     // rows grouped by read group: row i is stored as row perm[i] of `out` (straight back into input order); NULL: row i
     uint8_t* out; u64* status;
 };
 
+template <bool NIB = false>
 __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2V3_WAVES, 8))) void k2v3_apply(K2v3Params p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -397,8 +448,9 @@ __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2
         const long long myread = read0 + lane;
         const int n = (int)((seg_hi - read0) < p.rpb ? (seg_hi - read0) : p.rpb);
         const u32 m = lane < n ? p.meta[myread] : 0u;
+        const long long pm = (p.perm && lane < n) ? p.perm[myread] : 0ll;
         const int total = n * p.cpr;
-        const uint8_t* bseq = p.seq + (size_t)read0 * p.pitch;
+        const uint8_t* bseq = p.seq + (size_t)read0 * (NIB ? p.pitch >> 1 : p.pitch);
         const uint8_t* bqual = p.qual + (size_t)read0 * p.pitch;
         uint8_t* bout = p.out + (size_t)read0 * p.pitch;
         u32 carry_code = 20u, carry_char = 0u;
@@ -413,15 +465,21 @@ __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2
             ch.act0 = ch.kk < n;
             ch.k = ch.act0 ? ch.kk : 0;
             ch.mk = bperm(m, ch.k);
+            if (p.perm) { ch.dlo = bperm((u32)pm, ch.k); ch.dhi = bperm((u32)(pm >> 32), ch.k); }
             ch.nb = ch.act0 ? ((int)(ch.mk & 0xFFFFu) - 16 * ch.j) : 0;
 #ifndef KBBQ_ABL_NOLOAD
             const u32 rowoff = ch.nb > 0 ? __umul24((u32)ch.k, (u32)p.pitch) + (u32)(16 * ch.j) : 0u;
 #else
             const u32 rowoff = (u32)lane * 16u;
 #endif
-            const uint4 sv = *reinterpret_cast<const uint4*>(bseq + rowoff);
+            if constexpr (NIB) {
+                const uint2 sv = *reinterpret_cast<const uint2*>(bseq + (rowoff >> 1));
+                ch.s[0] = sv.x; ch.s[1] = sv.y;
+            } else {
+                const uint4 sv = *reinterpret_cast<const uint4*>(bseq + rowoff);
+                ch.s[0] = sv.x; ch.s[1] = sv.y; ch.s[2] = sv.z; ch.s[3] = sv.w;
+            }
             const uint4 qv = *reinterpret_cast<const uint4*>(bqual + rowoff);
-            ch.s[0] = sv.x; ch.s[1] = sv.y; ch.s[2] = sv.z; ch.s[3] = sv.w;
             ch.q[0] = qv.x; ch.q[1] = qv.y; ch.q[2] = qv.z; ch.q[3] = qv.w;
         };
         auto process = [&](const K2Chunk& ch) {
@@ -432,25 +490,36 @@ __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2
             const bool second = (ch.mk >> 31) != 0u;
             const int pos0 = 16 * j;
             u32 code[4], code5[4], badbits = 0u, hiq = 0u;
+            if constexpr (NIB) {
+                code[0] = nib_lo(ch.s[0]); code[1] = nib_hi(ch.s[0]); code[2] = nib_lo(ch.s[1]); code[3] = nib_hi(ch.s[1]);
+                badbits = nib_invalid(ch.s[0]) | nib_invalid(ch.s[1]);
+            }
 #pragma unroll
             for (int wd = 0; wd < 4; ++wd) {
-                u32 expect;
-                decode4x(ch.s[wd], code[wd], code5[wd], expect);
-                badbits |= expect ^ ch.s[wd];
+                if constexpr (NIB) {
+                    code5[wd] = (code[wd] << 2) + code[wd];
+                } else {
+                    u32 expect;
+                    decode4x(ch.s[wd], code[wd], code5[wd], expect);
+                    badbits |= expect ^ ch.s[wd];
+                }
                 hiq |= ((ch.q[wd] & 0x7F7F7F7Fu) + hi_add) | ch.q[wd];
             }
             hiq &= 0x80808080u;
             const u32 last_code5 = code5[3] >> 24;
-            const u32 last_char = ch.s[3] >> 24;
             u32 prev_code5 = wave_shr1(last_code5, carry_code);
-            u32 prev_char = wave_shr1(last_char, carry_char);
             carry_code = (u32)__builtin_amdgcn_readlane((int)last_code5, 63);
-            carry_char = (u32)__builtin_amdgcn_readlane((int)last_char, 63);
+            u32 prev_char = 0u;
+            if constexpr (!NIB) {
+                const u32 last_char = ch.s[3] >> 24;
+                prev_char = wave_shr1(last_char, carry_char);
+                carry_char = (u32)__builtin_amdgcn_readlane((int)last_char, 63);
+            }
             if (j == 0) { prev_code5 = 20u; prev_char = 0u; }
 #ifdef KBBQ_ABL_COPY
             if (ch.act0) {      // timing-only build: the kernel's memory traffic with (almost) no work
                 *reinterpret_cast<uint4*>(bout + (__umul24((u32)k, (u32)p.pitch) + (u32)pos0)) =
-                    make_uint4(ch.q[0] ^ ch.s[0], ch.q[1] ^ ch.s[1], ch.q[2] ^ ch.s[2], ch.q[3] ^ ch.s[3]);
+                    make_uint4(ch.q[0] ^ ch.s[0], ch.q[1] ^ ch.s[1], ch.q[2] ^ ch.s[NIB ? 0 : 2], ch.q[3] ^ ch.s[NIB ? 1 : 3]);
                 return;
             }
 #endif
@@ -458,9 +527,13 @@ __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2
                 u32 o[4] = {0u, 0u, 0u, 0u};
                 if (act) {
                     const long long read = read0 + k;
-                    if (badbits && chunk_type_error(ch.s[0], ch.s[1], ch.s[2], ch.s[3], ch.q[0], ch.q[1], ch.q[2], ch.q[3],
-                                                    prev_char, nb, pos0, p.minscore))
-                        flag(p.status, ST_TYPE, read);
+                    if constexpr (NIB) {
+                        if (badbits) flag(p.status, ST_LUT, 0);                      // not a plane k7_lay_out wrote
+                    } else {
+                        if (badbits && chunk_type_error(ch.s[0], ch.s[1], ch.s[2], ch.s[3], ch.q[0], ch.q[1], ch.q[2], ch.q[3],
+                                                        prev_char, nb, pos0, p.minscore))
+                            flag(p.status, ST_TYPE, read);
+                    }
                     u32 d5[4];
                     u32 pc5 = prev_code5 << 24;
 #pragma unroll
@@ -468,8 +541,8 @@ __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2
                         d5[wd] = __builtin_amdgcn_alignbyte(code5[wd], pc5, 3) + code[wd];   // 5*prev + cur per byte
                         pc5 = code5[wd];
                     }
-                    const bool trouble = hiq != 0u || rg >= p.R || len > p.maxlen || (p.seg && rg != g);
-                    if (trouble && (p.pairs || (p.seg && rg != g))) {
+                    const bool trouble = hiq != 0u || rg >= p.R || len > p.maxlen || (p.seg && rg != g) || (NIB && badbits);
+                    if (trouble && (p.pairs || (p.seg && rg != g) || (NIB && badbits))) {
                         flag(p.status, ST_LUT, 0);                       // the caller re-runs on one-read-per-row planes
                     } else if (trouble) {
                         const uint4 e = chunk_apply_exact(p.lut16, p.rs16, p.R, p.Qt, p.S2, p.qlo, rg, second, pos0, nb,
@@ -502,7 +575,9 @@ __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2
                         }
                     }
                 }
-                *reinterpret_cast<uint4*>(bout + (__umul24((u32)k, (u32)p.pitch) + (u32)pos0)) = make_uint4(o[0], o[1], o[2], o[3]);
+                uint8_t* dst = p.perm ? p.out + (size_t)(((u64)ch.dhi << 32) | ch.dlo) * (size_t)p.pitch + (size_t)pos0
+                                      : bout + (__umul24((u32)k, (u32)p.pitch) + (u32)pos0);
+                *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
             }
         };
 

@@ -141,15 +141,30 @@ class ReadBatch:
     """Device-resident padded SoA of reads: seq / cseq / qual planes [n, pitch] uint8
     and the uint32 sidecar (layout: include/kbbq_hip.h)."""
 
-    def __init__(self, n, pitch, with_corrected=True, device=None):
+    nib = False          # seq / cseq hold one code nibble per base (include/kbbq_hip.h KBBQ_ROWS_NIBBLES)
+    seg = None           # rows grouped by read group: int64 [R + 1] on the device
+    perm = None          # ... and row i of this batch is row perm[i] of the batch it was made from
+
+    def __init__(self, n, pitch, with_corrected=True, device=None, nib=False):
         torch = _torch()
         dev = 'cuda' if device is None else device
-        self.n, self.pitch = int(n), int(pitch)
+        self.n, self.pitch, self.nib = int(n), int(pitch), bool(nib)
         rows = max(self.n, 1)
-        self.seq = torch.empty((rows, pitch), dtype=torch.uint8, device=dev)
+        sp = pitch // 2 if nib else pitch
+        self.seq = torch.empty((rows, sp), dtype=torch.uint8, device=dev)
         self.qual = torch.empty((rows, pitch), dtype=torch.uint8, device=dev)
-        self.cseq = torch.empty((rows, pitch), dtype=torch.uint8, device=dev) if with_corrected else None
+        self.cseq = torch.empty((rows, sp), dtype=torch.uint8, device=dev) if with_corrected else None
         self.meta = torch.empty(rows, dtype=torch.int32, device=dev)
+
+    def describe(self):
+        return _describe(self, 'one read per row, pitch %d' % self.pitch)
+
+    def layout_key(self):
+        return 'reads_nib' if self.nib else 'reads'
+
+    def chars(self, name='seq'):
+        """The seq / cseq plane as characters [n, pitch] whatever the layout stores (tests, debugging)."""
+        return _plane_chars(self, name)
 
     @classmethod
     def from_host(cls, seq, qual, meta, cseq=None, device=None):
@@ -222,17 +237,31 @@ class PairBatch:
     for 2 x 150 bp.  accumulate() / apply() take it like a ReadBatch and give identical results;
     `n` counts rows (pairs)."""
 
-    def __init__(self, npairs, S, with_corrected=True, device=None):
+    nib = False
+    seg = None
+    perm = None
+
+    def __init__(self, npairs, S, with_corrected=True, device=None, nib=False):
         torch = _torch()
         dev = 'cuda' if device is None else device
-        self.n, self.S = int(npairs), int(S)
+        self.n, self.S, self.nib = int(npairs), int(S), bool(nib)
         self.pitch = int(N.load().kbbq_pair_pitch(2 * self.S))
         rows = max(self.n, 1)
-        self.seq = torch.empty((rows, self.pitch), dtype=torch.uint8, device=dev)
+        sp = self.pitch // 2 if nib else self.pitch
+        self.seq = torch.empty((rows, sp), dtype=torch.uint8, device=dev)
         self.qual = torch.empty((rows, self.pitch), dtype=torch.uint8, device=dev)
-        self.cseq = torch.empty((rows, self.pitch), dtype=torch.uint8, device=dev) if with_corrected else None
+        self.cseq = torch.empty((rows, sp), dtype=torch.uint8, device=dev) if with_corrected else None
         self.meta = torch.empty(rows, dtype=torch.int32, device=dev)
         self.read_pitch = None
+
+    def describe(self):
+        return _describe(self, 'mate-pair rows, pitch %d per pair' % self.pitch)
+
+    def layout_key(self):
+        return 'pairs_nib' if self.nib else 'pairs'
+
+    def chars(self, name='seq'):
+        return _plane_chars(self, name)
 
     @staticmethod
     def worthwhile(S, pitch):
@@ -243,17 +272,14 @@ class PairBatch:
     def from_reads(cls, batch):
         """Re-lay a ReadBatch whose reads alternate first / second in pair, all of one length, mates in
         one read group.  ValueError otherwise (use the ReadBatch as it is)."""
-        torch = _torch()
         n = batch.n
-        meta = batch.meta[:n]
         if n == 0 or n % 2:
             raise ValueError('mate-pair rows need an even, non-zero number of reads')
-        lens = meta & 0xFFFF
-        S = int(lens[0].item())
-        first, second = meta[0::2], meta[1::2]
-        ok = bool((lens == S).all().item()) and bool((first >= 0).all().item()) and bool((second < 0).all().item()) \
-            and bool((((first ^ second) >> 16) & 0x7FFF == 0).all().item())
-        if not ok or S == 0:
+        if batch.nib:
+            raise ValueError('mate-pair rows are made from character planes (use lay_out)')
+        st = meta_stats(batch)
+        S = st['longest']
+        if st['pair_violations'] or S == 0:
             raise ValueError('reads are not uniform first/second pairs of one length and read group')
         pb = cls(n // 2, S, with_corrected=batch.cseq is not None, device=batch.seq.device)
         pb.read_pitch = batch.pitch
@@ -273,28 +299,134 @@ class PairBatch:
         return out
 
 
+def meta_stats(batch):
+    """One device pass over the sidecar words of a ReadBatch (k7_meta_stats): shortest non-empty / longest read, largest
+    read-group id, violations of the mate-pair preconditions, empty reads."""
+    ctx = context(batch.meta.device.index)
+    st = np.zeros(8, dtype=np.int32)
+    N.check(N.load().kbbq_meta_stats_dev(ctx.handle, N.ptr(batch.meta), batch.n, N.ptr(st)))
+    shortest = int(st[0]) if st[0] != 0x7FFFFFFF else 0
+    return {'shortest': shortest, 'longest': int(st[1]), 'max_rg': int(st[2]), 'pair_violations': int(st[3]), 'empty': int(st[4])}
+
+
+def _describe(batch, base):
+    if batch.nib:
+        base += ', 4-bit sequence planes'
+    if batch.seg is not None:
+        base += ', rows grouped by read group'
+    return base
+
+
+def _plane_chars(batch, name):
+    torch = _torch()
+    plane = getattr(batch, name)
+    if not batch.nib:
+        return plane
+    out = torch.empty((plane.shape[0], batch.pitch), dtype=torch.uint8, device=plane.device)
+    ctx = context(plane.device.index)
+    N.check(N.load().kbbq_unpack_nibbles_dev(ctx.handle, N.ptr(plane), plane.shape[0] * batch.pitch, N.ptr(out)))
+    return out
+
+
+GROUP_NATIVE_MAX_R = 256
+
+
+def _group_perm(meta, nrows, pairs, R):
+    """(perm, seg) of the stable sort of `nrows` rows by read group (pairs: row = pair, its group the first mate's):
+    the library's counting sort (kbbq_group_rows_dev) up to 256 groups, a torch sort beyond."""
+    torch = _torch()
+    dev_ = meta.device
+    if R <= GROUP_NATIVE_MAX_R:
+        lib = N.load()
+        ctx = context(dev_.index)
+        work = torch.empty(lib.kbbq_group_rows_work_bytes(nrows, R), dtype=torch.uint8, device=dev_)
+        perm = torch.empty(max(nrows, 1), dtype=torch.int64, device=dev_)
+        seg = torch.empty(R + 1, dtype=torch.int64, device=dev_)
+        N.check(lib.kbbq_group_rows_dev(ctx.handle, N.ptr(meta), nrows, 1 if pairs else 0, R, N.ptr(work), N.ptr(perm), N.ptr(seg)))
+        try:
+            ctx.status()
+        except ValueError as e:
+            raise ValueError('a row carries a read group >= R = %d (%s)' % (R, e)) from None
+        return perm[:nrows], seg
+    rg = ((meta[:2 * nrows:2] if pairs else meta[:nrows]) >> 16) & 0x7FFF
+    if nrows and int(rg.max().item()) >= R:
+        raise ValueError('a row carries read group %d but R = %d' % (int(rg.max().item()), R))
+    perm = torch.argsort(rg, stable=True)
+    seg = torch.zeros(R + 1, dtype=torch.int64, device=dev_)
+    seg[1:] = torch.cumsum(torch.bincount(rg, minlength=R), 0)
+    return perm, seg
+
+
+def _lay_out_rows(batch, flags, S2, perm, seg):
+    """kbbq_lay_out_dev: input-order rows -> the destination layout, one pass."""
+    pairs, nib = bool(flags & N.ROWS_PAIRS), bool(flags & N.ROWS_NIBBLES)
+    if pairs:
+        laid = PairBatch(batch.n // 2, S2 // 2, with_corrected=batch.cseq is not None, device=batch.seq.device, nib=nib)
+        laid.read_pitch = batch.pitch
+    elif isinstance(batch, PairBatch):                # pair rows gathered as rows: still pair rows
+        laid = PairBatch(batch.n, batch.S, with_corrected=batch.cseq is not None, device=batch.seq.device, nib=nib)
+        laid.read_pitch = batch.read_pitch
+    else:
+        laid = ReadBatch(batch.n, batch.pitch, with_corrected=batch.cseq is not None, device=batch.seq.device, nib=nib)
+    ctx = context(batch.seq.device.index)
+    N.check(N.load().kbbq_lay_out_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual), N.ptr(batch.meta),
+                                      batch.n, batch.pitch, flags, S2, N.ptr(perm),
+                                      N.ptr(laid.seq), N.ptr(laid.cseq), N.ptr(laid.qual), N.ptr(laid.meta)))
+    laid.seg, laid.perm = seg, perm
+    return laid
+
+
+def lay_out(batch, R, S=None, packed=True, pairs=None, stats=None):
+    """The device layout K1 / K2 run fastest on for this input-order ReadBatch, written in ONE pass
+    (k7_lay_out): mate-pair rows when the reads are uniform first / second pairs of one length and read group (and
+    pair rows are narrower than two rows), rows gathered by read-group segment when R > 1, 4-bit sequence planes when
+    `packed` and every base of seq AND cseq is one of ACGTN (otherwise the pass is repeated with character planes).
+    The result carries `perm` (apply(..., restore_order=True) stores straight back into input order) and `seg`.
+    Returns `batch` itself when no layout applies."""
+    if batch.nib or batch.seg is not None or isinstance(batch, PairBatch):
+        raise ValueError('lay_out takes input-order rows of characters')
+    if batch.n == 0:
+        return batch
+    st = stats or meta_stats(batch)
+    S_ = st['longest']
+    if pairs is None:
+        pairs = batch.n % 2 == 0 and st['pair_violations'] == 0 and S_ > 0 and PairBatch.worthwhile(S_, batch.pitch)
+    elif pairs and (batch.n % 2 or st['pair_violations'] or S_ == 0):
+        raise ValueError('reads are not uniform first/second pairs of one length and read group')
+    flags = (N.ROWS_PAIRS if pairs else 0) | (N.ROWS_NIBBLES if packed else 0)
+    perm = seg = None
+    if R > 1:
+        perm, seg = _group_perm(batch.meta, batch.n // 2 if pairs else batch.n, pairs, R)
+    if not flags and perm is None:
+        return batch
+    ctx = context(batch.seq.device.index)
+    laid = _lay_out_rows(batch, flags, 2 * S_, perm, seg)
+    if packed:
+        try:
+            ctx.status()
+        except N.LutNeedsCheckedApply:                # a base outside ACGTN: character planes keep the exact semantics
+            if not (flags & ~N.ROWS_NIBBLES) and perm is None:
+                return batch
+            laid = _lay_out_rows(batch, flags & ~N.ROWS_NIBBLES, 2 * S_, perm, seg)
+    return laid
+
+
 def group_by_rg(batch, R):
     """The same rows ordered by read group (stable), with `seg` (int64 [R + 1] on the device: group g owns rows
     [seg[g], seg[g + 1])) and `perm` (row i of the result is row perm[i] of `batch`).  accumulate() / apply()
     then run every group at the single-group rate (include/kbbq_hip.h "rows grouped by read group");
-    ungroup() puts an output plane back into the original order.  Works on ReadBatch and PairBatch."""
+    apply(..., restore_order=True) stores straight back into the original order (ungroup() does it as a separate
+    pass).  Works on ReadBatch and PairBatch (character planes)."""
     import copy
-    torch = _torch()
+    if batch.nib:
+        raise ValueError('group_by_rg takes character planes (lay_out groups and packs in one pass)')
     n = batch.n
-    rg = (batch.meta[:n] >> 16) & 0x7FFF
-    if n and int(rg.max().item()) >= R:
-        raise ValueError('a row carries read group %d but R = %d' % (int(rg.max().item()), R))
-    perm = torch.argsort(rg, stable=True)
-    seg = torch.zeros(R + 1, dtype=torch.int64, device=batch.meta.device)
-    seg[1:] = torch.cumsum(torch.bincount(rg, minlength=R), 0)
-    g = copy.copy(batch)
-    for name in ('seq', 'cseq', 'qual'):
-        plane = getattr(batch, name)
-        if plane is not None:
-            setattr(g, name, plane[:n].index_select(0, perm).contiguous() if n else plane)
-    g.meta = batch.meta[:n].index_select(0, perm).contiguous() if n else batch.meta
-    g.seg, g.perm = seg, perm
-    return g
+    perm, seg = _group_perm(batch.meta, n, False, R)
+    if n == 0:
+        g = copy.copy(batch)
+        g.seg, g.perm = seg, perm
+        return g
+    return _lay_out_rows(batch, 0, 2 * getattr(batch, 'S', 0), perm, seg)
 
 
 def ungroup(batch, plane):
@@ -310,40 +442,38 @@ def ungroup(batch, plane):
 _pair_luts = {}
 
 
+def _row_flags(batch):
+    return (N.ROWS_PAIRS if isinstance(batch, PairBatch) else 0) | (N.ROWS_NIBBLES if batch.nib else 0)
+
+
+LONG_READS = 160         # beyond this a band's shortest read decides whether K1's LDS tables fit (kbbq_accumulate_band_dev)
+
+
 def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None, s_band=0, s_min=0):
     """K1 over a device batch, adding into `tables` (recalibrate.py:57-119).  s_band: the longest read of THIS batch
     when it is one length band of a mixed-length input (its rows packed at a narrower pitch than the tables' S):
     the kernel's LDS tables are then laid out for s_band instead of tables.S2 / 2.  s_min: no non-empty read of the
-    batch is shorter (0: unknown); it lets bands of ~200-300-base reads fit the table-driven kernel."""
+    batch is shorter; it lets bands of ~200-300-base reads fit the table-driven kernel.  Left at 0 for such reads,
+    both are measured on the device (k7_meta_stats) before the launch."""
     ctx = context(batch.seq.device.index)
-    if getattr(batch, 'seg', None) is not None:
-        pairs = isinstance(batch, PairBatch)
-        if pairs and tables.S2 != 2 * batch.S:
-            raise ValueError('mate-pair rows of %d-base reads need tables with 2S = %d columns' % (batch.S, 2 * batch.S))
-        N.check(N.load().kbbq_accumulate_grouped_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual),
-                                                     N.ptr(batch.meta), batch.n, batch.pitch, 1 if pairs else 0,
-                                                     tables.R, tables.S2, 0 if pairs else int(s_band),
-                                                     0 if pairs else int(s_min), minscore,
-                                                     minscore if dinuc_minscore is None else dinuc_minscore,
-                                                     N.ptr(batch.seg), N.ptr(tables.buf)))
-        if check:
-            ctx.status()
-        return
-    if isinstance(batch, PairBatch):
-        if tables.S2 != 2 * batch.S:
-            raise ValueError('mate-pair rows of %d-base reads need tables with 2S = %d columns' % (batch.S, 2 * batch.S))
-        N.check(N.load().kbbq_accumulate_pairs_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual),
-                                                   N.ptr(batch.meta), batch.n, tables.R, tables.S2, minscore,
-                                                   minscore if dinuc_minscore is None else dinuc_minscore,
-                                                   N.ptr(tables.buf)))
-        if check:
-            ctx.status()
-        return
-    N.check(N.load().kbbq_accumulate_band_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq),
-                                            N.ptr(batch.qual), N.ptr(batch.meta), batch.n, batch.pitch,
-                                            tables.R, tables.S2, int(s_band), int(s_min), minscore,
-                                            minscore if dinuc_minscore is None else dinuc_minscore,
-                                            N.ptr(tables.buf)))
+    pairs = isinstance(batch, PairBatch)
+    if pairs and tables.S2 != 2 * batch.S:
+        raise ValueError('mate-pair rows of %d-base reads need tables with 2S = %d columns' % (batch.S, 2 * batch.S))
+    if not pairs and not s_min and batch.n and (s_band or tables.S2 // 2) > LONG_READS:
+        st = meta_stats(batch)
+        s_min = st['shortest']
+        s_band = s_band or min(max(st['longest'], 1), tables.S2 // 2)
+    dm = minscore if dinuc_minscore is None else dinuc_minscore
+    if batch.seg is not None or batch.nib or pairs:
+        N.check(N.load().kbbq_accumulate_rows_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual),
+                                                  N.ptr(batch.meta), batch.n, batch.pitch, _row_flags(batch),
+                                                  tables.R, tables.S2, int(s_band), int(s_min), minscore, dm,
+                                                  N.ptr(batch.seg), N.ptr(tables.buf)))
+    else:
+        N.check(N.load().kbbq_accumulate_band_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.cseq),
+                                                  N.ptr(batch.qual), N.ptr(batch.meta), batch.n, batch.pitch,
+                                                  tables.R, tables.S2, int(s_band), int(s_min), minscore, dm,
+                                                  N.ptr(tables.buf)))
     if check:
         ctx.status()
 
@@ -366,21 +496,22 @@ def build_lut(meanq, rgdq, qdq, posdq, dinucdq, minscore=MINSCORE):
     return blob, (R, Qt, S2, N.APPLY_FAST if flags.value == 0 else N.APPLY_CHECKED)
 
 
-def apply(batch, lut_dev, shape, out=None, minscore=MINSCORE, check=True):
+def apply(batch, lut_dev, shape, out=None, minscore=MINSCORE, check=True, restore_order=False):
     """K2 over a device batch: new quality bytes [n, pitch] (compare_reads.py:320-328).
     With check=False the caller must call context().status() itself (and re-run with
-    mode APPLY_CHECKED on LutNeedsCheckedApply)."""
+    mode APPLY_CHECKED on LutNeedsCheckedApply).  restore_order: rows of a batch grouped by read group are stored
+    through its `perm`, i.e. straight back into the row order before the grouping."""
     torch = _torch()
     R, Qt, S2, mode = shape
     ctx = context(batch.seq.device.index)
     if out is None:
         out = torch.empty_like(batch.qual)
     pairs = isinstance(batch, PairBatch)
-    grouped = getattr(batch, 'seg', None) is not None
-    if pairs or grouped:
-        # pair rows use their own layout of the table-driven LUT, derived on the device from the blob; rows the
-        # fast kernel cannot serve (and a LUT that is not range-safe) surface as LutNeedsCheckedApply: re-run on
-        # plain one-read-per-row planes
+    grouped = batch.seg is not None
+    if pairs or grouped or batch.nib:
+        # these layouts use the table-driven LUT only (pair rows: their own layout of it, derived on the device from
+        # the blob); rows the fast kernel cannot serve (and a LUT that is not range-safe) surface as
+        # LutNeedsCheckedApply: re-run on plain one-read-per-row planes
         if Qt != NQ or mode != N.APPLY_FAST or (pairs and S2 != 2 * batch.S):
             raise N.LutNeedsCheckedApply('this layout needs the fast LUT of a %d-column model' % S2)
         lib = N.load()
@@ -392,13 +523,10 @@ def apply(batch, lut_dev, shape, out=None, minscore=MINSCORE, check=True):
                 plut = torch.empty(lib.kbbq_pair_lut_bytes(R, NQ, S2), dtype=torch.uint8, device=batch.seq.device)
                 _pair_luts[key] = plut
             N.check(lib.kbbq_pair_lut_dev(ctx.handle, N.ptr(lut_dev), R, S2, minscore, N.ptr(plut)))
-        if grouped:
-            N.check(lib.kbbq_apply_grouped_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.qual), N.ptr(batch.meta), batch.n,
-                                               batch.pitch, 1 if pairs else 0, R, S2, minscore, N.ptr(lut_dev),
-                                               N.ptr(plut), N.ptr(batch.seg), N.ptr(out)))
-        else:
-            N.check(lib.kbbq_apply_pairs_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.qual), N.ptr(batch.meta), batch.n,
-                                             R, S2, minscore, N.ptr(lut_dev), N.ptr(plut), N.ptr(out)))
+        perm = batch.perm if (restore_order and grouped) else None
+        N.check(lib.kbbq_apply_rows_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.qual), N.ptr(batch.meta), batch.n,
+                                        batch.pitch, _row_flags(batch), R, S2, minscore, N.ptr(lut_dev), N.ptr(plut),
+                                        N.ptr(batch.seg), N.ptr(perm), N.ptr(out)))
         if check:
             ctx.status()
         return out
@@ -460,6 +588,12 @@ def delta_q(prior_q, numerrs, numtotal):
                pq.size, N.ptr(_model_consts()), N.ptr(out)))
     res = out.cpu().numpy().reshape(pq.shape)
     return res - pq if is_float else res.astype(np.int_)
+
+
+def solve_lut(tables, minscore=MINSCORE):
+    """(lut_dev, shape) of solve(): what apply() needs."""
+    lut, shape, _, _ = solve(tables, minscore=minscore)
+    return lut, shape
 
 
 def solve(tables, want_dq=False, minscore=MINSCORE):

@@ -22,6 +22,7 @@ KBBQ_E_RANGE = -5
 KBBQ_E_NAME = -6
 KBBQ_E_LUT = -7
 APPLY_CHECKED, APPLY_FAST = 0, 1
+ROWS_PAIRS, ROWS_NIBBLES = 1, 2
 
 NQ = 43
 NDINUC = 16
@@ -77,6 +78,13 @@ PROTOTYPES = {
     'kbbq_apply_pairs_dev': (_i, [_vp] * 4 + [_i64, _i, _i, _i] + [_vp] * 3),
     'kbbq_accumulate_grouped_dev': (_i, [_vp] * 5 + [_i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'kbbq_apply_grouped_dev': (_i, [_vp] * 4 + [_i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'kbbq_accumulate_rows_dev': (_i, [_vp] * 5 + [_i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'kbbq_apply_rows_dev': (_i, [_vp] * 4 + [_i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'kbbq_meta_stats_dev': (_i, [_vp, _vp, _i64, _vp]),
+    'kbbq_group_rows_work_bytes': (_sz, [_i64, _i]),
+    'kbbq_group_rows_dev': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
+    'kbbq_lay_out_dev': (_i, [_vp] * 5 + [_i64, _i, _i, _i] + [_vp] * 5),
+    'kbbq_unpack_nibbles_dev': (_i, [_vp, _vp, _i64, _vp]),
     'kbbq_sam_open': (_i, [_c.c_char_p, _vp]),
     'kbbq_sam_close': (_i, [_vp]),
     'kbbq_sam_info': (_i, [_vp, _vp]),

@@ -41,6 +41,20 @@ def stage(name, sync=False):
             _events.append((w0, time.time(), name))
 
 
+def collect(enable):
+    """Programmatic form of KBBQ_TIMING (bench.py): collect(True) starts collecting stage times in this process,
+    collect(False) stops and returns {stage: seconds} of what was collected."""
+    global ON
+    if enable:
+        _acc.clear()
+        ON = True
+        return None
+    out = {n: round(s, 4) for n, (s, _) in _acc.items()}
+    _acc.clear()
+    ON = bool(os.environ.get('KBBQ_TIMING'))
+    return out
+
+
 def report(reset=True):
     if ON and _acc:
         total = sum(s for s, _ in _acc.values())

@@ -39,17 +39,15 @@ def _vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore)
     return _solve.vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore)
 
 
-def _lay_out(batch, R, S):
-    """The device layout that moves the fewest bytes / keeps every lane busy for this batch:
-    mate-pair rows for uniform first/second pairs, rows grouped by read group when there are several.  None: the
-    batch stays as it is."""
-    try:
-        laid = dev.PairBatch.from_reads(batch) if dev.PairBatch.worthwhile(S, batch.pitch) else None
-    except ValueError:
-        laid = None                          # not uniform first/second pairs
-    if R > 1:
-        laid = dev.group_by_rg(laid if laid is not None else batch, R)
-    return laid
+def _lay_out(batch, R, S, S_global=None):
+    """The device layout that moves the fewest bytes / keeps every lane busy for this batch, made
+    in one native pass (dev.lay_out): mate-pair rows for uniform first/second pairs, rows gathered by read-group segment
+    when there are several groups, 4-bit sequence planes when every base is one of ACGTN.  None: the batch stays as
+    it is.  Mate-pair rows need count tables of exactly 2S columns, so a band shorter than the input's longest read
+    keeps one read per row."""
+    pairs = None if S_global in (None, S) else False
+    laid = dev.lay_out(batch, R, S, packed=S <= dev.LONG_READS, pairs=pairs)
+    return None if laid is batch else laid
 
 
 def _tally_local(packed, minscore, maxscore):
@@ -73,7 +71,7 @@ def _tally_local(packed, minscore, maxscore):
                 tables.buf += part.buf
                 band['laid'] = laid
                 return
-            except (IndexError, TypeError, dev.N.LutNeedsCheckedApply):
+            except (IndexError, TypeError, ValueError, dev.N.LutNeedsCheckedApply):
                 pass                         # bad input or an unsupported shape: the row-per-read kernel decides
         dev.accumulate(batch, tables, minscore, **hints)
 
@@ -84,7 +82,7 @@ def _tally_local(packed, minscore, maxscore):
                 batch = dev.ReadBatch.from_host(band['seq'], band['qual'], band['meta'], cseq=band['cseq'])
         band['batch'], band['laid'] = batch, None      # still resident: pass 2 re-uses them when it covers file A
         with stage('layout', sync=True):
-            laid = _lay_out(batch, R, band['S'])
+            laid = _lay_out(batch, R, band['S'], S)
         try:
             with stage('K1', sync=True):
                 tally_band(band, batch, laid)
@@ -101,11 +99,9 @@ def _tally(packed, minscore, maxscore):
     exc, tables = None, None
     try:
         tables = _tally_local(packed, minscore, maxscore)
-    except (IndexError, TypeError) as e:
-        if not hasattr(e, 'read_index'):
-            raise
-        exc = e
-    parallel.raise_first_error(exc, None if exc is None else packed.get('first', 0) + max(exc.read_index, 0))
+    except Exception as e:                   # noqa: BLE001 -- whatever stops one rank (bad input, a device error, out of
+        exc = e                              # memory) must stop them all before anybody waits in the allreduce
+    parallel.raise_first_error(exc, None if exc is None else packed.get('first', 0) + max(getattr(exc, 'read_index', 0), 0))
     if tables is not None:
         parallel.allreduce_tables(tables.buf)
     return tables
@@ -188,7 +184,7 @@ def _collective(fn, first=0):
     exc, res = None, None
     try:
         res = fn()
-    except (IndexError, TypeError, ValueError) as e:
+    except Exception as e:                   # noqa: BLE001 -- see _tally
         exc = e
     parallel.raise_first_error(exc, None if exc is None else first + max(getattr(exc, 'read_index', 0), 0))
     return res
@@ -240,15 +236,13 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
                 text = fastx.NativeFastq(fastq[0])                 # a shard's reader: pass 2 needs all of file A
             single = fastx.pack_single(text, infer_rg, shard, bands=True, to_device=True)
         for band in single['bands']:
-            band['laid'] = _lay_out(band['batch'], R, band['S'])
+            band['laid'] = _lay_out(band['batch'], R, band['S'], single['S'])
 
     def apply_band(band):
         laid, out = band.get('laid'), None
         if laid is not None:
             try:
-                out = dev.apply(laid, lut, shape)
-                if getattr(laid, 'seg', None) is not None:
-                    out = dev.ungroup(laid, out)
+                out = dev.apply(laid, lut, shape, restore_order=True)      # grouped rows: stored straight back in input order
                 if isinstance(laid, dev.PairBatch):
                     out = laid.unpack(out)
             except dev.N.LutNeedsCheckedApply:
@@ -282,6 +276,11 @@ def recalibrate_bam(bam, use_oq=False, set_oq=False):
 
 
 def recalibrate(bam, fastq, infer_rg=False, use_oq=False, set_oq=False, gatkreport=None):
+    """Dispatcher of `kbbq recalibrate` (reference recalibrate.py:166-174).  The reference raises NotImplementedError
+    for ANY gatkreport; here `-g` works with FASTQ input (a deliberate, documented divergence: SURVEY.md 8(f) #3), and
+    the cases that stay unimplemented -- no FASTQ input, or a BAM -- raise NotImplementedError as the reference does."""
+    if gatkreport is not None and fastq is None:
+        raise NotImplementedError('GATKreport reading / creation is only implemented for FASTQ input (-f).')
     if bam is not None:
         recalibrate_bam(bam, use_oq, set_oq)
     elif fastq is not None:

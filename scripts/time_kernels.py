@@ -10,14 +10,18 @@ ap.add_argument('--reps', type=int, default=5)
 ap.add_argument('--len', type=int, default=150)
 ap.add_argument('--pairs', action='store_true', help='mate-pair rows instead of one read per row')
 ap.add_argument('--group', action='store_true', help='rows grouped by read group')
+ap.add_argument('--packed', action='store_true', help='the bench layout: dev.lay_out (mate-pair rows, 4-bit sequence planes, grouped by read group)')
 args = ap.parse_args()
 import torch
 from kbbq import _device as dev
 b = dev.ReadBatch.synthetic(0, args.reads, args.reads, seed=1, nrg=args.rgs, len_lo=args.len, len_hi=args.len)
-if args.pairs:
-    b = dev.PairBatch.from_reads(b)
-if args.group:
-    b = dev.group_by_rg(b, args.rgs)
+if args.packed:
+    b = dev.lay_out(b, args.rgs, args.len, packed=True)
+else:
+    if args.pairs:
+        b = dev.PairBatch.from_reads(b)
+    if args.group:
+        b = dev.group_by_rg(b, args.rgs)
 out = torch.empty_like(b.qual)
 t = dev.Tables(args.rgs, 2 * args.len)
 ctx = dev.context()

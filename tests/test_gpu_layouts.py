@@ -1,0 +1,216 @@
+"""
+GPU tests (-m gpu) of the native layout passes (csrc/kbbq_layout_kernels.h, include/kbbq_hip.h "layouts in one
+interface"): sidecar statistics, the counting sort by read group, the one-pass lay_out (pair packing + gather by
+read-group segment + 4-bit sequence planes) and K1 / K2 on what it writes, K2's store through the permutation.
+Everything is compared with the CPU oracle on the same seeded reads (bit-exact: integer / byte work).
+"""
+import numpy as np
+import pytest
+
+from test_gpu_parity import dev                      # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _host(b, n):
+    return [x[:n].cpu().numpy() for x in (b.seq, b.cseq, b.qual)] + [b.meta[:n].cpu().numpy().view(np.uint32)]
+
+
+def _oracle_run(oracle, seq, cseq, qual, meta, R, S, minscore=6):
+    want = oracle.accumulate(seq, cseq, qual, meta, R, S, minscore=minscore)
+    dqs = oracle.get_delta_qs(*want)
+    ref = oracle.apply(seq, qual, meta, want[0], *dqs, minscore=minscore)
+    return want, ref
+
+
+def test_meta_stats(dev):
+    import torch
+    b = dev.ReadBatch.synthetic(0, 5000, 5000, seed=5, len_lo=36, len_hi=150, nrg=7)
+    meta = b.meta[:5000].cpu().numpy().view(np.uint32)
+    lens = (meta & 0xFFFF).astype(int)
+    st = dev.meta_stats(b)
+    assert st['shortest'] == lens[lens > 0].min() and st['longest'] == lens.max()
+    assert st['max_rg'] == int(((meta >> 16) & 0x7FFF).max()) and st['empty'] == int((lens == 0).sum())
+    assert st['pair_violations'] > 0                       # lengths differ
+    u = dev.ReadBatch.synthetic(0, 4000, 4000, seed=6, nrg=3)
+    assert dev.meta_stats(u)['pair_violations'] == 0
+    good = u.meta[:4000].cpu().numpy().view(np.uint32).copy()
+
+    def with_meta(m):
+        u.meta[:4000].copy_(torch.from_numpy(m.view(np.int32)))
+        return dev.meta_stats(u)['pair_violations']
+    m = good.copy(); m[1001] &= 0x7FFFFFFF                   # a "second" read that claims to be first
+    assert with_meta(m) == 1
+    m = good.copy(); m[2000] = (m[2000] & ~np.uint32(0x7FFF0000)) | np.uint32((((m[2000] >> 16) & 0x7FFF) + 1) % 3 << 16)
+    assert with_meta(m) == 1                                 # mates in different read groups
+    m = good.copy(); m[3000] = (m[3000] & ~np.uint32(0xFFFF)) | np.uint32(149)
+    assert with_meta(m) == 1                                 # one read of another length
+    assert with_meta(good) == 0
+    e = dev.ReadBatch.synthetic(0, 7, 7, seed=1)
+    assert dev.meta_stats(e)['pair_violations'] >= 1      # odd number of reads
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('n,R,pairs', [(9000, 8, False), (9000, 8, True), (4096 * 3 + 17, 3, False), (70, 256, False),
+                                       (200000, 5, True), (2, 1, True)])
+def test_group_rows_is_the_stable_sort(dev, n, R, pairs):
+    import torch
+    n -= n % 2
+    b = dev.ReadBatch.synthetic(0, n, n, seed=9 + R, nrg=R)
+    nrows = n // 2 if pairs else n
+    perm, seg = dev._group_perm(b.meta, nrows, pairs, R)
+    meta = b.meta[:n].cpu().numpy().view(np.uint32)
+    rg = ((meta[0::2] if pairs else meta) >> 16) & 0x7FFF
+    want = np.argsort(rg, kind='stable')
+    assert np.array_equal(perm.cpu().numpy(), want)
+    assert np.array_equal(seg.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(rg, minlength=R))]))
+    if int(rg.max()) > 0:
+        with pytest.raises(ValueError):                      # a sidecar with a read group the caller did not announce
+            dev._group_perm(b.meta, nrows, pairs, int(rg.max()))
+
+
+@pytest.mark.parametrize('S,R,n', [(150, 1, 6002), (150, 8, 20000), (100, 3, 4000), (151, 2, 3000), (16, 2, 1280),
+                                   (75, 1, 2000), (33, 5, 2000)])
+def test_lay_out_tally_and_apply_match_the_oracle(dev, oracle, S, R, n):
+    import torch
+    b = dev.ReadBatch.synthetic(0, n, n, seed=21 + S + R, len_lo=S, len_hi=S, nrg=R)
+    seq, cseq, qual, meta = _host(b, n)
+    want, ref = _oracle_run(oracle, seq, cseq, qual, meta, R, S)
+    laid = dev.lay_out(b, R, S, packed=True)
+    pair_rows = dev.PairBatch.worthwhile(S, b.pitch)
+    assert laid.nib and isinstance(laid, dev.PairBatch) == pair_rows and (laid.seg is not None) == (R > 1)
+    # the planes: characters recovered from the nibbles equal the character layout of the same rows
+    plain = dev.lay_out(b, R, S, packed=False)
+    if plain is b:
+        assert not pair_rows and R == 1
+    for name in ('seq', 'cseq'):
+        assert torch.equal(laid.chars(name)[:laid.n], getattr(plain, name)[:laid.n])
+    assert torch.equal(laid.qual[:laid.n], plain.qual[:laid.n]) and torch.equal(laid.meta[:laid.n], plain.meta[:laid.n])
+    # K1
+    t = dev.Tables(R, 2 * S)
+    dev.accumulate(laid, t)
+    for got, w in zip(t.to_host(), want[5:9]):
+        assert np.array_equal(got, w)
+    # K3 -> K2, stored straight back into input order
+    lut, shape, _, _ = dev.solve(t)
+    out = dev.apply(laid, lut, shape, restore_order=True)
+    if pair_rows:
+        out = laid.unpack(out, b.pitch)
+    assert np.array_equal(out[:n, :S].cpu().numpy().astype(np.int32) - 33, ref[:, :S])
+    # ... and in grouped order + ungroup, the separate-pass form
+    out2 = dev.apply(laid, lut, shape)
+    if laid.seg is not None:
+        out2 = dev.ungroup(laid, out2)
+    if pair_rows:
+        out2 = laid.unpack(out2, b.pitch)
+    assert torch.equal(out2[:n], out[:n])
+
+
+def test_lay_out_ragged_rows_keep_one_read_per_row(dev, oracle):
+    n, R = 5000, 4
+    b = dev.ReadBatch.synthetic(0, n, n, seed=77, len_lo=36, len_hi=150, nrg=R)
+    seq, cseq, qual, meta = _host(b, n)
+    want, ref = _oracle_run(oracle, seq, cseq, qual, meta, R, 150)
+    laid = dev.lay_out(b, R, 150, packed=True)
+    assert laid.nib and not isinstance(laid, dev.PairBatch) and laid.seg is not None
+    t = dev.Tables(R, 300)
+    dev.accumulate(laid, t)
+    for got, w in zip(t.to_host(), want[5:9]):
+        assert np.array_equal(got, w)
+    lut, shape, _, _ = dev.solve(t)
+    out = dev.apply(laid, lut, shape, restore_order=True)[:n].cpu().numpy().astype(np.int32)
+    lens = (meta & 0xFFFF).astype(int)
+    for i in (0, 1, 17, 999, n - 1):
+        assert np.array_equal(out[i, :lens[i]] - 33, ref[i, :lens[i]]) and not out[i, lens[i]:].any()
+    mask = np.arange(b.pitch)[None, :] < lens[:, None]
+    assert np.array_equal((out - 33)[mask], ref[mask])
+
+
+def test_a_base_outside_acgtn_keeps_character_planes(dev, oracle):
+    """4-bit planes exist only for ACGTN batches: anything else stays in character planes, which carry the reference's
+    TypeError rule (compare_reads.py:281-293) -- here a letter that is never looked up, so the run succeeds."""
+    import torch
+    n, S = 4000, 150
+    b = dev.ReadBatch.synthetic(0, n, n, seed=4)
+    b.seq[10, 5] = ord('X'); b.cseq[10, 5] = ord('X')
+    b.qual[10, 5] = 33 + 2; b.qual[10, 6] = 33 + 3          # below minscore: neither (4,5) nor (5,6) is looked up
+    seq, cseq, qual, meta = _host(b, n)
+    want, ref = _oracle_run(oracle, seq, cseq, qual, meta, 1, S)
+    laid = dev.lay_out(b, 1, S, packed=True)
+    assert isinstance(laid, dev.PairBatch) and not laid.nib
+    t = dev.Tables(1, 2 * S)
+    dev.accumulate(laid, t)
+    for got, w in zip(t.to_host(), want[5:9]):
+        assert np.array_equal(got, w)
+    # only the corrected read differs from ACGTN: still not packable (the comparison of codes would lose the letter)
+    c = dev.ReadBatch.synthetic(0, n, n, seed=4)
+    c.cseq[3, 7] = ord('a')
+    assert not dev.lay_out(c, 1, S, packed=True).nib
+    # a looked-up bad letter is the reference's TypeError, from the character planes
+    d = dev.ReadBatch.synthetic(0, n, n, seed=4)
+    d.seq[10, 5] = ord('X'); d.qual[10, 5] = 33 + 30; d.seq[10, 4] = ord('A')
+    laid = dev.lay_out(d, 1, S, packed=True)
+    assert not laid.nib
+    with pytest.raises(TypeError):
+        dev.accumulate(laid, dev.Tables(1, 2 * S))
+    torch.cuda.synchronize()
+
+
+def test_corrupt_nibble_planes_are_reported(dev):
+    n, S = 2000, 150
+    b = dev.ReadBatch.synthetic(0, n, n, seed=8)
+    laid = dev.lay_out(b, 1, S, packed=True)
+    assert laid.nib
+    laid.seq[5, 3] = 0x7F                                    # nibbles 15 and 7: not codes
+    with pytest.raises(dev.N.LutNeedsCheckedApply):
+        dev.accumulate(laid, dev.Tables(1, 2 * S))
+
+
+@pytest.mark.parametrize('minscore', [2, 6, 20])
+def test_minscore_on_packed_rows(dev, oracle, minscore):
+    n, S, R = 4000, 150, 2
+    b = dev.ReadBatch.synthetic(0, n, n, seed=31, nrg=R, qlo=2)
+    seq, cseq, qual, meta = _host(b, n)
+    want, ref = _oracle_run(oracle, seq, cseq, qual, meta, R, S, minscore=minscore)
+    laid = dev.lay_out(b, R, S, packed=True)
+    t = dev.Tables(R, 2 * S)
+    dev.accumulate(laid, t, minscore)
+    for got, w in zip(t.to_host(), want[5:9]):
+        assert np.array_equal(got, w)
+    lut, shape, _, _ = dev.solve(t, minscore=minscore)
+    out = laid.unpack(dev.apply(laid, lut, shape, minscore=minscore, restore_order=True), b.pitch)
+    assert np.array_equal(out[:n, :S].cpu().numpy().astype(np.int32) - 33, ref[:, :S])
+
+
+def test_long_reads_measure_their_shortest_read_on_the_device(dev, oracle):
+    """Plain accumulate() on 300-base reads: the shortest-read promise that lets K1's LDS tables fit is measured by
+    k7_meta_stats instead of coming from the file path's length bands (no first-generation fallback)."""
+    n, S = 3000, 300
+    b = dev.ReadBatch.synthetic(0, n, n, seed=12, len_lo=280, len_hi=300)
+    seq, cseq, qual, meta = _host(b, n)
+    order = np.argsort(meta & 0xFFFF, kind='stable')         # the reference needs non-decreasing lengths
+    want = oracle.accumulate(seq[order], cseq[order], qual[order], meta[order], 1, S)
+    t = dev.Tables(1, 2 * S)
+    ctx = dev.context()
+    ctx.timing(True)
+    dev.accumulate(b, t)
+    ctx.timing(False)
+    for got, w in zip(t.to_host(), want[5:9]):
+        assert np.array_equal(got, w)
+
+
+def test_large_packed_batch_properties(dev):
+    """BASELINE-sized property checks that need no oracle: counts add up, output of the packed layout equals the
+    character layout's, bytes past the reads stay zero."""
+    import torch
+    n, S = 4_000_000, 150
+    b = dev.ReadBatch.synthetic(0, n, n, seed=1)
+    laid = dev.lay_out(b, 1, S, packed=True)
+    plain = dev.lay_out(b, 1, S, packed=False)
+    t1, t2 = dev.Tables(1, 2 * S), dev.Tables(1, 2 * S)
+    dev.accumulate(laid, t1); dev.accumulate(plain, t2)
+    assert torch.equal(t1.buf, t2.buf)
+    pe, pt, de, dt = t1.views()
+    assert int(pt.sum()) == int(((b.qual[:n, :S] >= 33 + 6)).sum())
+    lut, shape, _, _ = dev.solve(t1)
+    assert torch.equal(dev.apply(laid, lut, shape), dev.apply(plain, lut, shape))
