@@ -346,9 +346,9 @@ def test_dispatcher_errors():
         recalibrate.recalibrate_bam(None)
     with pytest.raises(NotImplementedError):
         recalibrate.recalibrate(fastq=None, bam='foo')
-    # the reference raises NotImplementedError for any gatkreport (recalibrate.py:167-168); here the
-    # option is implemented, so without an input it is the ValueError below
-    with pytest.raises(ValueError):
+    # the reference raises NotImplementedError for any gatkreport (recalibrate.py:167-168, tests/test_recalibrate.py:113-114);
+    # here the option is implemented for FASTQ input and every other use of it raises as the reference does
+    with pytest.raises(NotImplementedError):
         recalibrate.recalibrate(fastq=None, bam=None, gatkreport='foo')
     with pytest.raises(NotImplementedError):
         recalibrate.recalibrate(fastq=None, bam='foo', gatkreport='foo')
