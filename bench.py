@@ -267,7 +267,7 @@ def timed_steps(torch, dist, use_dist, dev, parallel, res, steps, warmup, rehear
             b.record()
             if timed:
                 ar_events.append((a, b))
-        lut, shape = dev.solve_lut(res.tables)
+        lut, shape = dev.solve_lut(res.tables, check=False)
         dev.apply(res.batch, lut, shape, out=res.out, check=False, restore_order=restore_order)
 
     def fence():
@@ -471,8 +471,8 @@ def build_extra(torch, dev, parallel, args, headline_layout):
     for key, fn in (('config3_8rg', lambda: extra_config3(torch, dev, parallel, n, small, 1)),
                     ('layout_pairs', lambda: extra_layout(torch, dev, parallel, n, small, 1, 'pairs')),
                     ('layout_reads', lambda: extra_layout(torch, dev, parallel, n, small, 1, 'reads')),
-                    ('aligned_read_kernels', lambda: extra_aligned(torch, dev)),
-                    ('file_path', lambda: extra_file_path(torch, dev))):
+                    ('aligned_read_kernels', lambda: extra_aligned(torch, dev, n=min(4_000_000, n), G=min(200_000_000, 50 * n))),
+                    ('file_path', lambda: extra_file_path(torch, dev, n=min(8_000_000, n)))):
         if key == 'layout_' + headline_layout:
             continue
         t0 = time.perf_counter()
@@ -488,6 +488,8 @@ def build_extra(torch, dev, parallel, args, headline_layout):
 
 # ---------------------------------------------------------------- one rank
 def run_rank(args):
+    if int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started %s ranks' % (args.gpus, os.environ.get('WORLD_SIZE', '1')))
     # stdout carries exactly ONE JSON line: library banners (RCCL prints its version to stdout under
     # NCCL_DEBUG=VERSION) are sent to stderr until the result is printed
     sys.stdout.flush()
@@ -499,8 +501,6 @@ def run_rank(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        raise SystemExit('bench.py: --gpus %d but the launcher started %d ranks' % (args.gpus, world))
     use_dist = 'RANK' in os.environ                 # launched by torch.distributed.run (any N, also 1)
     # fewer devices than ranks (a one-GPU box): every rank on the devices that exist, gloo instead of RCCL --
     # a functional rehearsal of the N > 1 path; its numbers mean nothing (KBBQ_BENCH_REHEARSE=gloo forces it)

@@ -52,6 +52,7 @@ extern "C" {
 #define KBBQ_E_RANGE    -5   /* recalibrated quality + 33 outside 0..255     */
 #define KBBQ_E_NAME     -6   /* corrected read name does not start with the read name    */
 #define KBBQ_E_LUT      -7   /* a device-built LUT needs kbbq_apply_dev(KBBQ_APPLY_CHECKED)  */
+#define KBBQ_E_MEANQ    -8   /* kbbq_solve_device_dev: meanq sits on a truncation boundary, solve with the host's longdouble meanq */
 
 #define KBBQ_APPLY_CHECKED 0 /* per-base range test, int16 LUT                            */
 #define KBBQ_APPLY_FAST    1 /* table-driven int8 LUT, no per-base tests (LUT flags == 0) */
@@ -204,6 +205,26 @@ int    kbbq_combiln_host(const int64_t* errs, const int64_t* total, int64_t ncel
  * and aux = the gammaln term of every cell in kbbq_solve_dev's order [rg R | q R*43 | pos R*43*S2 | dinuc R*43*16]. */
 int kbbq_solve_prep_host(const int64_t* tables, int R, int S2, double* aux, int64_t* marg, int threads);
 int    kbbq_gammaln_host(const double* x, int64_t n, double* out);
+/* The solve without the host (csrc/lgam_core.h): kbbq_libm_log_data reads the constants of the host libm's own log()
+ * (ln 2 split in two, 5 coefficients, 128 x {1/c, log c}: 263 doubles) out of the mapped library, so that a kernel can
+ * evaluate the same gammaln bit for bit; KBBQ_E_HIP when they are not found (then kbbq_solve_dev's host-fed form stays
+ * in use).  kbbq_gammaln_restated_host evaluates that restatement on the host (no call into libm; x integer-valued
+ * and >= 1), kbbq_gammaln_dev on the device: the caller checks either against kbbq_gammaln_host before relying on
+ * kbbq_solve_device_dev.  */
+int    kbbq_libm_log_data(double* out263, int count);
+int    kbbq_gammaln_restated_host(const double* x, int64_t n, const double* logtab263, double* out);
+int    kbbq_gammaln_dev(kbbq_ctx* ctx, const double* d_x, int64_t n, const double* d_logtab263, double* d_out);
+/* kbbq_solve_dev with NOTHING from the host inside the step: marginals, the gammaln term of every cell (d_logtab263:
+ * kbbq_libm_log_data's table on the device) and meanq = p_to_q(sum_q q_total[q] * 10^(-q/10) / rg_total)
+ * (recalibrate.py:111,120; compare_reads.py:262-271) are formed by the kernels.  h_consts172 = the 129 model constants
+ * of kbbq_solve_dev + the 43 float64 values q_to_p(q).  meanq is a TRUNCATION of a longdouble quotient in the
+ * reference; the kernel forms it in double precision and, when -10 log10(mean) lies within 1e-7 of an integer (where
+ * the reference's own 80-bit rounding decides; always so when a read group has one quality value only) or a read
+ * group has no counted base, reports KBBQ_E_MEANQ through kbbq_ctx_status: the caller then solves through
+ * kbbq_solve_dev with the host's longdouble meanq.  d_meanq_out [R] (may be NULL) receives the kernel's meanq.   */
+int    kbbq_solve_device_dev(kbbq_ctx* ctx, const int64_t* d_tables, int R, int S2, int minscore,
+                             const double* d_logtab263, const double* h_consts172, int32_t* d_post_q,
+                             void* d_lut, int32_t* d_dq, int32_t* d_meanq_out);
 size_t kbbq_solve_aux_count(int R, int S2);
 size_t kbbq_solve_dq_count(int R, int S2);
 int    kbbq_solve_dev(kbbq_ctx* ctx, const int64_t* d_tables, int R, int S2, int minscore,

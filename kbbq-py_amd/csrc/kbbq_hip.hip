@@ -43,7 +43,7 @@ struct kbbq_ctx {
     char name[128] = {0};
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    u64* d_status = nullptr;          // [4]
+    u64* d_status = nullptr;          // [KBBQ_NSTATUS]
     int* d_stats = nullptr;           // [K7_NSTATS] scratch of kbbq_meta_stats_dev
     bool timing = false;
     // per-kernel event pairs recorded while timing is on
@@ -52,7 +52,8 @@ struct kbbq_ctx {
     int64_t launches[2] = {0, 0};
 };
 
-static const u64 ST_INIT[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+#define KBBQ_NSTATUS 8
+static const u64 ST_INIT[KBBQ_NSTATUS] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
 
 extern "C" {
 
@@ -151,15 +152,20 @@ int kbbq_ctx_status(kbbq_ctx* c, int64_t* read_index)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
-    u64 st[4];
+    u64 st[KBBQ_NSTATUS];
     HIPCHK(hipMemcpyAsync(st, c->d_status, sizeof st, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (read_index) *read_index = -1;
-    if (st[0] == ~0ull && st[1] == ~0ull && st[2] == ~0ull && st[3] == ~0ull) return KBBQ_OK;
+    if (st[0] == ~0ull && st[1] == ~0ull && st[2] == ~0ull && st[3] == ~0ull && st[ST_MEANQ] == ~0ull) return KBBQ_OK;
     HIPCHK(hipMemcpyAsync(c->d_status, ST_INIT, sizeof ST_INIT, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     // the reference stops at the FIRST offending read; within one read the dinucleotide
     // lookup (TypeError, recalibrate.py:94) runs before the table indexing (IndexError, :114)
+    if (st[0] == ~0ull && st[1] == ~0ull && st[2] == ~0ull && st[ST_MEANQ] != ~0ull) {
+        if (read_index) *read_index = (int64_t)st[ST_MEANQ];
+        return fail(KBBQ_E_MEANQ, "read group %lld: meanq lies on a truncation boundary (or the group has no counted base): "
+                    "solve through kbbq_solve_dev with the host's longdouble meanq", (long long)st[ST_MEANQ]);
+    }
     if (st[0] == ~0ull && st[1] == ~0ull && st[2] == ~0ull)
         return fail(KBBQ_E_LUT, "the device-built LUT can leave 0..255 or does not fit int8: re-run kbbq_apply_dev in checked mode");
     int code = KBBQ_E_TYPE; u64 best = st[ST_TYPE];
@@ -586,6 +592,8 @@ int kbbq_posterior_q_dev(kbbq_ctx* c, const double* d_prior_q, const int64_t* d_
 size_t kbbq_solve_aux_count(int R, int S2) { return (size_t)R + (size_t)R * KQ + (size_t)R * KQ * S2 + (size_t)R * KQ * KND; }
 size_t kbbq_solve_dq_count(int R, int S2) { return (size_t)R + (size_t)R * KQ + (size_t)R * KQ * S2 + (size_t)R * KQ * 17; }
 
+static int launch_solve(kbbq_ctx* c, K3FusedParams& p, int minscore);
+
 int kbbq_solve_dev(kbbq_ctx* c, const int64_t* d_tables, int R, int S2, int minscore, const int32_t* d_meanq,
                    const double* d_aux, const double* h_consts129, int32_t* d_post_q,
                    void* d_lut, int32_t* d_dq)
@@ -597,8 +605,17 @@ int kbbq_solve_dev(kbbq_ctx* c, const int64_t* d_tables, int R, int S2, int mins
     K3FusedParams p;
     p.tables = (const long long*)d_tables; p.R = R; p.S2 = S2; p.rs = lut_row_stride(S2);
     p.meanq = d_meanq; p.aux = d_aux; p.post_q = d_post_q; p.lut = reinterpret_cast<int16_t*>(d_lut); p.dq = d_dq;
+    p.logtab = nullptr; p.meanq_out = nullptr; p.status = c->d_status;
+    memset(p.perr, 0, sizeof p.perr);
     int rc = load_consts(p.c, h_consts129);
     if (rc) return rc;
+    return launch_solve(c, p, minscore);
+}
+
+static int launch_solve(kbbq_ctx* c, K3FusedParams& p, int minscore)
+{
+    const int R = p.R, S2 = p.S2;
+    void* d_lut = p.lut;
     hipLaunchKernelGGL(k3_levels_ab, dim3((unsigned)R), dim3(1024), 0, c->stream, p);
     const int64_t cells = (int64_t)R * KQ * ((int64_t)S2 + KND);              // one wave per cell
     int gx = (int)std::min<int64_t>((cells + 3) / 4, (int64_t)c->cus * 32);
@@ -612,6 +629,36 @@ int kbbq_solve_dev(kbbq_ctx* c, const int64_t* d_tables, int R, int S2, int mins
     f.status = c->d_status;
     HIPCHK(hipMemsetAsync(f.flags, 0, 16, c->stream));
     hipLaunchKernelGGL(k3_fill_full_lut, dim3((unsigned)(R * (33 + KQ))), dim3(256), 0, c->stream, f);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+int kbbq_solve_device_dev(kbbq_ctx* c, const int64_t* d_tables, int R, int S2, int minscore, const double* d_logtab,
+                          const double* h_consts172, int32_t* d_post_q, void* d_lut, int32_t* d_dq, int32_t* d_meanq_out)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (R <= 0 || R > 32767 || S2 <= 0 || S2 > 65536) return fail(KBBQ_E_ARG, "kbbq_solve_device_dev: bad shape R=%d S2=%d", R, S2);
+    if (!d_tables || !d_logtab || !h_consts172 || !d_post_q || !d_lut) return fail(KBBQ_E_ARG, "kbbq_solve_device_dev: NULL pointer");
+    HIPCHK(hipSetDevice(c->device));
+    K3FusedParams p;
+    p.tables = (const long long*)d_tables; p.R = R; p.S2 = S2; p.rs = lut_row_stride(S2);
+    p.meanq = nullptr; p.aux = nullptr; p.post_q = d_post_q; p.lut = reinterpret_cast<int16_t*>(d_lut); p.dq = d_dq;
+    p.logtab = d_logtab; p.meanq_out = d_meanq_out; p.status = c->d_status;
+    memcpy(p.perr, h_consts172 + 3 * KSOLVE_NQ, sizeof p.perr);
+    int rc = load_consts(p.c, h_consts172);
+    if (rc) return rc;
+    return launch_solve(c, p, minscore);
+}
+
+int kbbq_gammaln_dev(kbbq_ctx* c, const double* d_x, int64_t n, const double* d_logtab, double* d_out)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (n < 0 || (n > 0 && (!d_x || !d_out)) || !d_logtab) return fail(KBBQ_E_ARG, "kbbq_gammaln_dev: bad argument");
+    if (n == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    K3GammalnParams p; p.x = d_x; p.n = n; p.logtab = d_logtab; p.out = d_out;
+    int gx = (int)std::min<int64_t>((n + 255) / 256, (int64_t)c->cus * 8);
+    hipLaunchKernelGGL(k3_gammaln, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
 }

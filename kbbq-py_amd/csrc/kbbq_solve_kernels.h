@@ -11,6 +11,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "solve_core.h"
+#include "lgam_core.h"
+
+#ifndef ST_MEANQ
+#define ST_MEANQ 4   // status word: a read group whose meanq the all-device solve cannot decide (see k3_levels_ab)
+#endif
 
 struct K3CellParams {
     const long long* prior_q; const long long* errs; const long long* total; const double* comb;
@@ -26,7 +31,25 @@ struct K3FusedParams {
     int16_t* lut;                // K2 layout, rows of rs
     int* dq;                     // optional [rgdq R | qdq R*43 | posdq R*43*S2 | dinucdq R*43*17]
     SolveConsts c;
+    // all-device form (aux == NULL): the gammaln terms come from csrc/lgam_core.h over `logtab` (the host libm's own
+    // constants, 263 doubles on the device), meanq from the marginals and perr[q] = q_to_p(q)
+    const double* logtab;
+    double perr[KSOLVE_NQ];
+    int* meanq_out;              // optional [R]
+    unsigned long long* status;
 };
+
+struct K3GammalnParams { const double* x; long long n; const double* logtab; double* out; };
+
+// gammaln of integer-valued arguments >= 1 through csrc/lgam_core.h (self-check and tests of the all-device solve)
+__global__ __launch_bounds__(256) void k3_gammaln(K3GammalnParams p)
+{
+    __shared__ double T[LGAM_LOGTAB_DOUBLES];
+    for (int i = threadIdx.x; i < LGAM_LOGTAB_DOUBLES; i += blockDim.x) T[i] = p.logtab[i];
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long long)gridDim.x * blockDim.x)
+        p.out[i] = lgam_count(p.x[i], T);
+}
 
 __global__ __launch_bounds__(256) void k3_delta_q(K3CellParams p)
 {
@@ -108,10 +131,16 @@ __global__ __launch_bounds__(1024) void k3_levels_ab(K3FusedParams p)
 {
     __shared__ long long qe[KSOLVE_NQ], qt[KSOLVE_NQ];
     __shared__ double sc[3 * KSOLVE_NQ];
+    __shared__ double T[LGAM_LOGTAB_DOUBLES];
+    __shared__ double perr[KSOLVE_NQ];
     __shared__ int post_rg;
     const int r = blockIdx.x, lane = k3_lane(), wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6);
     for (int i = threadIdx.x; i < 3 * KSOLVE_NQ; i += blockDim.x)
         sc[i] = i < KSOLVE_NQ ? p.c.prior[i] : i < 2 * KSOLVE_NQ ? p.c.logp[i - KSOLVE_NQ] : p.c.log1mp[i - 2 * KSOLVE_NQ];
+    if (!p.aux) {
+        for (int i = threadIdx.x; i < LGAM_LOGTAB_DOUBLES; i += blockDim.x) T[i] = p.logtab[i];
+        for (int i = threadIdx.x; i < KSOLVE_NQ; i += blockDim.x) perr[i] = p.perr[i];
+    }
     const size_t npos = (size_t)p.R * KSOLVE_NQ * p.S2;
     for (int q = wave; q < KSOLVE_NQ; q += nwaves) {
         const long long* pe = p.tables + ((size_t)r * KSOLVE_NQ + q) * p.S2;
@@ -125,14 +154,36 @@ __global__ __launch_bounds__(1024) void k3_levels_ab(K3FusedParams p)
     if (wave == 0) {
         const long long e = wave_sum_ll(lane < KSOLVE_NQ ? qe[lane] : 0ll);
         const long long t = wave_sum_ll(lane < KSOLVE_NQ ? qt[lane] : 0ll);
-        const int prior = p.meanq[r];
-        const int post = solve_cell_wave(sc, prior, e, t, p.aux[r]);
+        int prior;
+        if (p.aux) prior = p.meanq[r];
+        else {
+            // meanq = p_to_q(expected_errs / rg_total) (recalibrate.py:111,120; compare_reads.py:262-267): the reference
+            // TRUNCATES -10 log10 of a longdouble quotient.  Formed here in double precision; whenever the value lies
+            // within 1e-7 of an integer -- far wider than the double arithmetic's and the reference's own accumulated
+            // rounding (its sum takes one 80-bit add per base: <= 2e-9 in this quantity at 10^10 bases) -- the read group
+            // is reported and the caller solves with the host's longdouble meanq instead.  One quality value only puts
+            // the quotient exactly ON such a boundary (the reference's "float badness", tests/test_recalibrate.py:63).
+            const long long mine = lane < KSOLVE_NQ ? qt[lane] : 0ll;
+            double ex = lane < KSOLVE_NQ ? (double)mine * perr[lane] : 0.0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) ex += __shfl_xor(ex, off);
+            const int kinds = __popcll(__ballot(mine != 0ll));
+            const double v = -10.0 * log10(ex / (double)t);
+            const bool decided = t > 0 && kinds > 1 && v == v && fabs(v) < 1e6 && fabs(v - rint(v)) >= 1e-7;
+            int mq = decided ? (int)trunc(v) : 0;
+            mq = mq < 0 ? 0 : mq > KSOLVE_NQ - 1 ? KSOLVE_NQ - 1 : mq;
+            if (!decided && lane == 0) atomicMin(&p.status[ST_MEANQ], (unsigned long long)r);
+            if (lane == 0 && p.meanq_out) p.meanq_out[r] = mq;
+            prior = mq;
+        }
+        const int post = solve_cell_wave(sc, prior, e, t, p.aux ? p.aux[r] : lgam_combiln(e, t, T));
         if (lane == 0) { post_rg = post; if (p.dq) p.dq[r] = post - prior; }
     }
     __syncthreads();
     const int prior = post_rg;
     for (int q = wave; q < KSOLVE_NQ; q += nwaves) {
-        const int post = solve_cell_wave(sc, prior, qe[q], qt[q], p.aux[p.R + (size_t)r * KSOLVE_NQ + q]);
+        const int post = solve_cell_wave(sc, prior, qe[q], qt[q],
+                                         p.aux ? p.aux[p.R + (size_t)r * KSOLVE_NQ + q] : lgam_combiln(qe[q], qt[q], T));
         if (lane == 0) {
             p.post_q[r * KSOLVE_NQ + q] = post;
             if (p.dq) p.dq[p.R + r * KSOLVE_NQ + q] = post - prior;
@@ -144,8 +195,10 @@ __global__ __launch_bounds__(1024) void k3_levels_ab(K3FusedParams p)
 __global__ __launch_bounds__(256) void k3_level_c(K3FusedParams p)
 {
     __shared__ double sc[3 * KSOLVE_NQ];
+    __shared__ double T[LGAM_LOGTAB_DOUBLES];
     for (int i = threadIdx.x; i < 3 * KSOLVE_NQ; i += blockDim.x)
         sc[i] = i < KSOLVE_NQ ? p.c.prior[i] : i < 2 * KSOLVE_NQ ? p.c.logp[i - KSOLVE_NQ] : p.c.log1mp[i - 2 * KSOLVE_NQ];
+    if (!p.aux) for (int i = threadIdx.x; i < LGAM_LOGTAB_DOUBLES; i += blockDim.x) T[i] = p.logtab[i];
     __syncthreads();
     const int lane = k3_lane(), wave = (int)(threadIdx.x >> 6), nwaves = (int)(blockDim.x >> 6);
     const long long npos = (long long)p.R * KSOLVE_NQ * p.S2;
@@ -154,8 +207,8 @@ __global__ __launch_bounds__(256) void k3_level_c(K3FusedParams p)
     const long long* pos_total = p.tables + npos;
     const long long* dn_errs = p.tables + 2 * npos;
     const long long* dn_total = dn_errs + ndn;
-    const double* comb_pos = p.aux + p.R + (size_t)p.R * KSOLVE_NQ;
-    const double* comb_dn = comb_pos + npos;
+    const double* comb_pos = p.aux ? p.aux + p.R + (size_t)p.R * KSOLVE_NQ : nullptr;
+    const double* comb_dn = p.aux ? comb_pos + npos : nullptr;
     int* dq_pos = p.dq ? p.dq + p.R + p.R * KSOLVE_NQ : nullptr;
     int* dq_dn = p.dq ? dq_pos + npos : nullptr;
     for (long long i = (long long)blockIdx.x * nwaves + wave; i < npos + ndn; i += (long long)gridDim.x * nwaves) {
@@ -163,7 +216,8 @@ __global__ __launch_bounds__(256) void k3_level_c(K3FusedParams p)
             const long long cell = i / p.S2;               // r * 43 + q
             const int col = (int)(i - cell * p.S2);
             const int prior = p.post_q[cell];
-            const int post = solve_cell_wave(sc, prior, pos_errs[i], pos_total[i], comb_pos[i]);
+            const long long ce = pos_errs[i], ct = pos_total[i];
+            const int post = solve_cell_wave(sc, prior, ce, ct, comb_pos ? comb_pos[i] : lgam_combiln(ce, ct, T));
             if (lane == 0) {
                 p.lut[cell * p.rs + col] = (int16_t)post;  // meanq + rgdq + qdq + posdq
                 if (dq_pos) dq_pos[i] = post - prior;
@@ -173,7 +227,8 @@ __global__ __launch_bounds__(256) void k3_level_c(K3FusedParams p)
             const long long cell = j >> 4;
             const int d = (int)(j & 15);
             const int prior = p.post_q[cell];
-            const int v = solve_cell_wave(sc, prior, dn_errs[j], dn_total[j], comb_dn[j]) - prior;
+            const long long ce = dn_errs[j], ct = dn_total[j];
+            const int v = solve_cell_wave(sc, prior, ce, ct, comb_dn ? comb_dn[j] : lgam_combiln(ce, ct, T)) - prior;
             int16_t* row = p.lut + cell * p.rs + p.S2;
             if (lane == 0) {
                 row[5 * (d >> 2) + (d & 3)] = (int16_t)v;

@@ -13,6 +13,10 @@
 // checks that over millions of arguments.  Why it exists: three SciPy ufunc passes over 13.6 k cells cost
 // 0.32 ms of a 10 ms bench step; one fused threaded pass costs a fraction of it.
 #include "../../include/kbbq_hip.h"
+#include "lgam_core.h"
+
+#include <link.h>
+#include <cstring>
 
 #include <algorithm>
 #include <cmath>
@@ -192,6 +196,76 @@ int kbbq_solve_prep_host(const int64_t* tables, int R, int S2, double* aux, int6
     }
     combiln_range(q_errs, q_total, 0, rows, aux_q);
     combiln_range(rg_errs, rg_total, 0, R, aux_rg);
+    return KBBQ_OK;
+}
+
+// ---- the constants of the host's own `log`, for the device restatement (csrc/lgam_core.h) --------------------
+// glibc keeps them in one read-only structure (__log_data: ln2hi, ln2lo, poly[5], poly1[11], 128 x {invc, logc}; not
+// an exported symbol).  It is located in the libm image this process has mapped by the bit patterns of its first two
+// members -- the split of ln 2 that the routine was published with -- and accepted only if the 128 pairs that follow
+// look like what they must be: 1/c in (0.7, 1.5) descending, log c within 2^-20 of -log(invc).
+namespace {
+struct LogDataSearch { double* out; bool found; };
+
+bool plausible_log_data(const double* d)
+{
+    if (!(d[2] < -0.49 && d[2] > -0.51)) return false;                 // A0 ~ -1/2
+    const double* tab = d + 18;                                        // 2 + 5 + 11 doubles precede the table
+    double prev = 2.0;
+    for (int i = 0; i < 128; ++i) {
+        const double invc = tab[2 * i], logc = tab[2 * i + 1];
+        if (!(invc > 0.7 && invc < 1.5) || !(invc < prev)) return false;
+        if (std::fabs(logc + std::log(invc)) > 1e-6) return false;
+        prev = invc;
+    }
+    return true;
+}
+
+int scan_object(struct dl_phdr_info* info, size_t, void* arg)
+{
+    LogDataSearch* s = static_cast<LogDataSearch*>(arg);
+    if (s->found || !info->dlpi_name || !strstr(info->dlpi_name, "libm")) return 0;
+    const uint64_t ln2hi = 0x3FE62E42FEFA3800ull, ln2lo = 0x3D2EF35793C76730ull;
+    for (int h = 0; h < info->dlpi_phnum; ++h) {
+        const ElfW(Phdr)& ph = info->dlpi_phdr[h];
+        if (ph.p_type != PT_LOAD || !(ph.p_flags & PF_R) || ph.p_filesz < (18 + 256) * 8) continue;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(info->dlpi_addr + ph.p_vaddr);
+        const size_t span = ph.p_filesz - (18 + 256) * 8;
+        for (size_t off = ((8 - (reinterpret_cast<uintptr_t>(base) & 7)) & 7); off <= span; off += 8) {
+            uint64_t a, b;
+            memcpy(&a, base + off, 8);
+            if (a != ln2hi) continue;
+            memcpy(&b, base + off + 8, 8);
+            if (b != ln2lo) continue;
+            double d[18 + 256];
+            memcpy(d, base + off, sizeof d);
+            if (!plausible_log_data(d)) continue;
+            memcpy(s->out, d, 7 * 8);                                  // ln2hi, ln2lo, A0..A4
+            memcpy(s->out + LGAM_LOGTAB_HEAD, d + 18, 256 * 8);        // 128 x (invc, logc)
+            s->found = true;
+            return 1;
+        }
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" int kbbq_libm_log_data(double* out, int count)
+{
+    if (!out || count < LGAM_LOGTAB_DOUBLES) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_libm_log_data: need room for 263 doubles");
+    (void)std::log(2.0);                                               // libm is mapped (and its ifunc resolved)
+    LogDataSearch s{out, false};
+    dl_iterate_phdr(scan_object, &s);
+    if (!s.found) return kbbq_set_error_(KBBQ_E_HIP, "kbbq_libm_log_data: the constants of this libm's log() were not found; the host pass of the solve stays in use");
+    return KBBQ_OK;
+}
+
+// gammaln of the solve's arguments through csrc/lgam_core.h on the HOST (no call into libm): what the device evaluates,
+// for tests without a GPU.  x: integer-valued doubles >= 1.
+extern "C" int kbbq_gammaln_restated_host(const double* x, int64_t n, const double* logtab, double* out)
+{
+    if (n < 0 || (n > 0 && (!x || !out)) || !logtab) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_gammaln_restated_host: bad argument");
+    for (int64_t i = 0; i < n; ++i) out[i] = lgam_count(x[i], logtab);
     return KBBQ_OK;
 }
 

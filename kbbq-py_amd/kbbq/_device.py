@@ -39,7 +39,7 @@ def warm_up(device=0):
         pairs = PairBatch.from_reads(batch)
         tables = Tables(1, 2 * pairs.S)
         accumulate(pairs, tables)
-        lut, shape, _, _ = solve(tables)
+        lut, shape = solve_lut(tables)            # also proves (once per process) the device's gammaln against the host's
         pairs.unpack(apply(pairs, lut, shape)).cpu()
         torch.cuda.synchronize()
     _warm = True
@@ -590,10 +590,95 @@ def delta_q(prior_q, numerrs, numtotal):
     return res - pq if is_float else res.astype(np.int_)
 
 
-def solve_lut(tables, minscore=MINSCORE):
-    """(lut_dev, shape) of solve(): what apply() needs."""
-    lut, shape, _, _ = solve(tables, minscore=minscore)
-    return lut, shape
+_logtabs = {}            # device index -> the host libm's log() constants on the device, or None (host pass in use)
+_solve_bufs = {}
+
+
+def _gammaln_check_arguments():
+    """> 10^6 integer-valued arguments of the kind the solve forms (counts + 1 ... + 3): every small one, a log-uniform
+    sample up to 2^40, and the neighbourhoods of the routine's branch points and of the powers of two."""
+    rng = np.random.default_rng(20240229)
+    edges = np.array([1, 2, 3, 12, 13, 14, 999, 1000, 1001, 1e8 - 1, 1e8, 1e8 + 1, 1e10, 7.5e9 + 3], dtype=np.float64)
+    pow2 = 2.0 ** np.arange(0, 41)
+    return np.concatenate([np.arange(1, 262145, dtype=np.float64), np.floor(2.0 ** rng.uniform(0, 40, 1 << 20)),
+                           edges, pow2, pow2[1:] + 1, pow2[2:] - 1])
+
+
+def device_logtab(device=None):
+    """The constants of the HOST libm's log() on the device (csrc/lgam_core.h), once the device's gammaln over them has
+    been checked bit for bit against the host routine on > 10^6 arguments; None when the constants are not found or any
+    bit differs (the solve then keeps its host pass).  KBBQ_HOST_SOLVE=1 forces None."""
+    import os
+    torch = _torch()
+    if device is None:
+        device = torch.cuda.current_device()
+    if device in _logtabs:
+        return _logtabs[device]
+    tab = None
+    if not os.environ.get('KBBQ_HOST_SOLVE'):
+        lib = N.load()
+        host = np.zeros(263, dtype=np.float64)
+        if lib.kbbq_libm_log_data(N.ptr(host), host.size) == N.KBBQ_OK:
+            with torch.cuda.device(device):
+                ctx = context(device)
+                cand = torch.from_numpy(host).cuda()
+                x = _gammaln_check_arguments()
+                want = np.empty_like(x)
+                N.check(lib.kbbq_gammaln_host(N.ptr(x), x.size, N.ptr(want)))
+                d_x = torch.from_numpy(x).cuda()
+                d_out = torch.empty_like(d_x)
+                N.check(lib.kbbq_gammaln_dev(ctx.handle, N.ptr(d_x), x.size, N.ptr(cand), N.ptr(d_out)))
+                got = d_out.cpu().numpy()
+                if np.array_equal(got.view(np.uint64), want.view(np.uint64)):
+                    tab = cand
+    _logtabs[device] = tab
+    return tab
+
+
+def _consts172():
+    global _consts172_
+    if _consts172_ is None:
+        from . import compare_reads as utils
+        perr = np.asarray(utils.q_to_p(np.arange(NQ, dtype=np.int_)), dtype=np.float64)
+        _consts172_ = np.ascontiguousarray(np.concatenate([_model_consts(), perr]))
+    return _consts172_
+
+
+_consts172_ = None
+
+
+def solve_lut(tables, minscore=MINSCORE, check=True):
+    """(lut_dev, shape) for apply(): count tables -> apply LUT with NOTHING from the host inside the step when the
+    device's gammaln has been proven equal to the host's (device_logtab): marginals, gammaln terms, meanq and the four
+    levels of applybqsr.get_delta_qs are kernels on the launch stream, the buffers are kept per table shape.  A meanq the
+    kernel cannot decide in double precision (within 1e-7 of a truncation boundary -- one quality value only is such a
+    case) is reported by the status word: with check=True it is read here (one synchronisation) and the solve redone
+    with the host's longdouble meanq; with check=False the caller's context().status() raises MeanqNeedsHost."""
+    torch = _torch()
+    dev_ = tables.buf.device
+    tab = device_logtab(dev_.index)
+    if tab is None:
+        lut, shape, _, _ = solve(tables, minscore=minscore)
+        return lut, shape
+    R, S2 = tables.R, tables.S2
+    lib = N.load()
+    key = (dev_.index, R, S2)
+    bufs = _solve_bufs.get(key)
+    if bufs is None:
+        bufs = (torch.zeros(lib.kbbq_lut_bytes(R, NQ, S2), dtype=torch.uint8, device=dev_),
+                torch.empty(R * NQ, dtype=torch.int32, device=dev_))
+        _solve_bufs[key] = bufs
+    lut, post_q = bufs
+    ctx = context(dev_.index)
+    N.check(lib.kbbq_solve_device_dev(ctx.handle, N.ptr(tables.buf), R, S2, minscore, N.ptr(tab), N.ptr(_consts172()),
+                                      N.ptr(post_q), N.ptr(lut), None, None))
+    if check:
+        try:
+            ctx.status()
+        except N.MeanqNeedsHost:
+            lut, shape, _, _ = solve(tables, minscore=minscore)
+            return lut, shape
+    return lut, (R, NQ, S2, N.APPLY_FAST)
 
 
 def solve(tables, want_dq=False, minscore=MINSCORE):

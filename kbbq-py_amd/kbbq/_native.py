@@ -21,6 +21,7 @@ KBBQ_E_ARG = -4
 KBBQ_E_RANGE = -5
 KBBQ_E_NAME = -6
 KBBQ_E_LUT = -7
+KBBQ_E_MEANQ = -8
 APPLY_CHECKED, APPLY_FAST = 0, 1
 ROWS_PAIRS, ROWS_NIBBLES = 1, 2
 
@@ -63,6 +64,10 @@ PROTOTYPES = {
     'kbbq_combiln_host': (_i, [_vp, _vp, _i64, _vp, _i]),
     'kbbq_solve_prep_host': (_i, [_vp, _i, _i, _vp, _vp, _i]),
     'kbbq_gammaln_host': (_i, [_vp, _i64, _vp]),
+    'kbbq_libm_log_data': (_i, [_vp, _i]),
+    'kbbq_gammaln_restated_host': (_i, [_vp, _i64, _vp, _vp]),
+    'kbbq_gammaln_dev': (_i, [_vp, _vp, _i64, _vp, _vp]),
+    'kbbq_solve_device_dev': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kbbq_posterior_q_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'kbbq_solve_aux_count': (_sz, [_i, _i]),
     'kbbq_solve_dq_count': (_sz, [_i, _i]),
@@ -129,6 +134,10 @@ class LutNeedsCheckedApply(KbbqHipError):
     """kbbq_ctx_status: the device-built LUT is not usable by the table-driven apply kernel."""
 
 
+class MeanqNeedsHost(KbbqHipError):
+    """kbbq_ctx_status: the all-device solve met a meanq on a truncation boundary; solve with the host's longdouble meanq."""
+
+
 def _preload_torch_hip_runtime():
     import sys
     if 'torch' in sys.modules:
@@ -189,6 +198,8 @@ def check(rc):
         raise ValueError(msg)
     if rc == KBBQ_E_LUT:
         raise LutNeedsCheckedApply(msg)
+    if rc == KBBQ_E_MEANQ:
+        raise MeanqNeedsHost(msg)
     raise KbbqHipError(msg or ('libkbbq_hip error %d' % rc))
 
 

@@ -222,7 +222,7 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
                 save_model(tables, packed['rg_to_int'], gatkreport)
             parallel.barrier()
     with stage('solve', sync=True):
-        lut, shape, _, _ = dev.solve(tables)
+        lut, shape = dev.solve_lut(tables)
     R = shape[0]
     if packed is not None and packed['total'] == text.total:
         # pass 2 walks the same reads with the same first-appearance read groups (:141-148):

@@ -254,6 +254,89 @@ def test_k3_get_delta_qs_and_fused_solve_match_reference(dev, name):
     assert np.array_equal(lut.cpu().numpy(), want_lut)     # canonical + table-driven parts + flags, byte for byte
 
 
+# ------------------------------------------------------------------ K3 without the host (csrc/lgam_core.h)
+def test_device_gammaln_is_the_hosts_bit_for_bit(dev):
+    """The precondition of the all-device solve: gammaln evaluated by a kernel over the host libm's own log() constants
+    equals the host routine (= scipy.special.gammaln, tests/test_solve_core_host.py) on every argument tried."""
+    import torch
+    from kbbq import _native as N
+    tab = dev.device_logtab()
+    assert tab is not None, 'the device restatement of gammaln was not accepted on this box: the host pass is in use'
+    rng = np.random.default_rng(7)
+    x = np.concatenate([np.floor(2.0 ** rng.uniform(0, 34, 2_000_000)), np.arange(1, 5001, dtype=np.float64)])
+    want = np.empty_like(x)
+    N.check(N.load().kbbq_gammaln_host(N.ptr(x), x.size, N.ptr(want)))
+    d_x = torch.from_numpy(x).cuda(); d_out = torch.empty_like(d_x)
+    N.check(N.load().kbbq_gammaln_dev(dev.context().handle, N.ptr(d_x), x.size, N.ptr(tab), N.ptr(d_out)))
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want.view(np.uint64))
+
+
+def _both_solves(dev, t):
+    """(LUT of the host-fed solve, LUT of solve_lut) as byte arrays."""
+    lut_host, shape_host, _, _ = dev.solve(t)
+    lut_dev, shape_dev = dev.solve_lut(t)
+    assert shape_dev == shape_host
+    return lut_host.cpu().numpy(), lut_dev.cpu().numpy()
+
+
+@pytest.mark.parametrize('name', ['c1_10k_1rg', 'c3cut_2k_8rg', 'c5cut_2k_mixed', 'q42_500_3rg', 'short_64_1rg'])
+def test_all_device_solve_equals_the_host_fed_solve_on_golden_tables(dev, name):
+    import torch
+    _, g = load_golden(name)
+    R, _, S2 = g['pos_total'].shape
+    t = dev.Tables(R, S2)
+    t.buf.copy_(torch.from_numpy(np.concatenate([g[k].ravel() for k in ('pos_errs', 'pos_total', 'dinuc_errs', 'dinuc_total')])))
+    assert dev.device_logtab() is not None
+    a, b = _both_solves(dev, t)
+    assert np.array_equal(a, b)
+    want_lut, _ = dev.build_lut(g['meanq'], g['rgdq'], g['qdq'], g['posdq'], g['dinucdq'])
+    assert np.array_equal(b, want_lut)
+
+
+@pytest.mark.parametrize('seed,R,S2,scale', [(1, 1, 300, 10.3), (2, 3, 300, 8.0), (3, 8, 100, 6.0), (4, 2, 600, 9.5), (5, 5, 32, 3.0)])
+def test_all_device_solve_on_adversarial_tables(dev, seed, R, S2, scale):
+    """Random count tables up to 2 * 10^10 per cell, empty cells, errs == total, tiny cells: the LUT of the all-device
+    solve (kernel marginals, kernel gammaln, kernel meanq) equals the host-fed one byte for byte."""
+    import torch
+    rng = np.random.default_rng(seed)
+    t = dev.Tables(R, S2)
+    npos, ndn = R * 43 * S2, R * 43 * 16
+
+    def cells(n):
+        tot = (10 ** rng.uniform(0, scale, n)).astype(np.int64)
+        err = np.minimum((tot * 10 ** (-rng.uniform(0, 5, n))).astype(np.int64), tot)
+        k = rng.random(n)
+        tot[k < 0.1] = 0; err[k < 0.1] = 0
+        err[(k > 0.1) & (k < 0.15)] = tot[(k > 0.1) & (k < 0.15)]
+        return err, tot
+    pe, pt = cells(npos)
+    de, dt = cells(ndn)
+    t.buf.copy_(torch.from_numpy(np.concatenate([pe, pt, de, dt])))
+    a, b = _both_solves(dev, t)
+    assert np.array_equal(a, b)
+
+
+def test_all_device_solve_hands_undecidable_meanq_to_the_host(dev):
+    """One quality value only: the mean error is 10^(-q/10) itself and -10 log10 of it sits ON the truncation boundary (the
+    reference's "float badness", tests/test_recalibrate.py:63).  The kernel must not guess: status -> host longdouble."""
+    import torch
+    from kbbq import _native as N
+    t = dev.Tables(2, 300)
+    pe, pt, de, dt = t.views()
+    pt[0, 7, :] = 1000; pe[0, 7, :3] = 2
+    pt[1, 20, :] = 500; pt[1, 30, :] = 500
+    a, b = _both_solves(dev, t)
+    assert np.array_equal(a, b)
+    ctx = dev.context()
+    dev.solve_lut(t, check=False)
+    with pytest.raises(N.MeanqNeedsHost):
+        ctx.status()
+    empty = dev.Tables(1, 300)                               # no counted base at all: 0 / 0 in the reference
+    dev.solve_lut(empty, check=False)
+    with pytest.raises(N.MeanqNeedsHost):
+        ctx.status()
+
+
 def test_get_delta_qs_known_answer(dev):
     # reference tests/test_gatk_applybqsr.py:105-121
     from kbbq.gatk import applybqsr
@@ -539,6 +622,33 @@ def test_bench_prints_one_json_line_with_the_contract_fields(dev):
     assert d['value'] > 1e9 and abs(d['value'] - 400000 * 150 / (d['ms_per_step'] / 1e3)) / d['value'] < 1e-6
     roof = d['roofline']
     assert roof['bound'] == 'hbm' and roof['unit'] == 'GB/s' and roof['peak'] == 8000.0
-    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-9 and 0 < roof['frac'] < 1 and roof['traffic'] > 0
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-9 and 0 < roof['frac'] < 1 and (roof['traffic'] is None or roof['traffic'] > 0)
     cpu = d['cpu_baseline']
     assert cpu['kind'] in ('port', 'reference') and cpu['cores'] >= 1 and cpu['value'] > 1e6 and cpu['unit'] == 'bases/s' and cpu['sample']
+    # the figures next to it: the reference's own measured rate, the port on all host cores
+    assert cpu['reference_bases_per_s'] > 1e5 and cpu['reference_cores'] == 1 and cpu['all_cores']['cores'] == cpu['host_cores']
+    assert d['ranks_seen'] == 1 and d['kernels']['host_solve_and_sync_ms'] < 5
+    # the other configurations and the rows next to the path, measured in the same process
+    extra = d['extra']
+    for key in ('config3_8rg', 'layout_pairs', 'layout_reads', 'aligned_read_kernels', 'file_path'):
+        assert key in extra and 'error' not in extra[key], (key, extra.get(key))
+    assert extra['config3_8rg']['layout_inclusive']['value'] < extra['config3_8rg']['value']
+    assert all(extra['aligned_read_kernels'][k]['GB/s'] > 0 for k in ('k4_find_errors', 'k5_count_q', 'k6_canonical_reads'))
+    assert extra['file_path']['value'] > 1e6 and extra['file_path']['stages_s']
+
+
+def test_bench_launches_its_own_two_rank_job(dev):
+    """`python bench.py --gpus 2` from a plain command line: the parent starts torch.distributed.run as a child before it
+    imports anything GPU-side; on this one-GPU box the two ranks share the device over gloo (a rehearsal, flagged)."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ); env.pop('RANK', None); env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--reads', '200000'], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.split('\n') if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['backend'] == 'gloo' and 'rehearsal' in d['data']
+    assert abs(d['value'] - 2 * 200000 * 150 / (d['ms_per_step'] / 1e3)) / d['value'] < 1e-6
+    assert 'extra' not in d and 'cpu_baseline' not in d

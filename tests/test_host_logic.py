@@ -628,3 +628,41 @@ def test_bgzip_fastq_is_inflated_block_parallel(oracle, tmp_path):
     (tmp_path / 'bad.fq.gz').write_bytes(bytes(bad))
     with pytest.raises(ValueError):
         fastx.NativeFastq(str(tmp_path / 'bad.fq.gz'))
+
+
+def test_bench_parent_launches_a_child_job_without_touching_the_gpu(monkeypatch, capsys):
+    """bench.py --gpus N > 1 without a launcher's environment: the parent composes the torch.distributed.run command
+    the driver itself would use, runs it as a CHILD (subprocess, never exec) before importing torch, and relays the
+    one JSON line.  (The ranks themselves need GPUs: tests/test_gpu_parity.py::test_bench_launches_its_own_two_rank_job.)"""
+    import importlib, subprocess, sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    seen = {}
+
+    class Done:
+        returncode = 0
+        stdout = b'RCCL version banner\n{"metric": "x", "n_gpus": 4}\n'
+
+    def fake_run(cmd, env=None, stdout=None):
+        seen['cmd'], seen['env'], seen['torch_loaded'] = cmd, env, 'torch' in sys.modules
+        return Done()
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.delenv('RANK', raising=False)
+    torch_mod = sys.modules.pop('torch', None)            # other tests of this process may have imported it
+    try:
+        rc = bench.main(['--gpus', '4', '--steps', '3', '--warmup', '1', '--reads', '1000', '--no-extra'])
+    finally:
+        if torch_mod is not None:
+            sys.modules['torch'] = torch_mod
+    assert rc == 0 and not seen['torch_loaded']
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run'] and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    tail = cmd[cmd.index(os.path.join(ROOT, 'bench.py')) + 1:]
+    assert tail[:6] == ['--gpus', '4', '--steps', '3', '--warmup', '1'] and '--no-extra' in tail
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    assert capsys.readouterr().out.strip() == '{"metric": "x", "n_gpus": 4}'
+    # a rank (RANK set) with the wrong world size refuses instead of measuring something else
+    monkeypatch.setenv('RANK', '0'); monkeypatch.setenv('WORLD_SIZE', '2')
+    with pytest.raises(SystemExit):
+        bench.main(['--gpus', '4', '--no-extra'])
