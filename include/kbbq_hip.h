@@ -357,6 +357,25 @@ int    kbbq_lay_out_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_cs
                         uint8_t* d_lseq, uint8_t* d_lcseq, uint8_t* d_lqual, uint32_t* d_lmeta);
 int    kbbq_unpack_nibbles_dev(kbbq_ctx* ctx, const uint8_t* d_nib, int64_t nbases, uint8_t* d_chars);
 
+/* ---- the exchange step of the sharded path without torch: RCCL allreduce of the count tables -------------
+ * Reads shard across GPUs by contiguous record ranges, every rank tallies its shard (K1) and the ONLY exchange is the
+ * sum of the int64 count-table buffers; marginals, meanq and the solve are then replicated and K2 is
+ * local.  One process (or thread) per GPU, each with its own kbbq_ctx.  Rank 0 obtains a 128-byte id
+ * (kbbq_comm_unique_id) and hands it to the other ranks by whatever channel the caller has (file, socket, MPI);
+ * every rank then calls kbbq_comm_create with the same id -- collective, as ncclCommInitRank is.
+ * kbbq_allreduce_tables: in place, enqueued on the context's stream (ordered between K1 and the solve, no host wait).
+ * librccl is bound at the first call with dlopen (a copy already loaded by the process, else KBBQ_RCCL_LIB /
+ * kbbq_comm_library(path), else the loader's librccl.so.1, else /opt/rocm/lib): libkbbq_hip.so itself does not link it.
+ * The Python layer of this repository uses torch.distributed for the same step (kbbq/parallel.py); these entry points
+ * are for C / C++ / other-language callers.  */
+#define KBBQ_COMM_ID_BYTES 128
+typedef struct kbbq_comm kbbq_comm;
+int kbbq_comm_library(const char* path);
+int kbbq_comm_unique_id(void* id128);
+int kbbq_comm_create(kbbq_ctx* ctx, const void* id128, int nranks, int rank, kbbq_comm** out);
+int kbbq_allreduce_tables(kbbq_comm* comm, int64_t* d_buf, size_t n);
+int kbbq_comm_destroy(kbbq_comm* comm);
+
 /* ---- host SAM / BAM reader (no GPU) ----------------------------------------------------------
  * Replaces, for the truth-set benchmark and the BAM-sourced tally, what the reference gets from
  * pysam.AlignmentFile / AlignedSegment (benchmark.py:57-74,102-143; gatk/bqsr.py:23-123): per alignment

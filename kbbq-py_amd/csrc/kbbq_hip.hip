@@ -131,6 +131,10 @@ int kbbq_ctx_set_stream(kbbq_ctx* c, void* s)
     return KBBQ_OK;
 }
 
+// for comm_rccl.cpp (not part of the public header)
+void* kbbq_ctx_stream_(kbbq_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int kbbq_ctx_device_(kbbq_ctx* c) { return c ? c->device : 0; }
+
 int kbbq_ctx_sync(kbbq_ctx* c)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
