@@ -377,18 +377,17 @@ def extra_aligned(torch, dev, n=4_000_000, L=150, G=200_000_000, ins=0.05, reps=
     batch = dev.ReadBatch(n, pitch, with_corrected=True)
     tables = dev.Tables(1, 2 * L)
     ctx, lib = dev.context(), N.load()
-    aux = dev.cigar_prefix(cig_off, cig_n, cigar) if hasattr(dev, 'cigar_prefix') else None
 
-    def k4(fl):
+    def k4(fl, two_planes=False):
         N.check(lib.kbbq_find_errors_dev(ctx.handle, N.ptr(seq), N.ptr(lens), n, pitch, N.ptr(start), N.ptr(ref_len),
                                          N.ptr(cig_off), N.ptr(cig_n), N.ptr(cigar), N.ptr(fused), None, G, N.ptr(fl),
-                                         N.ptr(err), N.ptr(skip)))
+                                         N.ptr(err), N.ptr(skip) if two_planes else None))
 
-    def k5():
-        N.check(lib.kbbq_count_q_dev(ctx.handle, N.ptr(qual), N.ptr(err), N.ptr(skip), N.ptr(lens), n, pitch, 0, N.ptr(counts)))
+    def k5(two_planes=False):
+        N.check(lib.kbbq_count_q_dev(ctx.handle, N.ptr(qual), N.ptr(err), N.ptr(skip) if two_planes else None, N.ptr(lens), n, pitch, 0, N.ptr(counts)))
 
-    def k6():
-        N.check(lib.kbbq_canonical_reads_dev(ctx.handle, N.ptr(seq), N.ptr(oq), N.ptr(err), N.ptr(skip), N.ptr(lens),
+    def k6(two_planes=False):
+        N.check(lib.kbbq_canonical_reads_dev(ctx.handle, N.ptr(seq), N.ptr(oq), N.ptr(err), N.ptr(skip) if two_planes else None, N.ptr(lens),
                                              N.ptr(clip), N.ptr(trim), N.ptr(flags), n, pitch, L, 6, 6,
                                              N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual), N.ptr(batch.meta)))
 
@@ -396,11 +395,17 @@ def extra_aligned(torch, dev, n=4_000_000, L=150, G=200_000_000, ins=0.05, reps=
         dev.accumulate(batch, tables, 6, check=False, dinuc_minscore=6)
 
     out = {'workload': '%d aligned reads x %d bp, %d Mb random genome, %.0f %% of the reads with a 2-base insertion, half '
-                       'reverse-strand; HIP events on the launch stream, %d launches each' % (n, L, G // 1000000, ins * 100, reps)}
+                       'reverse-strand; HIP events on the launch stream, %d launches each' % (n, L, G // 1000000, ins * 100, reps),
+           'bytes_per_base': 'algorithmic, by the arrays of the reference: K4 3 read (read, reference, site mask) + 2 written (errors, '
+                             'skips); K5 3 read; K6 4 read + 3 written.  The product keeps errors and skips in ONE plane of flags between '
+                             'these kernels (and the site mask in bit 7 of the reference bytes): each kernel moves 1 B/base less than its '
+                             'algorithmic count; the *_two_planes entries are the form with separate error / skip planes'}
     bases = n * L
     for name, fn, bpb in (('k4_find_errors', lambda: k4(flip), 5), ('k5_count_q', k5, 3),
                           ('k4_find_errors_tally', lambda: k4(noflip), 5), ('k6_canonical_reads', k6, 7),
-                          ('k1_on_canonical_reads', k1, 3)):
+                          ('k1_on_canonical_reads', k1, 3),
+                          ('k4_find_errors_two_planes', lambda: k4(flip, True), 5), ('k5_count_q_two_planes', lambda: k5(True), 3),
+                          ('k6_canonical_reads_two_planes', lambda: k6(True), 7)):
         fn()
         torch.cuda.synchronize()
         evs = []

@@ -246,7 +246,14 @@ int    kbbq_solve_dev(kbbq_ctx* ctx, const int64_t* d_tables, int R, int S2, int
  * KBBQ_E_RANGE.
  * kbbq_count_q_dev replaces the two np.bincount calls of benchmark.calculate_q
  * (benchmark.py:76-91) over the unskipped bases: counts[0..255] = observations per
- * quality (byte - qoffset), counts[256..511] = errors; ADDS into d_counts512.          */
+ * quality (byte - qoffset), counts[256..511] = errors; ADDS into d_counts512.
+ * ONE PLANE OF FLAGS: with d_skip == NULL kbbq_find_errors_dev writes both answers into d_err -- bit 0 error,
+ * bit 1 skip -- and kbbq_count_q_dev / kbbq_canonical_reads_dev called with d_skip == NULL read that plane: one
+ * byte per base less to write and to read when no caller wants the two boolean arrays themselves.
+ * Implementation (csrc/kbbq_aligned_kernels.h): the first four CIGAR operations of every read are copied into one
+ * 16-byte record per read (context-owned scratch), a lane walks them in registers and fetches the one reference
+ * window its chunk needs; chunks on an operation boundary, reads with more operations and malformed input take the
+ * sequential walk.  KBBQ_K4=v1 in the environment selects the first form (A/B timing).          */
 int kbbq_find_errors_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint32_t* d_len, int64_t nreads, int pitch,
                          const int64_t* d_ref_start, const int32_t* d_ref_len,
                          const uint32_t* d_cig_off, const uint32_t* d_cig_n, const uint32_t* d_cigar,

@@ -4,6 +4,7 @@
 #include "kbbq_kernels_v3.h"
 #include "kbbq_solve_kernels.h"
 #include "kbbq_layout_kernels.h"
+#include "kbbq_aligned_kernels.h"
 #include "../../include/kbbq_hip.h"
 
 #include <algorithm>
@@ -45,6 +46,8 @@ struct kbbq_ctx {
     hipStream_t stream = nullptr;
     u64* d_status = nullptr;          // [KBBQ_NSTATUS]
     int* d_stats = nullptr;           // [K7_NSTATS] scratch of kbbq_meta_stats_dev
+    void* d_ops4 = nullptr;           // K4: one 32-byte record of the first CIGAR operations per read (grown on demand)
+    size_t ops4_bytes = 0;
     bool timing = false;
     // per-kernel event pairs recorded while timing is on
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
@@ -119,6 +122,7 @@ int kbbq_ctx_destroy(kbbq_ctx* c)
         for (auto& pr : c->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_ops4) (void)hipFree(c->d_ops4);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return KBBQ_OK;
@@ -180,6 +184,16 @@ int kbbq_ctx_status(kbbq_ctx* c, int64_t* read_index)
                      : code == KBBQ_E_INDEX ? "quality/read-group/cycle beyond the tables (reference: IndexError)"
                                             : "recalibrated quality + 33 outside 0..255";
     return fail(code, "read %lld: %s", (long long)best, what);
+}
+
+// diagnostic builds only (-DK4_DEBUG_COUNT): the raw status words
+int kbbq_debug_status_words_(kbbq_ctx* c, uint64_t* out8)
+{
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(out8, c->d_status, sizeof ST_INIT, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_status, ST_INIT, sizeof ST_INIT, hipMemcpyHostToDevice, c->stream));
+    return KBBQ_OK;
 }
 
 int kbbq_dev_alloc(kbbq_ctx* c, size_t bytes, void** dptr)
@@ -1053,8 +1067,27 @@ int kbbq_find_errors_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint32_t* d_le
         return fail(KBBQ_E_ARG, "kbbq_find_errors_dev: planes must be 16-byte aligned");
     const int rpb4 = (pitch / 16) <= 256 ? 256 / (pitch / 16) : 1;              // reads per workgroup iteration
     int gx = (int)std::min<int64_t>((nreads + rpb4 - 1) / rpb4, (int64_t)c->cus * 16);
-    if (d_skipmask) hipLaunchKernelGGL(k4_find_errors<false>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
-    else hipLaunchKernelGGL(k4_find_errors<true>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    const char* force = getenv("KBBQ_K4");              // "v1" forces the first form (A/B timing): needs both output planes
+    if (force && !strcmp(force, "v1") && d_skip) {
+        if (d_skipmask) hipLaunchKernelGGL(k4_find_errors<false>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+        else hipLaunchKernelGGL(k4_find_errors<true>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+        HIPCHK(hipGetLastError());
+        return KBBQ_OK;
+    }
+    // the first four operations of every read inline, one 16-byte record per read (context-owned scratch)
+    const size_t need = (size_t)nreads * sizeof(K4Rec);
+    if (c->ops4_bytes < need) {
+        if (c->d_ops4) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_ops4); c->d_ops4 = nullptr; c->ops4_bytes = 0; }
+        HIPCHK(hipMalloc(&c->d_ops4, need));
+        c->ops4_bytes = need;
+    }
+    K4RecParams ip; ip.len = d_len; ip.ref_len = d_ref_len; ip.cig_off = d_cig_off; ip.cig_n = d_cig_n; ip.cigar = d_cigar;
+    ip.nreads = nreads; ip.recs = (K4Rec*)c->d_ops4;
+    int gi = (int)std::min<int64_t>((nreads + 255) / 256, (int64_t)c->cus * 16);
+    hipLaunchKernelGGL(k4_read_records, dim3((unsigned)std::max(gi, 1)), dim3(256), 0, c->stream, ip);
+    K4v2Params q; q.base = p; q.recs = (const K4Rec*)c->d_ops4; q.idle16 = reinterpret_cast<const uint8_t*>(c->d_status);
+    if (d_skipmask) hipLaunchKernelGGL(k4v2_find_errors<false>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, q);
+    else hipLaunchKernelGGL(k4v2_find_errors<true>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, q);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
 }
@@ -1071,6 +1104,7 @@ int kbbq_canonical_reads_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d
     if (minscore < 0 || minscore > 94 || dinuc_minscore < 0 || dinuc_minscore > 94)
         return fail(KBBQ_E_ARG, "kbbq_canonical_reads_dev: minscore out of range");
     if (nreads == 0) return KBBQ_OK;
+    if (!d_seq || !d_oq || !d_err) return fail(KBBQ_E_ARG, "kbbq_canonical_reads_dev: NULL plane");
     if (((uintptr_t)d_seq | (uintptr_t)d_oq | (uintptr_t)d_err | (uintptr_t)d_skip | (uintptr_t)d_out_seq
          | (uintptr_t)d_out_cseq | (uintptr_t)d_out_qual) & 15)
         return fail(KBBQ_E_ARG, "kbbq_canonical_reads_dev: planes must be 16-byte aligned");
@@ -1092,6 +1126,7 @@ int kbbq_count_q_dev(kbbq_ctx* c, const uint8_t* d_qual, const uint8_t* d_err, c
                      const uint32_t* d_len, int64_t nreads, int pitch, int qoffset, int64_t* d_counts512)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (!d_qual || !d_err) return fail(KBBQ_E_ARG, "kbbq_count_q_dev: NULL plane");
     int rc = check_planes("kbbq_count_q_dev", nreads, pitch, d_qual, d_err, d_skip);
     if (rc) return rc;
     if (nreads == 0) return KBBQ_OK;

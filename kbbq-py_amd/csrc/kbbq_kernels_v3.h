@@ -991,7 +991,11 @@ __global__ __launch_bounds__(256) void k6_canonical_reads(K6Params p)
         load16_upto(p.seq, at, plane, w.s);
         load16_upto(p.oq, at, plane, w.q);
         load16_upto(p.err, at, plane, w.e);
-        load16_upto(p.skip, at, plane, w.k);
+        if (p.skip) load16_upto(p.skip, at, plane, w.k);
+        else {                                                     // one plane of flags: bit 0 error, bit 1 skip
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { w.k[x] = w.e[x] & 0x02020202u; w.e[x] &= 0x01010101u; }
+        }
     };
     K6Item it0{(long long)blockIdx.x * step, j0};
     K6Item it1 = next(it0), it2 = next(it1);
@@ -1221,7 +1225,11 @@ __global__ __launch_bounds__(K5_THREADS) void k5_count_q(K5Params p)
         const size_t off = (size_t)c.r * p.pitch + (size_t)16 * j;
         c.q = *reinterpret_cast<const uint4*>(p.qual + off);
         c.e = *reinterpret_cast<const uint4*>(p.err + off);
-        c.s = *reinterpret_cast<const uint4*>(p.skip + off);
+        if (p.skip) c.s = *reinterpret_cast<const uint4*>(p.skip + off);
+        else {                                                     // one plane of flags: bit 0 error, bit 1 skip
+            c.s = make_uint4(c.e.x & 0x02020202u, c.e.y & 0x02020202u, c.e.z & 0x02020202u, c.e.w & 0x02020202u);
+            c.e = make_uint4(c.e.x & 0x01010101u, c.e.y & 0x01010101u, c.e.z & 0x01010101u, c.e.w & 0x01010101u);
+        }
     };
     long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     Chunk cur, nxt;

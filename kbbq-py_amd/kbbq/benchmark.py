@@ -131,10 +131,11 @@ def _read_arrays(reads, genome, flip_reverse, rows=None):
     return n, lens, pitch, seq, ref_start, ref_len, cig_off, cig_n, np.array(cigar, dtype=np.uint32), flip
 
 
-def _flag_batch(reads, genome, flip_reverse, keep=None, rows=None):
+def _flag_batch(reads, genome, flip_reverse, keep=None, rows=None, fused=False):
     """K4 over aligned reads (an aln.AlignmentFile or a list of read objects) -> (err, skip) device planes
     [n, pitch], lens (host).  `keep`, a dict, receives the device seq plane for callers that go on to K6.
-    rows = (lo, hi): only those alignments (one rank's shard)."""
+    rows = (lo, hi): only those alignments (one rank's shard).  fused: ONE plane of flags (bit 0 error, bit 1 skip)
+    comes back as `err` and `skip` is None -- the form K5 / K6 read when they are the only consumers."""
     from . import _device as dev
     from . import _native as N
     torch = dev._torch()
@@ -144,7 +145,7 @@ def _flag_batch(reads, genome, flip_reverse, keep=None, rows=None):
     d_seq, d_len = up(seq), up(pad(lens, np.uint32).view(np.int32))
     d_cigar = up(pad(cigar, np.uint32).view(np.int32))
     err = torch.zeros((max(n, 1), pitch), dtype=torch.uint8, device='cuda')
-    skip = torch.zeros((max(n, 1), pitch), dtype=torch.uint8, device='cuda')
+    skip = None if fused else torch.zeros((max(n, 1), pitch), dtype=torch.uint8, device='cuda')
     if keep is not None:
         keep['seq'] = d_seq
     ctx = dev.context()
@@ -313,7 +314,7 @@ def benchmark_bam(bamfile, ref, var_sites, use_oq=False, bedfh=None):
     genome = _Genome(ref, fullskips)
 
     def shard():
-        err, skip, lens, pitch = _flag_batch(reads, genome, flip_reverse=False, rows=rows)
+        err, skip, lens, pitch = _flag_batch(reads, genome, flip_reverse=False, rows=rows, fused=True)
         qual = torch.from_numpy(_qual_plane(reads, lens, pitch, use_oq, rows)).cuda()
         return qual, err, skip, lens, pitch
     qual, err, skip, lens, pitch = _on_all_ranks(shard, rows[0] if rows else 0)
@@ -327,7 +328,7 @@ def benchmark_fastq(fqfile, bamfile, ref, var_sites, bedfh=None):
     torch = dev._torch()
     fullskips = get_full_skips(ref, var_sites, bedfh)
     reads = bamfile if isinstance(bamfile, aln.AlignmentFile) else list(bamfile)
-    err, skip, lens, pitch = _flag_batch(reads, _Genome(ref, fullskips), flip_reverse=True)
+    err, skip, lens, pitch = _flag_batch(reads, _Genome(ref, fullskips), flip_reverse=True, fused=True)
     fq = fastx.NativeFastq(fqfile)
     if isinstance(reads, aln.AlignmentFile):
         idx = _match_native(reads, fq)                               # both sides native: no Python object per read
@@ -351,10 +352,10 @@ def benchmark_fastq(fqfile, bamfile, ref, var_sites, bedfh=None):
     _on_all_ranks(check, lo)
     d_idx = torch.from_numpy(np.ascontiguousarray(idx)).cuda()
     fp = fqual.shape[1]
-    e = torch.zeros((max(m, 1), fp), dtype=torch.uint8, device='cuda'); s = torch.zeros_like(e)
+    e = torch.zeros((max(m, 1), fp), dtype=torch.uint8, device='cuda')          # the flags of every FASTQ read's alignment
     if m:
-        e[:m, :pitch] = err.index_select(0, d_idx); s[:m, :pitch] = skip.index_select(0, d_idx)
-    return _actual_q(*_count_q(torch.from_numpy(fqual).cuda(), e, s, flens, fp, 33, reduce=world > 1))
+        e[:m, :pitch] = err.index_select(0, d_idx)
+    return _actual_q(*_count_q(torch.from_numpy(fqual).cuda(), e, None, flens, fp, 33, reduce=world > 1))
 
 
 def print_benchmark(actual_q, label, nbases):

@@ -214,7 +214,7 @@ def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxsc
 
     def shard():
         kept = {}
-        err, skip, _, pitch = benchmark._flag_batch(reads, genome, flip_reverse=False, keep=kept, rows=(lo, hi))
+        err, skip, _, pitch = benchmark._flag_batch(reads, genome, flip_reverse=False, keep=kept, rows=(lo, hi), fused=True)
         oq = reads.batch().plane(2, pitch, lo, m) if native else oq_all[lo:hi, :pitch]
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
         d_seq, d_oq = kept['seq'], up(oq)

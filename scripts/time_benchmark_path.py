@@ -73,12 +73,28 @@ def k6():
                                          N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual), N.ptr(batch.meta)))
 def k1():
     dev.accumulate(batch, tables, 6, check=False, dinuc_minscore=6)
+def k4f():
+    N.check(lib.kbbq_find_errors_dev(ctx.handle, N.ptr(seq), N.ptr(lens), n, pitch, N.ptr(start), N.ptr(ref_len),
+                                     N.ptr(cig_off), N.ptr(cig_n), N.ptr(cigar), gptr, mptr, G, N.ptr(flip),
+                                     N.ptr(err), None))
+def k5f():
+    N.check(lib.kbbq_count_q_dev(ctx.handle, N.ptr(qual), N.ptr(err), None, N.ptr(lens), n, pitch, 0, N.ptr(counts)))
+def k4nf():
+    N.check(lib.kbbq_find_errors_dev(ctx.handle, N.ptr(seq), N.ptr(lens), n, pitch, N.ptr(start), N.ptr(ref_len),
+                                     N.ptr(cig_off), N.ptr(cig_n), N.ptr(cigar), gptr, mptr, G, N.ptr(noflip),
+                                     N.ptr(err), None))
+def k6f():
+    N.check(lib.kbbq_canonical_reads_dev(ctx.handle, N.ptr(seq), N.ptr(oq), N.ptr(err), None, N.ptr(lens),
+                                         N.ptr(clip), N.ptr(trim), N.ptr(flags), n, pitch, L, 6, 6,
+                                         N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual), N.ptr(batch.meta)))
 for f, name, bpb in ((k4, 'K4 find_errors', 5), (k5, 'K5 count_q', 3), (k4n, 'K4 (no flip)', 5),
-                     (k6, 'K6 canonical_reads', 7), (k1, 'K1 on canonical reads', 3)):
+                     (k6, 'K6 canonical_reads', 7), (k1, 'K1 on canonical reads', 3),
+                     (k4f, 'K4 find_errors -> flags plane', 4), (k5f, 'K5 count_q <- flags plane', 2),
+                     (k4nf, 'K4 (no flip) -> flags plane', 4), (k6f, 'K6 canonical_reads <- flags plane', 6)):
     f(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(3): f()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+    for _ in range(5): f()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
     print('%s: %.3f ms for %d reads x %d = %.1f Gbases/s, %.0f GB/s algorithmic (%d B/base)' % (
         name, dt * 1e3, n, L, n * L / dt / 1e9, bpb * n * L / dt / 1e9, bpb), flush=True)
 ctx.status()
