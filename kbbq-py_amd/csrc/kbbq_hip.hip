@@ -105,6 +105,8 @@ int kbbq_ctx_create(int device, kbbq_ctx** out)
     (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<true, K1V3_DNREP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<true, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<false, K1V3_DNREP, true, 19>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<true, K1V3_DNREP, true, 19>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k2v3_apply<false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k2v3_apply<true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2_apply<int16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
@@ -770,6 +772,16 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     // instead of 16 free the rest: reads of up to ~300 bases still run this kernel.
     const int trim = (!pairs && S_min > 0) ? std::min(S_min, S) : 0;
     int dn = 0; size_t lds3 = 0;
+    // mate-pair rows of 19 chunks (2 x 150 bp) on 4-bit planes: the chunk-position-major cycle table (kernel comment)
+    const char* km_off = getenv("KBBQ_K1_KM");
+    const bool km = pairs && nib && q.cpr == 19 && !(km_off && !strcmp(km_off, "0"));
+    if (km) {
+        q.row_bytes = (u32)(((16 * 19 + 31) & ~31) * 4);
+        q.minlen = 0; q.slack_bytes = 0;
+        q.dn_flush_iters = std::max(1, 65535 / ((K1V3_THREADS / K1V3_DNREP) * 16 * q.cpr));
+        lds3 = (size_t)q.nrows * 128 * K1V3_DNREP + (size_t)q.nrows * q.row_bytes;
+        if (lds3 <= (size_t)c->lds_bytes) dn = K1V3_DNREP;
+    }
     for (int attempt = 0; attempt < (trim ? 3 : 1) && !dn; ++attempt) {
         const int copies = attempt == 2 ? 8 : K1V3_DNREP, cut = attempt ? trim : 0;
         const int words = (3 * S - cut) | 1;
@@ -792,7 +804,10 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     dim3 grid((unsigned)gx, (unsigned)R, 1), block(K1V3_THREADS, 1, 1);
     {
         Timed t(c, 0);
-        if (nib) {
+        if (km && dn == K1V3_DNREP) {
+            if (split) hipLaunchKernelGGL((k1v3_accumulate<true, K1V3_DNREP, true, 19>), grid, block, lds3, c->stream, q);
+            else hipLaunchKernelGGL((k1v3_accumulate<false, K1V3_DNREP, true, 19>), grid, block, lds3, c->stream, q);
+        } else if (nib) {
             if (dn == K1V3_DNREP) {
                 if (split) hipLaunchKernelGGL((k1v3_accumulate<true, K1V3_DNREP, true>), grid, block, lds3, c->stream, q);
                 else hipLaunchKernelGGL((k1v3_accumulate<false, K1V3_DNREP, true>), grid, block, lds3, c->stream, q);

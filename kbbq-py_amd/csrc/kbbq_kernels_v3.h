@@ -120,7 +120,14 @@ struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int k; int j; int nb; };
 //      rows are ordered by the INVERTED quality byte (row = 42 - q, one v_min clamps every
 //      uncounted byte onto the trash row, which is last); bytes past the end of a short read
 //      (quality 0 -> trash) can index beyond the trash row's end: `slack_bytes` absorb that.
-template <bool SPLIT, int DN = K1V3_DNREP, bool NIB = false>
+// KJ > 0 (mate-pair rows of exactly KJ chunks): the cycle table is laid out CHUNK-POSITION MAJOR -- position 16 j + k of
+// a row lives in word k * KJ + j of a table row whose stride is a multiple of 32 words.  The bank of a lane's atomic is
+// then (k * KJ + j) mod 32 whatever its quality: for the 16-base unroll's fixed k, lanes of one row hit DIFFERENT banks
+// (only the lanes of the next row, 19 chunks on, meet them again: 2 LDS cycles per half-wave), where the
+// position-major layout lets the random quality row pick the bank (a 32-lane half-wave on 32 banks: ~3.5 cycles).
+// Measured (profiles/r02_k1_lds.md): the cycle-table atomics were the larger half of K1's LDS time once the 4-bit
+// sequence planes had made K1 LDS-bound.  The per-base offset 4 * k * KJ is an instruction immediate.
+template <bool SPLIT, int DN = K1V3_DNREP, bool NIB = false, int KJ = 0>
 __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -184,6 +191,20 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
             const int q = KQ - 1 - r;
             const size_t grow = ((size_t)g * KQ + q) * p.gS2;
             u32* prow = pos + (size_t)r * (row_bytes >> 2);
+            if (KJ > 0) {
+                for (int x = lane; x < 16 * KJ; x += 64) {
+                    const u32 v = prow[x];
+                    if (v) {
+                        prow[x] = 0u;
+                        const int k = x / KJ, j = x - k * KJ, at = 16 * j + k;       // byte offset within the mate-pair row
+                        if (at == S || at > S2) continue;                           // separator / padding: never counted
+                        const int col = at < S ? at : (S2 - 1 - (at - S - 1));
+                        atomicAdd(&pos_total[grow + col], (u64)(v & 0xFFFFu));
+                        if (v >> 16) atomicAdd(&pos_errs[grow + col], (u64)(v >> 16));
+                    }
+                }
+                continue;
+            }
             for (int x = lane; x < 3 * S - p.minlen; x += 64) {
                 const u32 v = prow[x];
                 if (v) {
@@ -306,7 +327,7 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                     if (!hiq && fits_tables && !(NIB && badbits)) {
                         // A: pos address less the row term; both mates ascend with the base index
                         const u32 half = second ? (u32)(S + 2 * (S - len)) : 0u;     // column 2*len-1-pos
-                        const u32 A = pos_base + (half + (u32)pos0) * 4u;
+                        const u32 A = KJ > 0 ? pos_base + 4u * (u32)j : pos_base + (half + (u32)pos0) * 4u;
                         u32 pc5 = prev_code5 << 24;
 #pragma unroll
                         for (int wd = 0; wd < 4; ++wd) {
@@ -325,7 +346,7 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
 #else
                                 const u32 inc = ((xwd >> (8 * b)) & 0xFFu) != 0u ? 0x10001u : 1u;
 #endif
-                                const u32 a = __umul24(tq, row_bytes) + A + (u32)(4 * (4 * wd + b));
+                                const u32 a = __umul24(tq, row_bytes) + A + (u32)(KJ > 0 ? 4 * KJ * (4 * wd + b) : 4 * (4 * wd + b));
 #ifndef KBBQ_ABL_NOPOS
                                 atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + a), inc);   // recalibrate.py:116-117
 #else
