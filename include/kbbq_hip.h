@@ -428,6 +428,11 @@ int         kbbq_fastq_close(kbbq_fastq* f);
  * [byte_lo, byte_hi) (record starts from kbbq_fastq_record_offset; byte_hi < 0: to the end; uncompressed files only,
  * kbbq_fastq_is_plain) and take the file-wide read-group names from rank 0 (count NUL-terminated strings). */
 int         kbbq_fastq_open_range(const char* path, int64_t byte_lo, int64_t byte_hi, kbbq_fastq** out);
+/* The first record start at or after `offset` (the file size when there is none; -1 on error): a rank of a multi-GPU
+ * run cuts ITS byte range out of an uncompressed file with it, nobody indexes the whole file (kbbq/fastx.py). */
+int64_t     kbbq_fastq_sync_offset(const char* path, int64_t offset);
+/* skip_second != 0: never cut in front of a second-in-pair record (name field ends with "/2"): mates stay together */
+int64_t     kbbq_fastq_sync_offset_ex(const char* path, int64_t offset, int skip_second);
 int64_t     kbbq_fastq_record_offset(const kbbq_fastq* f, int64_t i);
 int         kbbq_fastq_is_plain(const kbbq_fastq* f);
 int         kbbq_fastq_set_rg_names(kbbq_fastq* f, const char* names, int count);

@@ -200,6 +200,65 @@ static int open_impl(const char* path, int64_t range_lo, int64_t range_hi, kbbq_
 }
 
 int kbbq_fastq_open(const char* path, kbbq_fastq** out) { return open_impl(path, 0, -1, out); }
+int64_t kbbq_fastq_sync_offset_ex(const char* path, int64_t offset, int skip_second);
+
+// The byte offset of the first record that starts at or after `offset` in an uncompressed 4-line FASTQ file (the file
+// size when there is none): how a rank of a multi-GPU run finds ITS part of the file without anybody having indexed all
+// of it.  A record starts at a line that begins with '@' and whose second-next line begins with '+': a quality line may
+// begin with '@' too, but the line two below it is a sequence line, which cannot begin with '+'.  Deterministic: every
+// rank computes the same cut for the same offset.  Returns -1 on error.
+int64_t kbbq_fastq_sync_offset(const char* path, int64_t offset)
+{
+    return kbbq_fastq_sync_offset_ex(path, offset, 0);
+}
+
+// skip_second != 0: a record whose name says "second in pair" (compare_reads.py:304-306: the first '_' field ends with
+// "/2") is not a cut point -- the cut moves on to the next record, so that mates stay in one rank's range.
+int64_t kbbq_fastq_sync_offset_ex(const char* path, int64_t offset, int skip_second)
+{
+    if (!path || offset < 0) { kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_sync_offset: bad argument"); return -1; }
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) { kbbq_set_error_(KBBQ_E_ARG, (std::string("cannot open ") + path).c_str()); return -1; }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); kbbq_set_error_(KBBQ_E_ARG, "fstat failed"); return -1; }
+    const int64_t size = (int64_t)st.st_size;
+    if (offset == 0 || offset >= size) { close(fd); return offset == 0 ? 0 : size; }
+    std::vector<char> buf;
+    int64_t result = -2;
+    for (size_t window = 1 << 16; result == -2; window <<= 2) {
+        const int64_t from = offset - 1;                              // one byte back: is `offset` itself a line start?
+        const size_t want = (size_t)std::min<int64_t>((int64_t)window, size - from);
+        buf.resize(want);
+        size_t got = 0;
+        while (got < want) {
+            const ssize_t k = pread(fd, buf.data() + got, want - got, from + (int64_t)got);
+            if (k <= 0) break;
+            got += (size_t)k;
+        }
+        if (got < want) { close(fd); kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_sync_offset: read failed"); return -1; }
+        const bool whole = from + (int64_t)want == size;
+        // line starts inside the window (as offsets into buf)
+        std::vector<size_t> starts;
+        for (size_t i = 0; i + 1 < want; ++i) if (buf[i] == '\n') starts.push_back(i + 1);
+        for (size_t k = 0; k < starts.size() && result == -2; ++k) {
+            if (buf[starts[k]] != '@') continue;
+            if (k + 2 < starts.size()) {
+                if (buf[starts[k + 2]] != '+') continue;
+                if (skip_second) {
+                    size_t e = starts[k] + 1;                          // name: up to the first whitespace; its first '_' field
+                    while (e < starts[k + 1] - 1 && buf[e] != ' ' && buf[e] != '\t' && buf[e] != '_' && buf[e] != '\r') ++e;
+                    if (e >= starts[k] + 3 && buf[e - 2] == '/' && buf[e - 1] == '2') continue;
+                }
+                result = from + (int64_t)starts[k];
+            }
+            else if (!whole) break;                                   // the deciding line is beyond the window: read more
+        }
+        if (result == -2 && whole) result = size;                     // no further record
+        if (window > ((size_t)1 << 30)) { result = size; }
+    }
+    close(fd);
+    return result;
+}
 
 // Only the records inside the byte range [byte_lo, byte_hi) of an uncompressed file (both must be record starts, as
 // kbbq_fastq_record_offset gives them; byte_hi < 0: to the end): what one rank of a multi-GPU run needs once rank 0

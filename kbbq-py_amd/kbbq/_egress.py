@@ -86,14 +86,14 @@ def _slabs(bands, outs, step):
             k += 1
 
 
-def emit_records(text, base, bands, outs, slab=1 << 18):
+def emit_records(text, base, bands, outs, slab=1 << 18, sink=None):
     """Print the recalibrated records of this rank -- reads base + band['first'] + row of the fastx.NativeFastq `text`,
     new quality characters in the device planes `outs` (one per band) -- to sys.stdout, rendered by the C++ writer in
     slabs.  A binary stdout gets the bytes through the three-stage pipeline above (copy off the device into
     page-locked buffers | rendering into re-used buffers | write(2)); a text-only stdout (StringIO) gets print(),
     like the reference."""
     sys.stdout.flush()
-    raw = getattr(sys.stdout, 'buffer', None)
+    raw = sink if sink is not None else getattr(sys.stdout, 'buffer', None)      # sink: a binary file of the caller's
     if raw is None:
         for _, band, out, first, m in _slabs(bands, outs, 1 << 20):
             newq = out[first:first + m].cpu().numpy()

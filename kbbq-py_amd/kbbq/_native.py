@@ -108,6 +108,8 @@ PROTOTYPES = {
     'kbbq_fastq_close': (_i, [_vp]),
     'kbbq_fastq_open_range': (_i, [_c.c_char_p, _i64, _i64, _c.POINTER(_vp)]),
     'kbbq_fastq_record_offset': (_i64, [_vp, _i64]),
+    'kbbq_fastq_sync_offset': (_i64, [_c.c_char_p, _i64]),
+    'kbbq_fastq_sync_offset_ex': (_i64, [_c.c_char_p, _i64, _i]),
     'kbbq_fastq_is_plain': (_i, [_vp]),
     'kbbq_fastq_set_rg_names': (_i, [_vp, _c.c_char_p, _i]),
     'kbbq_fastq_count': (_i64, [_vp]),

@@ -459,6 +459,14 @@ class PairScan:
         _N.check(_N.load().kbbq_fastq_pair_wait(job, _ct.byref(a), _ct.byref(b), _N.ptr(info)))
         return NativeFastq(None, _handle=a), (NativeFastq(None, _handle=b) if self._has_b else None), [int(x) for x in info]
 
+    def discard(self):
+        """Join the job and drop its readers (the caller opened the files another way)."""
+        if getattr(self, '_job', None) is not None:
+            try:
+                self.result()
+            except Exception:
+                pass
+
     def __del__(self):
         try:
             if getattr(self, '_job', None) is not None:
@@ -479,7 +487,91 @@ def _shard_plan(A, B, scanned, world):
                 plain=A.is_plain() and B.is_plain())
 
 
-def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None, to_device=False, exchange=None):
+def _is_gzip(path):
+    with open(path, 'rb') as fh:
+        return fh.read(2) == b'\x1f\x8b'
+
+
+def local_ranges(path_a, path_b, infer_rg_flag, rank, world, gather):
+    """The multi-rank opening of a pair in which NOBODY reads a whole file: every rank cuts its own
+    byte range out of either file (cut r = the first record start at or after size * r / world that is not a
+    second-in-pair record: kbbq_fastq_sync_offset_ex, computed identically by both ranks that share the cut), indexes
+    and scans only that, and ONE all_gather_object carries what is file-wide: record counts (-> every rank's first
+    record number), read-group names in first-appearance order (merged in rank order), the longest read, the first
+    read's length (a first read shorter than the longest read of the ranks before it is the reference's IndexError,
+    recalibrate.py:89-101) and the first offender each rank's own scan found.
+    Returns (A, B, [usable, S, R, kind, idx]) with A / B range readers numbered file-wide, or None when the two files
+    do not cut into the same records (different record counts per range: the corrected file is shorter, or its lines
+    have other lengths; compressed input) -- the caller then falls back to the plan of a rank that scans everything.
+    `gather`: obj -> the list of every rank's obj (parallel.all_gather_object)."""
+    import os
+    lib = _N.load()
+    plain = not _is_gzip(path_a) and not _is_gzip(path_b)
+    A = B = None
+    mine = dict(plain=plain, nA=0, nB=0, scan=None, rgs=[], len0=0, error=None)
+    if plain:
+        try:
+            def cuts(path):
+                size = os.path.getsize(path)
+                lo, hi = (int(lib.kbbq_fastq_sync_offset_ex(str(path).encode(), size * r // world, 1)) if 0 < r < world
+                          else (0 if r == 0 else size) for r in (rank, rank + 1))
+                if lo < 0 or hi < 0:
+                    _N.check(_N.KBBQ_E_ARG)
+                return lo, max(hi, lo)
+            a_lo, a_hi = cuts(path_a)
+            A = NativeFastq.open_range(path_a, a_lo, a_hi, 0, 0)
+            b_lo, b_hi = cuts(path_b)
+            B = NativeFastq.open_range(path_b, b_lo, b_hi, 0, 0)
+            mine.update(nA=A.n, nB=B.n)
+            if A.n == B.n:
+                mine['scan'] = A.scan(B, infer_rg_flag)
+                mine['rgs'] = A.rg_names()
+                mine['len0'] = int(A.lengths(0, 1)[0]) if A.n else 0
+        except Exception as e:               # noqa: BLE001 -- every rank must reach the gather
+            mine['error'] = (type(e).__name__, str(e))
+    everyone = gather(mine)
+    for o in everyone:                                           # a rank that could not read its range stops them all
+        if o['error'] is not None:
+            import builtins
+            raise getattr(builtins, o['error'][0], RuntimeError)(o['error'][1])
+    if not all(o['plain'] and o['nA'] == o['nB'] and o['scan'] is not None for o in everyone):
+        for f in (A, B):
+            if f is not None:
+                f.close()
+        return None
+    firsts = np.concatenate([[0], np.cumsum([o['nA'] for o in everyone])]).astype(np.int64)
+    total = int(firsts[-1])
+    # the first offender, file-wide: every rank's own (made file-wide), and a first read shorter than what came before
+    err = None                                                   # (index, kind)
+    longest_before = 0
+    S = 0
+    order = {}
+    for r, o in enumerate(everyone):
+        usable_r, S_r, R_r, kind_r, idx_r = o['scan']
+        cand = []
+        if kind_r:
+            cand.append((int(firsts[r]) + idx_r, kind_r))
+        if o['nA'] and o['len0'] < longest_before:
+            cand.append((int(firsts[r]), 5))
+        for nm in o['rgs']:
+            order.setdefault(nm, len(order))
+        if cand:
+            err = min(cand)
+            S = max(S, S_r if err == (int(firsts[r]) + idx_r, kind_r) and kind_r else o['len0'])
+            break
+        S = max(S, S_r)
+        longest_before = max(longest_before, S_r)
+    usable = total if err is None else err[0] + (1 if err[1] == 5 else 0)
+    rgs = list(order) if infer_rg_flag else (['0'] if total else [])
+    R = (len(rgs) if infer_rg_flag else 1) if usable > 0 else 0
+    blob = b''.join(str(x).encode('ascii') + b'\0' for x in rgs)
+    for f in (A, B):
+        f.first, f.total = int(firsts[rank]), total
+        _N.check(lib.kbbq_fastq_set_rg_names(f._h, blob, len(rgs)))
+    return A, B, [usable, S, R, err[1] if err else 0, err[0] if err else -1]
+
+
+def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None, to_device=False, exchange=None, gather=None):
     """Pass-1 input (recalibrate.py:56-57) through the C++ packer; same dictionary as pack_pair_py
     except that `text` is the NativeFastq of file A and `names` is filled lazily by callers.
     shard = (rank, world): the rank packs only its own records [first, first + n); `total` is the global number of
@@ -495,7 +587,19 @@ def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None,
     planned = exchange is not None and world > 1
     A = B = scanned = None
     failure = None
-    if not planned or rank == 0:
+    own_range = None                         # (first, n): this rank's records when the ranks cut their own byte ranges
+    if gather is not None and world > 1:
+        with stage('open+index+scan (own byte range)'):
+            got = local_ranges(path_a, path_b, infer_rg_flag, rank, world, gather)
+        if got is not None:
+            A, B, scanned = got
+            own_range = (A.first, A.n)
+            planned = False
+            if scan is not None:
+                scan.discard()
+    if own_range is not None:
+        pass
+    elif not planned or rank == 0:
         try:
             with stage('open+index+scan (wait)'):
                 A, B, scanned = (scan or PairScan(path_a, path_b, infer_rg_flag)).result()
@@ -528,7 +632,13 @@ def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None,
     total, S, R, kind, idx = scanned
     pending = (idx, _SCAN_ERRORS[kind](idx), kind == 5) if kind else None
     pitch = pitch_for(S)
-    lo, hi = _shard(total, shard)
+    if own_range is not None:                # this rank's own records, cut at the first offender
+        lo = min(own_range[0], total)
+        hi = min(own_range[0] + own_range[1], total)
+        if hi <= lo:                         # everything this rank holds lies behind the first offender
+            lo = hi = own_range[0]
+    else:
+        lo, hi = _shard(total, shard)
     rgs = A.rg_names()
     common = dict(n=hi - lo, first=lo, total=total, pitch=pitch, S=S, R=R,
                   rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)},

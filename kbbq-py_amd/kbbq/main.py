@@ -13,7 +13,7 @@ def recalibrate(args):
     from . import parallel
     parallel.init_from_env()          # one process per GPU under torch.distributed.run; no-op otherwise
     _recal.recalibrate(bam=args.bam, fastq=args.fastq, infer_rg=args.infer_rg,
-                       use_oq=args.use_oq, set_oq=args.set_oq, gatkreport=args.gatkreport)
+                       use_oq=args.use_oq, set_oq=args.set_oq, gatkreport=args.gatkreport, output=args.output)
 
 
 def benchmark(args):
@@ -42,6 +42,9 @@ def main():
     rp.add_argument('-s', '--set-oq', action='store_true',
                     help="Set the 'OQ' tag before recalibration (BAM output only).")
     rp.add_argument('-g', '--gatkreport', help='Load the model from / save it to a GATK report.')
+    rp.add_argument('-o', '--output', default=None,
+                    help='Write the recalibrated FASTQ to this file instead of stdout (not in the reference); under '
+                         'torch.distributed.run every rank writes FILE.rankNNNN, to be concatenated in rank order.')
     rp.add_argument('--infer-rg', action='store_true',
                     help='Infer the read group from the FASTQ read name (name_RG:Z:id).')
     rp.set_defaults(command=recalibrate)

@@ -65,6 +65,16 @@ def broadcast_object(obj, src=0):
     return box[0]
 
 
+def all_gather_object(obj):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (any picklable objects); without a process group: [obj]."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return [obj]
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, obj)
+    return everyone
+
+
 def world_rank():
     """(world size, rank) of the initialised process group, (1, 0) without one."""
     dist = _dist()

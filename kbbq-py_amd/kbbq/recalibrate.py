@@ -120,12 +120,15 @@ def _pack_and_tally(fastq, infer_rg, minscore, maxscore):
     world, rank = parallel.world_rank()
     # rank 0 (or the only process) opens and scans the pair on the reader's own threads -- no interpreter lock needed --
     # while the device warms up; the other ranks then index only the byte ranges of their shards (fastx.pack_pair)
-    scan = fastx.PairScan(fastq[0], fastq[1], infer_rg) if rank == 0 else None
+    # (several ranks: every rank cuts, indexes and scans its own byte range of either file -- fastx.local_ranges -- and
+    # only when the files do not cut alike does rank 0 scan all of them for a plan)
+    scan = fastx.PairScan(fastq[0], fastq[1], infer_rg) if world == 1 else None
     _warm_up()
     failure, packed = None, None
     try:
         packed = fastx.pack_pair(fastq[0], fastq[1], infer_rg, shard=(rank, world) if world > 1 else None, bands=True,
-                                 scan=scan, to_device=True, exchange=parallel.broadcast_object if world > 1 else None)
+                                 scan=scan, to_device=True, exchange=parallel.broadcast_object if world > 1 else None,
+                                 gather=parallel.all_gather_object if world > 1 else None)
     except Exception as e:                   # noqa: BLE001 -- one rank's failure (its shard unreadable, out of memory) stops them all
         failure = e
     parallel.raise_first_error(failure, 0)
@@ -190,7 +193,7 @@ def _collective(fn, first=0):
     return res
 
 
-def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
+def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None, output=None):
     """Recalibrate FASTQ file fastq[0] using its error-corrected version fastq[1];
     the recalibrated FASTQ is printed to stdout.  K1 -> K3 -> K2, tables and LUT stay on
     the device between the kernels.  gatkreport (the reference declares the option and raises
@@ -198,7 +201,10 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
     is not read); otherwise the model of pass 1 is saved there.
     Under torch.distributed (one process per GPU, parallel.init_from_env) every rank takes a contiguous
     shard of the records, the count tables are summed with one allreduce, the solve is replicated and
-    the ranks print their records in rank order: the concatenated output is the single-process output."""
+    the ranks print their records in rank order: the concatenated output is the single-process output.
+    output (not in the reference, which only prints): write the records to this file instead of stdout; with several
+    ranks every rank writes ITS records to `output`.rankNNNN at the same time (the files, concatenated in rank order,
+    are the single-process output) -- ranks sharing one stdout can only write in turn."""
     world, rank = parallel.world_rank()
     shard = (rank, world) if world > 1 else None
     packed, single = None, None
@@ -266,7 +272,11 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None):
 
     # recalibrate.py:153-156: '@' + name, sequence, '+', qualities
     from . import _egress
-    parallel.in_rank_order(lambda: _egress.emit_records(text, single['first'], single['bands'], outs))
+    if output is None:
+        parallel.in_rank_order(lambda: _egress.emit_records(text, single['first'], single['bands'], outs))
+    else:
+        with open(output if world == 1 else '%s.rank%04d' % (output, rank), 'wb') as sink:
+            _egress.emit_records(text, single['first'], single['bands'], outs, sink=sink)
 
 
 def recalibrate_bam(bam, use_oq=False, set_oq=False):
@@ -275,7 +285,7 @@ def recalibrate_bam(bam, use_oq=False, set_oq=False):
                               'Convert the BAM to FASTQ with `samtools fastq` first.')
 
 
-def recalibrate(bam, fastq, infer_rg=False, use_oq=False, set_oq=False, gatkreport=None):
+def recalibrate(bam, fastq, infer_rg=False, use_oq=False, set_oq=False, gatkreport=None, output=None):
     """Dispatcher of `kbbq recalibrate` (reference recalibrate.py:166-174).  The reference raises NotImplementedError
     for ANY gatkreport; here `-g` works with FASTQ input (a deliberate, documented divergence: SURVEY.md 8(f) #3), and
     the cases that stay unimplemented -- no FASTQ input, or a BAM -- raise NotImplementedError as the reference does."""
@@ -285,6 +295,6 @@ def recalibrate(bam, fastq, infer_rg=False, use_oq=False, set_oq=False, gatkrepo
         recalibrate_bam(bam, use_oq, set_oq)
     elif fastq is not None:
         with stage('[recalibrate_fastq, wall]'):
-            recalibrate_fastq(fastq, infer_rg=infer_rg, gatkreport=gatkreport)
+            recalibrate_fastq(fastq, infer_rg=infer_rg, gatkreport=gatkreport, output=output)
     else:
         raise ValueError('A BAM or FASTQ file should be provided for recalibration.')

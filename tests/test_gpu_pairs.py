@@ -179,6 +179,35 @@ def test_two_ranks_print_the_reference_output(dev, oracle, name, tmp_path):
     assert len(text) == info['output_len'] and oracle.sha256(text) == info['output_sha256']
 
 
+@pytest.mark.parametrize('name,world', [('c1_10k_1rg', 2), ('c3cut_2k_8rg', 3), ('c5cut_2k_mixed', 2)])
+def test_ranks_write_their_own_files(dev, oracle, name, world, tmp_path):
+    """`kbbq recalibrate -o FILE` under torch.distributed.run: every rank cuts, indexes and scans its own byte range of
+    the two files (no rank reads a whole file), tallies it, and writes FILE.rankNNNN at the same time; the files
+    concatenated in rank order are the reference's output, and nothing goes to stdout."""
+    import glob, os
+    from conftest import load_golden
+    from test_gpu_parity import _files
+    info, _ = load_golden(name)
+    fa, fb = _files(oracle, info, tmp_path)
+    out = str(tmp_path / 'out.fq')
+    argv = ['recalibrate', '-f', fa, fb, '-o', out] + (['--infer-rg'] if info['case']['infer_rg'] else [])
+    env_timing = dict(KBBQ_TIMING='1')
+    os.environ.update(env_timing)
+    try:
+        r = _run_ranks(world, argv)
+    finally:
+        os.environ.pop('KBBQ_TIMING')
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout == b''
+    parts = sorted(glob.glob(out + '.rank*'))
+    assert len(parts) == world and all(os.path.getsize(p) > 0 for p in parts)
+    text = b''.join(open(p, 'rb').read() for p in parts).decode()
+    assert len(text) == info['output_len'] and oracle.sha256(text) == info['output_sha256']
+    # the stage report of every rank names its own byte range, never a whole-file scan
+    err = r.stderr.decode()
+    assert err.count('open+index+scan (own byte range)') == world and 'open+index+scan (wait)' not in err
+
+
 def test_two_ranks_agree_on_the_first_error(dev, oracle, tmp_path):
     """A quality above 42 in the second rank's shard: every rank raises the IndexError (no rank is left in the
     allreduce), nothing is printed."""

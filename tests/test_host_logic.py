@@ -385,6 +385,100 @@ def test_sharded_packing_concatenates_to_the_whole(oracle, tmp_path):
         assert np.array_equal(np.concatenate([p['qual'] for p in singles]), whole['qual'])
 
 
+def _ranks_in_threads(world, fn):
+    """fn(rank, gather) on `world` threads with a gather that works like all_gather_object: the results in rank order."""
+    import threading
+    barrier, box, results, errors = threading.Barrier(world), [None] * world, [None] * world, [None] * world
+
+    def worker(rank):
+        def gather(obj):
+            box[rank] = obj
+            barrier.wait()
+            everyone = list(box)
+            barrier.wait()
+            return everyone
+        try:
+            results[rank] = fn(rank, gather)
+        except Exception as e:               # noqa: BLE001
+            errors[rank] = e
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    return results, errors
+
+
+def test_every_rank_cuts_its_own_byte_range(oracle, tmp_path):
+    """The multi-rank opening in which nobody reads a whole file (fastx.local_ranges): byte cuts at record starts (never
+    in front of a second-in-pair read), one gather of counts / read groups / longest read / first offender; the ranks'
+    packed reads concatenate to the single-process packing, the file-wide facts equal the whole-file scan's."""
+    info, _ = load_golden('c5cut_2k_mixed')
+    c = info['case']
+    n = 1201
+    seq, cseq, qual, meta = oracle.synth(0, n, c['n'], c['seed'], c['len_lo'], c['len_hi'], c['nrg'])
+    names = oracle.synth_names(0, n, c['nrg'], with_rg=True)
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, names, cseq, qual, meta)
+    whole = fastx.pack_pair(fa, fb, True)
+    for world in (2, 3, 5):
+        parts, errors = _ranks_in_threads(world, lambda r, g: fastx.pack_pair(fa, fb, True, shard=(r, world), gather=g))
+        assert not any(errors), errors
+        assert [p['first'] for p in parts] == [sum(q['n'] for q in parts[:i]) for i in range(world)]
+        assert all(p['first'] % 2 == 0 for p in parts) and sum(p['n'] for p in parts) == whole['n'] == parts[0]['total']
+        assert all(p['n'] > 0 for p in parts) and len({p['n'] for p in parts}) > 1          # byte cuts, not equal counts
+        for k in ('seq', 'cseq', 'qual', 'meta'):
+            assert np.array_equal(np.concatenate([p[k] for p in parts]), whole[k]), k
+        assert all((p['S'], p['R'], p['pitch'], p['rg_to_int']) == (whole['S'], whole['R'], whole['pitch'], whole['rg_to_int'])
+                   for p in parts)
+        text = b''.join(p['text'].format(p['first'], p['n'], p['qual']) for p in parts)
+        assert text == open(fa, 'rb').read()
+    # the first offender is a file-wide fact: a read shorter than an earlier one, in another rank's range
+    lens = (meta & 0xFFFF).astype(int)
+    bad = 900
+    lines = open(fa).read().split('\n')
+    linesb = open(fb).read().split('\n')
+    keep = max(lens[bad] - 9, 1)
+    for L in (lines, linesb):
+        L[4 * bad + 1] = L[4 * bad + 1][:keep]; L[4 * bad + 3] = L[4 * bad + 3][:keep]
+    open(fa, 'w').write('\n'.join(lines)); open(fb, 'w').write('\n'.join(linesb))
+    want = fastx.pack_pair(fa, fb, True)
+    assert want['pending_error'][0] == bad and isinstance(want['pending_error'][1], IndexError)
+    parts, errors = _ranks_in_threads(3, lambda r, g: fastx.pack_pair(fa, fb, True, shard=(r, 3), gather=g))
+    assert not any(errors), errors
+    for p in parts:
+        assert p['pending_error'][0] == bad and isinstance(p['pending_error'][1], IndexError) and p['total'] == want['total']
+    assert sum(p['n'] for p in parts) == want['n']
+    # ... and when a rank's FIRST read is shorter than the reads of the rank before it
+    oracle.write_fastq(fa, names, seq, qual, meta); oracle.write_fastq(fb, names, cseq, qual, meta)
+    probe, _ = _ranks_in_threads(2, lambda r, g: fastx.pack_pair(fa, fb, True, shard=(r, 2), gather=g))
+    cut = probe[1]['first']
+    lines = open(fa).read().split('\n'); linesb = open(fb).read().split('\n')
+    keep = max(lens[cut] - 5, 1)
+    for L in (lines, linesb):
+        L[4 * cut + 1] = L[4 * cut + 1][:keep]; L[4 * cut + 3] = L[4 * cut + 3][:keep]
+    open(fa, 'w').write('\n'.join(lines)); open(fb, 'w').write('\n'.join(linesb))
+    want = fastx.pack_pair(fa, fb, True)
+    parts, errors = _ranks_in_threads(2, lambda r, g: fastx.pack_pair(fa, fb, True, shard=(r, 2), gather=g))
+    assert not any(errors), errors
+    assert all(p['pending_error'][0] == want['pending_error'][0] == cut for p in parts)
+    # files that do not cut alike (the corrected file is shorter): the ranks fall back to rank 0's plan
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, names[:800], cseq[:800], qual[:800], meta[:800])
+    want = fastx.pack_pair(fa, fb, True)
+
+    def fallback(r, g):
+        def exchange(obj):
+            return g(obj)[0]
+        return fastx.pack_pair(fa, fb, True, shard=(r, 2), gather=g, exchange=exchange)
+    parts, errors = _ranks_in_threads(2, fallback)
+    assert not any(errors), errors
+    assert sum(p['n'] for p in parts) == want['n'] == 800 and parts[0]['total'] == 800
+    for k in ('seq', 'cseq', 'qual', 'meta'):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), want[k]), k
+
+
 def test_gzip_fastq_is_read_like_plain_text(oracle, tmp_path):
     """pysam.FastxFile reads .gz transparently; so does the native reader (zlib, all gzip members)."""
     import gzip
