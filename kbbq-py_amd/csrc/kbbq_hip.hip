@@ -1041,8 +1041,8 @@ int kbbq_lay_out_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq, c
     p.meta = d_meta; p.dmeta = d_lmeta; p.perm = reinterpret_cast<const long long*>(d_perm);
     p.nrows = pairs ? nreads / 2 : nreads; p.pitch = pitch; p.dpitch = pairs ? pair_pitch(S2) : pitch; p.S = pairs ? S2 / 2 : 0;
     p.pairs = pairs; p.nib = nib; p.status = c->d_status;
-    const int64_t nchunks = p.nrows * (p.dpitch / 16);
-    int gx = (int)std::min<int64_t>((nchunks + 255) / 256, (int64_t)c->cus * 16);
+    const int rpb7 = (p.dpitch / 16) <= 256 ? 256 / (p.dpitch / 16) : 1;      // destination rows per workgroup iteration
+    int gx = (int)std::min<int64_t>((p.nrows + rpb7 - 1) / rpb7, (int64_t)c->cus * 16);
     hipLaunchKernelGGL(k7_lay_out, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;

@@ -186,72 +186,101 @@ struct LayOutParams {
     u64* status;
 };
 
+// byte i <- byte i - nb (0 <= nb <= 15), zero fill: the inverse of shr_bytes16
+__device__ __forceinline__ void shl_bytes16(u32 v[4], int nb)
+{
+    const int ws = nb >> 2; const u32 bs = (u32)(nb & 3) * 8u;
+    const u32 a3 = ws == 0 ? v[3] : ws == 1 ? v[2] : ws == 2 ? v[1] : v[0];
+    const u32 a2 = ws == 0 ? v[2] : ws == 1 ? v[1] : ws == 2 ? v[0] : 0u;
+    const u32 a1 = ws == 0 ? v[1] : ws == 1 ? v[0] : 0u;
+    const u32 a0 = ws == 0 ? v[0] : 0u;
+    // (hi:lo) >> (32 - bs) for bs in {0, 8, 16, 24}; bs == 0 keeps the word
+    v[3] = bs ? __builtin_amdgcn_alignbit(a3, a2, 32u - bs) : a3;
+    v[2] = bs ? __builtin_amdgcn_alignbit(a2, a1, 32u - bs) : a2;
+    v[1] = bs ? __builtin_amdgcn_alignbit(a1, a0, 32u - bs) : a1;
+    v[0] = a0 << bs;
+}
+
+// 16 bytes from plane[at .. at + 16) where `at` may be up to 15 bytes before the plane's start or run up to 15 bytes past
+// its end (`limit` bytes): ONE unconditional 16-byte load at the clamped offset, then a byte shift -- bytes outside the
+// plane come back zero.  (A load under a branch parks the wave at the branch's end; see kbbq_aligned_kernels.h.)
+__device__ __forceinline__ void load16_clamped(const uint8_t* plane, long long at, long long limit, u32 out[4])
+{
+    const long long hi = limit - 16;                                   // limit >= 16: the caller's planes are at least one chunk
+    const long long c = at < 0 ? 0 : (at > hi ? hi : at);
+    load16_any(plane, c, out);
+    if (at < 0) shl_bytes16(out, (int)(-at));
+    else if (at > hi) shr_bytes16(out, (int)(at - hi));
+}
+
+// a workgroup takes 256 / cpr whole destination rows per iteration: (row slot, chunk) of a thread are fixed, no division
+// per chunk; every load is unconditional
 __global__ __launch_bounds__(256) void k7_lay_out(LayOutParams p)
 {
     const int cpr = p.dpitch >> 4;
-    const long long nchunks = p.nrows * cpr;
     const int S = p.S;
-    for (long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks; ch += (long long)gridDim.x * blockDim.x) {
-        const long long d = ch / cpr;
-        const int j = (int)(ch - d * cpr);
+    const int rpb = cpr <= 256 ? 256 / cpr : 1;
+    const int slot = cpr <= 256 ? (int)threadIdx.x / cpr : 0;
+    const int j0 = (int)threadIdx.x - slot * cpr;
+    const bool idle = cpr <= 256 && slot >= rpb;
+    const long long src_rows = p.pairs ? 2 * p.nrows : p.nrows;
+    const long long limit = src_rows * (long long)p.pitch;              // bytes in a source plane (perm is a permutation)
+    for (long long rb = (long long)blockIdx.x * rpb; rb < p.nrows; rb += (long long)gridDim.x * rpb) {
+        const long long d = rb + slot;
+        if (idle || d >= p.nrows) continue;
         const long long r = p.perm ? p.perm[d] : d;
-        u32 o[3][4];
-        if (p.pairs) {
-            const long long limit = 2 * p.nrows * (long long)p.pitch;     // bytes in a source plane (perm is a permutation)
-            if (j == 0) p.dmeta[d] = (u32)(2 * S + 1) | (p.meta[2 * r] & 0x7FFF0000u);
+        for (int j = j0; j < cpr; j += 256) {
+            u32 o[3][4];
+            if (p.pairs) {
+                if (j == 0) p.dmeta[d] = (u32)(2 * S + 1) | (p.meta[2 * r] & 0x7FFF0000u);
+                // bytes [16j, 16j+16) of the pair row: mate 1 from its offset 16j, mate 2 from its offset 16j - S - 1
+                const long long at1 = (2 * r) * (long long)p.pitch + (16 * j < p.pitch ? 16 * j : p.pitch - 16);
+                const long long at2 = (2 * r + 1) * (long long)p.pitch + (16 * j - S - 1 < -15 ? 0 : 16 * j - S - 1);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                if (!p.src[pl]) continue;
-                const u32 f4 = pl == 2 ? 0u : 0x4E4E4E4Eu;
-                u32 a[4], b[4];
-                load16_upto(p.src[pl], (2 * r) * (long long)p.pitch + 16 * j, limit, a);
-                const long long off2 = (2 * r + 1) * (long long)p.pitch + (16 * j - S - 1);
-                if (16 * j + 15 > S) {
-                    if (16 * j - S - 1 >= 0) load16_upto(p.src[pl], off2, limit, b);
-                    else {                                                   // the chunk holding the separator
-                        b[0] = b[1] = b[2] = b[3] = 0u;
-                        for (int k = S + 1 - 16 * j; k < 16; ++k)
-                            b[k >> 2] |= (u32)p.src[pl][off2 + k] << (8 * (k & 3));
+                for (int pl = 0; pl < 3; ++pl) {
+                    if (!p.src[pl]) continue;
+                    const u32 f4 = pl == 2 ? 0u : 0x4E4E4E4Eu;
+                    u32 a[4], b[4];
+                    load16_any(p.src[pl], at1, a);
+                    load16_clamped(p.src[pl], at2, limit, b);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const u32 m1 = 16 * j < p.pitch ? byte_mask(S - 16 * j, w) : 0u;
+                        const u32 m2 = range_mask(S + 1 - 16 * j, 2 * S + 1 - 16 * j, w);
+                        o[pl][w] = (a[w] & m1) | (b[w] & m2) | (f4 & ~(m1 | m2));
                     }
-                } else { b[0] = b[1] = b[2] = b[3] = 0u; }
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const u32 m1 = byte_mask(S - 16 * j, w);
-                    const u32 m2 = range_mask(S + 1 - 16 * j, 2 * S + 1 - 16 * j, w);
-                    o[pl][w] = (a[w] & m1) | (b[w] & m2) | (f4 & ~(m1 | m2));
                 }
-            }
-        } else {
-            const u32 m = p.meta[r];
-            const int len = (int)(m & 0xFFFFu);
-            if (j == 0) p.dmeta[d] = m;
-            const size_t off = (size_t)r * p.pitch + (size_t)16 * j;
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                if (!p.src[pl]) continue;
-                const u32 f4 = pl == 2 ? 0u : 0x4E4E4E4Eu;
-                uint4 v = make_uint4(f4, f4, f4, f4);
-                if (16 * j < p.pitch) v = *reinterpret_cast<const uint4*>(p.src[pl] + off);
-                const u32 a[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const u32 m1 = byte_mask(len - 16 * j, w);
-                    o[pl][w] = (a[w] & m1) | (f4 & ~m1);
-                }
-            }
-        }
-        *reinterpret_cast<uint4*>(p.dst[2] + (size_t)d * p.dpitch + (size_t)16 * j) = make_uint4(o[2][0], o[2][1], o[2][2], o[2][3]);
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            if (!p.src[pl]) continue;
-            if (p.nib) {
-                u32 bad = 0u;
-                const u32 c0 = chars_to_codes(o[pl][0], bad), c1 = chars_to_codes(o[pl][1], bad);
-                const u32 c2 = chars_to_codes(o[pl][2], bad), c3 = chars_to_codes(o[pl][3], bad);
-                if (bad) flag(p.status, ST_LUT, 0);
-                *reinterpret_cast<uint2*>(p.dst[pl] + (size_t)d * (p.dpitch >> 1) + (size_t)8 * j) = make_uint2(c0 | (c1 << 4), c2 | (c3 << 4));
             } else {
-                *reinterpret_cast<uint4*>(p.dst[pl] + (size_t)d * p.dpitch + (size_t)16 * j) = make_uint4(o[pl][0], o[pl][1], o[pl][2], o[pl][3]);
+                const u32 m = p.meta[r];
+                const int len = (int)(m & 0xFFFFu);
+                if (j == 0) p.dmeta[d] = m;
+                const size_t off = (size_t)r * p.pitch + (size_t)16 * j;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    if (!p.src[pl]) continue;
+                    const u32 f4 = pl == 2 ? 0u : 0x4E4E4E4Eu;
+                    const uint4 v = *reinterpret_cast<const uint4*>(p.src[pl] + off);
+                    const u32 a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const u32 m1 = byte_mask(len - 16 * j, w);
+                        o[pl][w] = (a[w] & m1) | (f4 & ~m1);
+                    }
+                }
+            }
+            *reinterpret_cast<uint4*>(p.dst[2] + (size_t)d * p.dpitch + (size_t)16 * j) = make_uint4(o[2][0], o[2][1], o[2][2], o[2][3]);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                if (!p.src[pl]) continue;
+                if (p.nib) {
+                    u32 bad = 0u;
+                    const u32 c0 = chars_to_codes(o[pl][0], bad), c1 = chars_to_codes(o[pl][1], bad);
+                    const u32 c2 = chars_to_codes(o[pl][2], bad), c3 = chars_to_codes(o[pl][3], bad);
+                    if (bad) flag(p.status, ST_LUT, 0);
+                    *reinterpret_cast<uint2*>(p.dst[pl] + (size_t)d * (p.dpitch >> 1) + (size_t)8 * j) = make_uint2(c0 | (c1 << 4), c2 | (c3 << 4));
+                } else {
+                    *reinterpret_cast<uint4*>(p.dst[pl] + (size_t)d * p.dpitch + (size_t)16 * j) = make_uint4(o[pl][0], o[pl][1], o[pl][2], o[pl][3]);
+                }
             }
         }
     }
