@@ -182,11 +182,12 @@ bool kbbq_inflate_all(const uint8_t* src, size_t n, std::vector<uint8_t>& out, s
         if (inflateInit2(&z, -15) != Z_OK) { bad = 1; return; }
         for (size_t b = lo; b < hi && !bad.load(); ++b) {
             const Block& k = blocks[b];
-            z.next_in = const_cast<Bytef*>(src + k.src); z.avail_in = (uInt)k.csize;
-            z.next_out = out.data() + k.dst; z.avail_out = k.isize;
+            Bytef nothing = 0;                                   // an empty block (bgzip's EOF marker; an empty file is ONLY that):
+            z.next_in = const_cast<Bytef*>(src + k.src); z.avail_in = (uInt)k.csize;   // zlib rejects a NULL next_out
+            z.next_out = k.isize ? out.data() + k.dst : &nothing; z.avail_out = k.isize;
             const int rc = k.isize || k.csize ? inflate(&z, Z_FINISH) : Z_STREAM_END;
             if ((rc != Z_STREAM_END && !(rc == Z_OK && z.avail_out == 0)) || z.avail_out != 0
-                || crc32(crc32(0L, Z_NULL, 0), out.data() + k.dst, k.isize) != k.crc) { bad = 2; break; }
+                || crc32(crc32(0L, Z_NULL, 0), k.isize ? out.data() + k.dst : &nothing, k.isize) != k.crc) { bad = 2; break; }
             inflateReset(&z);
         }
         inflateEnd(&z);

@@ -432,6 +432,7 @@ int kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* i
         }
     }
     const int R = usable > 0 ? (infer_rg ? (int)seen.size() : 1) : 0;
+    if (R > 32767) return kbbq_set_error_(KBBQ_E_ARG, "more than 32767 read groups: the sidecar word holds 15 bits of read-group id");
     info[0] = usable; info[1] = S; info[2] = R; info[3] = err_kind; info[4] = err_idx;
     return KBBQ_OK;
 }

@@ -306,6 +306,10 @@ int kbbq_sam_fields(const kbbq_sam* f, int32_t* flag, int32_t* contig, int64_t* 
 {
     if (!f) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_sam_fields: NULL handle");
     const int64_t n = (int64_t)f->line0.size();
+    if (has_qual_oq)                                             // the two lengths share one int32: 16 bits / 15 bits
+        for (int64_t i = 0; i < n; ++i)
+            if (f->qual_len[i] > 65535 || f->oq_len[i] > 32768)
+                return kbbq_set_error_(KBBQ_E_ARG, "a QUAL field longer than 65535 or an OQ tag longer than 32768 characters: malformed line");
     for (int64_t i = 0; i < n; ++i) {
         if (flag) flag[i] = f->flag[i];
         if (contig) contig[i] = f->contig[i];

@@ -1,8 +1,9 @@
 """
 Text-format readers for the benchmark path and the BAM-sourced tally (SAM, FASTA, VCF, BED) --
 what the reference gets from pysam.AlignmentFile / FastaFile / VariantFile / tabix_iterator
-(reference kbbq/benchmark.py:9-30,57-74,145-164; kbbq/gatk/bqsr.py:23-206).  pysam/htslib is not available here, so
-binary BAM / BCF / bgzip-indexed inputs are not read: convert with `samtools view -h`.
+(reference kbbq/benchmark.py:9-30,57-74,145-164; kbbq/gatk/bqsr.py:23-206).  pysam/htslib is not available here:
+AlignmentFile reads SAM text, gzip / bgzip-compressed SAM and BAM through the library's own host reader
+(csrc/sam_host.cpp, csrc/bam_host.cpp: whole files, no index, no CRAM); BCF and tabix-indexed access are not read.
 Objects are duck-typed after pysam so code written against the reference keeps working.
 """
 import gzip

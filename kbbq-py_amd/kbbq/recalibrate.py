@@ -11,6 +11,13 @@ Behaviour kept: argument names and defaults, the 9-tuple order, int64 arrays
 owned by the caller, output through print(), and the exceptions the reference
 raises on bad input (AssertionError, IndexError, TypeError, NotImplementedError,
 ValueError -- SURVEY.md 8(b)).
+
+Deliberate deviations (also in README.md / INTEGRATION.md):
+  * gatkreport: the reference raises NotImplementedError for ANY value (recalibrate.py:167-168); here `-g FILE` with FASTQ
+    input saves / loads the model; without FASTQ input it raises NotImplementedError as the reference.
+  * maxscore: the device tables have the reference's default Q axis (43 = maxscore 42 + 1); another maxscore raises
+    ValueError instead of being honoured.
+  * output=...: an extra keyword (the reference only prints): write to a file, one file per rank under torch.distributed.
 """
 import os
 

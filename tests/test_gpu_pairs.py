@@ -153,6 +153,33 @@ def test_product_fastq_path_takes_pair_rows_when_it_can(dev, oracle, tmp_path):
             assert np.array_equal(v, gold[k]), (name, k)
 
 
+@pytest.mark.parametrize('short,long_', [(100, 150), (50, 100), (150, 250)])
+def test_a_shorter_band_of_uniform_pairs_keeps_one_read_per_row(dev, oracle, short, long_, tmp_path, capfd):
+    """2 x 100 bp pairs followed by 2 x 150 bp pairs (lengths non-decreasing: valid for the reference): the shorter band
+    qualifies for mate-pair rows by itself, but the count tables have 2 x 150 columns -- it must be tallied one read per
+    row (it used to raise ValueError out of pass 1).  Whole command against the oracle's text."""
+    from kbbq import recalibrate
+    n1, n2 = 600, 800
+    s1 = oracle.synth(0, n1, n1 + n2, 5, short, short, 2)
+    s2 = oracle.synth(n1, n2, n1 + n2, 5, long_, long_, 2)
+    pitch = s2[0].shape[1]
+
+    seq, cseq, qual = (np.concatenate([np.pad(a, ((0, 0), (0, pitch - a.shape[1])), constant_values=fill), b])
+                       for a, b, fill in ((s1[0], s2[0], ord('N')), (s1[1], s2[1], ord('N')), (s1[2], s2[2], 0)))
+    meta = np.concatenate([s1[3], s2[3]])
+    names = oracle.synth_names(0, n1 + n2, 2, with_rg=True)
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, names, cseq, qual, meta)
+    want, wantv, _ = oracle.recalibrate_fastq_text([fa, fb], True)
+    capfd.readouterr()
+    recalibrate.recalibrate_fastq([fa, fb], infer_rg=True)
+    assert capfd.readouterr().out == want
+    vec = recalibrate.fastq_to_covariate_arrays([fa, fb], infer_rg=True)
+    for g, w in zip(vec, wantv):
+        assert np.array_equal(g, w)
+
+
 def _run_ranks(world, argv, timeout=300):
     import os, socket, subprocess, sys
     from conftest import ROOT

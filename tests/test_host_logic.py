@@ -760,3 +760,24 @@ def test_bench_parent_launches_a_child_job_without_touching_the_gpu(monkeypatch,
     monkeypatch.setenv('RANK', '0'); monkeypatch.setenv('WORLD_SIZE', '2')
     with pytest.raises(SystemExit):
         bench.main(['--gpus', '4', '--no-extra'])
+
+
+def test_empty_bgzip_fastq_is_zero_reads(tmp_path):
+    """An empty file written by bgzip is ONLY the 28-byte EOF block (isize 0): zero reads, as the reference sees it."""
+    eof = bytes.fromhex('1f8b08040000000000ff0600424302001b0003000000000000000000')
+    for name, data in (('empty.fq.gz', eof), ('empty2.fq.gz', eof + eof)):
+        path = tmp_path / name
+        path.write_bytes(data)
+        f = fastx.NativeFastq(str(path))
+        assert f.n == 0
+        f.close()
+
+
+def test_scan_refuses_more_read_groups_than_the_sidecar_holds(tmp_path):
+    n = 32800
+    recs = ''.join('@r%d/1_RG:Z:g%d\nACGT\n+\nIIII\n' % (i, i) for i in range(n))
+    path = tmp_path / 'many.fq'
+    path.write_text(recs)
+    f = fastx.NativeFastq(str(path))
+    with pytest.raises(ValueError, match='32767 read groups'):
+        f.scan(f, True)

@@ -43,6 +43,12 @@ while time.time() < t_end:
             pass
     for name, src in list(layouts):
         layouts.append((name + '+grouped', dev.group_by_rg(src, nrg)))
+    # the one-pass native layout (pairs when they apply + read-group gather + 4-bit sequence planes), and the same
+    # with character planes; `restore` stores K2's output through the permutation (no ungroup pass)
+    for packed in (True, False):
+        laid = dev.lay_out(b, nrg, S, packed=packed)
+        if laid is not b:
+            layouts.append(('lay_out(packed=%s)' % packed, laid))
     lut = shape = None
     for name, lay in layouts:
         t = dev.Tables(nrg, 2 * S)
@@ -53,11 +59,15 @@ while time.time() < t_end:
         for k, (got, w) in enumerate(zip(t.to_host(), want[5:9])):
             check('tables[%d] %s' % (k, name), np.array_equal(got, w), info)
         lut, shape, _, _ = dev.solve(t, minscore=minscore)
+        restore = name.startswith('lay_out') and cases % 2 == 0
         try:
-            out = dev.apply(lay, lut, shape, minscore=minscore)
+            out = dev.apply(lay, lut, shape, minscore=minscore, restore_order=restore)
+            if cases % 3 == 0:                             # the all-device solve must give the same LUT
+                lut2, shape2 = dev.solve_lut(t, minscore=minscore)
+                check('solve_lut ' + name, shape2 == shape and torch.equal(lut2, lut), info)
         except dev.N.LutNeedsCheckedApply:
             continue
-        if getattr(lay, 'seg', None) is not None:
+        if getattr(lay, 'seg', None) is not None and not restore:
             out = dev.ungroup(lay, out)
         if isinstance(lay, dev.PairBatch):
             out = lay.unpack(out, b.pitch)
