@@ -363,6 +363,8 @@ int    kbbq_lay_out_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_cs
                         const uint32_t* d_meta, int64_t nreads, int pitch, int flags, int S2, const int64_t* d_perm,
                         uint8_t* d_lseq, uint8_t* d_lcseq, uint8_t* d_lqual, uint32_t* d_lmeta);
 int    kbbq_unpack_nibbles_dev(kbbq_ctx* ctx, const uint8_t* d_nib, int64_t nbases, uint8_t* d_chars);
+/* d_dst[i] += d_src[i], i < n: count tables tallied apart (a length band, a layout tried first) into the file's */
+int    kbbq_tables_add_dev(kbbq_ctx* ctx, int64_t* d_dst, const int64_t* d_src, size_t n);
 
 /* ---- the exchange step of the sharded path without torch: RCCL allreduce of the count tables -------------
  * Reads shard across GPUs by contiguous record ranges, every rank tallies its shard (K1) and the ONLY exchange is the

@@ -1048,6 +1048,19 @@ int kbbq_lay_out_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq, c
     return KBBQ_OK;
 }
 
+int kbbq_tables_add_dev(kbbq_ctx* c, int64_t* d_dst, const int64_t* d_src, size_t n)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (n && (!d_dst || !d_src)) return fail(KBBQ_E_ARG, "kbbq_tables_add_dev: NULL pointer");
+    if (n == 0) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    AddTablesParams p; p.dst = (long long*)d_dst; p.src = (const long long*)d_src; p.n = (long long)n;
+    int gx = (int)std::min<size_t>((n + 255) / 256, (size_t)c->cus * 8);
+    hipLaunchKernelGGL(k7_add_tables, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
 int kbbq_unpack_nibbles_dev(kbbq_ctx* c, const uint8_t* d_nib, int64_t nbases, uint8_t* d_chars)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");

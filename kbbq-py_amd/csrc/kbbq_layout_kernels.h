@@ -296,3 +296,11 @@ __global__ __launch_bounds__(256) void k7_unpack_nibbles(UnNibParams p)
                                                                  codes_to_chars(nib_lo(v.y)), codes_to_chars(nib_hi(v.y)));
     }
 }
+
+// dst[i] += src[i] over int64 count tables: a length band's tables into the file's (the tables of several bands, or of a
+// layout tried first, add up: kbbq_accumulate* itself adds, this is for tables already tallied apart)
+struct AddTablesParams { long long* dst; const long long* src; long long n; };
+__global__ __launch_bounds__(256) void k7_add_tables(AddTablesParams p)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long long)gridDim.x * blockDim.x) p.dst[i] += p.src[i];
+}

@@ -86,6 +86,13 @@ class Tables:
         t.buf.copy_(torch.from_numpy(flat))
         return t
 
+    def add(self, other):
+        """self += other (same shape), by the library's own kernel on the launch stream."""
+        if (other.R, other.S2) != (self.R, self.S2):
+            raise ValueError('count tables of different shapes')
+        ctx = context(self.buf.device.index)
+        N.check(N.load().kbbq_tables_add_dev(ctx.handle, N.ptr(self.buf), N.ptr(other.buf), self.buf.numel()))
+
     def views(self):
         R, S2 = self.R, self.S2
         npos, ndn = R * NQ * S2, R * NQ * 16

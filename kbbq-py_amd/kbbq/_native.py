@@ -90,6 +90,7 @@ PROTOTYPES = {
     'kbbq_group_rows_dev': (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     'kbbq_lay_out_dev': (_i, [_vp] * 5 + [_i64, _i, _i, _i] + [_vp] * 5),
     'kbbq_unpack_nibbles_dev': (_i, [_vp, _vp, _i64, _vp]),
+    'kbbq_tables_add_dev': (_i, [_vp, _vp, _vp, _sz]),
     'kbbq_comm_library': (_i, [_c.c_char_p]),
     'kbbq_comm_unique_id': (_i, [_vp]),
     'kbbq_comm_create': (_i, [_vp, _vp, _i, _i, _c.POINTER(_vp)]),

@@ -75,7 +75,7 @@ def _tally_local(packed, minscore, maxscore):
             part = dev.Tables(R, 2 * S)
             try:
                 dev.accumulate(laid, part, minscore, **hints)
-                tables.buf += part.buf
+                tables.add(part)
                 band['laid'] = laid
                 return
             except (IndexError, TypeError, ValueError, dev.N.LutNeedsCheckedApply):
