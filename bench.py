@@ -37,7 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, 'kbbq-py_amd'))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 READ_LEN = 150
-KERNEL_SOURCES = ('kbbq_kernels.h', 'kbbq_kernels_v3.h', 'kbbq_kernels_v4.h', 'kbbq_hip.hip')
+KERNEL_SOURCES = ('kbbq_kernels.h', 'kbbq_kernels_v3.h')      # where K1 / K2 live: what profiles/pmc_traffic.json is keyed to
 
 
 def parse_args(argv=None):
@@ -200,8 +200,8 @@ def kernel_source_sha():
 
 def pmc_traffic(layout_key, kernel):
     """HBM bytes per base of `kernel` from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3 --pmc
-    FETCH_SIZE x 2 + WRITE_SIZE, separate passes) -- only when they were taken on THIS kernel source (sha of
-    csrc/*kernels*.h + kbbq_hip.hip); otherwise None."""
+    FETCH_SIZE x 2 + WRITE_SIZE, separate passes) -- only when they were taken on THIS source of K1 / K2 (sha of
+    csrc/kbbq_kernels.h + kbbq_kernels_v3.h); otherwise None."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
             pmc = json.load(fh)
@@ -313,14 +313,23 @@ def extra_config3(torch, dev, parallel, n, steps, warmup):
     bases = n * READ_LEN
     step_ms, step_r_ms = elapsed / steps * 1e3, elapsed_r / steps * 1e3
     lay = res.layout_ms.get('lay_out', 0.0)
+    unpack_ms = None
+    if isinstance(res.batch, dev.PairBatch):              # pair rows of new qualities -> one read per row (callers that want rows)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        rows = res.batch.unpack(res.out); del rows
+        a.record(); rows = res.batch.unpack(res.out); b.record()
+        torch.cuda.synchronize()
+        unpack_ms = a.elapsed_time(b)
+        del rows
     return {'workload': '%d synthetic 2x150 bp reads, 8 read groups (BASELINE config 3)' % n, 'layout': res.name,
             'value': bases * steps / elapsed, 'unit': 'bases/s', 'ms_per_step': step_ms,
             'k1_accumulate': kernel_entry(k1, n1, bases), 'k2_apply': kernel_entry(k2, n2, bases),
             'host_solve_and_sync_ms': step_ms - k1 - k2,
-            'lay_out_ms': lay, 'k2_apply_storing_through_perm': kernel_entry(k2r, n2r, bases),
+            'lay_out_ms': lay, 'unpack_pairs_ms': unpack_ms, 'k2_apply_storing_through_perm': kernel_entry(k2r, n2r, bases),
             'layout_inclusive': {'value': bases / ((step_r_ms + lay) * 1e-3), 'unit': 'bases/s', 'ms': step_r_ms + lay,
                                  'note': 'input-order rows on the device -> layout pass (%.2f ms) + one step whose K2 stores '
-                                         'back in input order (%.2f ms)' % (lay, step_r_ms)}}
+                                         'back in input order (%.2f ms); the output is mate-pair rows in input order (the writer reads '
+                                         'them as they are; unpack_pairs_ms is the pass to one read per row for callers that want it)' % (lay, step_r_ms)}}
 
 
 def extra_layout(torch, dev, parallel, n, steps, warmup, layout):
@@ -535,6 +544,7 @@ def run_rank(args):
     ranks_seen = dist.get_world_size() if use_dist else 1
     backend = dist.get_backend() if use_dist else None
     layout_name = res.name
+    layout_pass_ms = res.layout_ms.get('lay_out')
     layout_key = res.batch.layout_key() if hasattr(res.batch, 'layout_key') else ('reads' if args.layout == 'reads' else 'pairs')
     del res
     torch.cuda.synchronize()
@@ -562,6 +572,7 @@ def run_rank(args):
             'config': {'workload': '%d synthetic 2x150 bp reads per GPU, %d read group(s), Q0-41, '
                                    'accumulate + solve + apply end-to-end, device-resident' % (n, R),
                        'reads_per_gpu': n, 'read_len': S, 'read_groups': R, 'layout': layout_name,
+                       'layout_pass_ms_before_the_timed_region': layout_pass_ms,
                        'parallelism': 'reads sharded x%d, 1 allreduce of count tables' % world},
             'ranks_seen': ranks_seen, 'backend': backend,
             'allreduce_ms_per_step': ar_ms,
