@@ -37,7 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, 'kbbq-py_amd'))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 READ_LEN = 150
-KERNEL_SOURCES = ('kbbq_kernels.h', 'kbbq_kernels_v3.h')      # where K1 / K2 live: what profiles/pmc_traffic.json is keyed to
+KERNEL_SOURCES = ('kbbq_kernels.h', 'kbbq_kernels_v3.h', 'kbbq_k2_tile.h')      # where K1 / K2 live: what profiles/pmc_traffic.json is keyed to
 
 
 def parse_args(argv=None):
@@ -201,7 +201,7 @@ def kernel_source_sha():
 def pmc_traffic(layout_key, kernel):
     """HBM bytes per base of `kernel` from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3 --pmc
     FETCH_SIZE x 2 + WRITE_SIZE, separate passes) -- only when they were taken on THIS source of K1 / K2 (sha of
-    csrc/kbbq_kernels.h + kbbq_kernels_v3.h); otherwise None."""
+    csrc/kbbq_kernels.h + kbbq_kernels_v3.h + kbbq_k2_tile.h); otherwise None."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
             pmc = json.load(fh)

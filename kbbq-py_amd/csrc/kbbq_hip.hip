@@ -5,6 +5,7 @@
 #include "kbbq_solve_kernels.h"
 #include "kbbq_layout_kernels.h"
 #include "kbbq_aligned_kernels.h"
+#include "kbbq_k2_tile.h"
 #include "../../include/kbbq_hip.h"
 
 #include <algorithm>
@@ -46,6 +47,8 @@ struct kbbq_ctx {
     hipStream_t stream = nullptr;
     u64* d_status = nullptr;          // [KBBQ_NSTATUS]
     int* d_stats = nullptr;           // [K7_NSTATS] scratch of kbbq_meta_stats_dev
+    int* d_wgplan = nullptr;          // K2 (short-lived workgroups): first workgroup of every read group
+    int wgplan_n = 0;
     void* d_ops4 = nullptr;           // K4: one 32-byte record of the first CIGAR operations per read (grown on demand)
     size_t ops4_bytes = 0;
     bool timing = false;
@@ -109,6 +112,7 @@ int kbbq_ctx_create(int device, kbbq_ctx** out)
     (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<true, K1V3_DNREP, true, 19>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k2v3_apply<false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k2v3_apply<true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)k2t_apply, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2_apply<int16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2_apply<int8_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipGetLastError();
@@ -125,6 +129,7 @@ int kbbq_ctx_destroy(kbbq_ctx* c)
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_ops4) (void)hipFree(c->d_ops4);
+    if (c->d_wgplan) (void)hipFree(c->d_wgplan);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return KBBQ_OK;
@@ -903,6 +908,36 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
     const int slices = d_seg ? R : 1;
     int gx = (int)std::min<int64_t>(want, std::max<int64_t>(1, (int64_t)c->cus * per_cu / slices));
 
+    // mate-pair rows on 4-bit planes: short-lived workgroups (kbbq_k2_tile.h) unless KBBQ_K2_TILE=0 (A/B timing); everything
+    // else, and LUTs of one group beyond a third of the LDS, keeps the persistent kernel
+    const char* tile = getenv("KBBQ_K2_TILE");
+    if (!(tile && !strcmp(tile, "0")) && pairs && nib && (R == 1 || d_seg) && q.cpr >= 2 && q.cpr <= 4096
+        && rg_bytes * 3 <= (size_t)c->lds_bytes) {
+        K2tParams t;
+        t.seq = d_seq; t.qual = d_qual; t.meta = d_meta; t.nchunks = nrows * q.cpr; t.cpr = q.cpr; t.cpr_magic = q.cpr_magic;
+        t.Qt = KQ; t.S2 = S2; t.maxlen = q.maxlen; t.lut = q.full; t.lut_bytes = (int)((rg_bytes + 15) & ~(size_t)15);
+        t.rb = q.rb; t.ctx_off = q.ctx_off; t.seg = reinterpret_cast<const long long*>(d_seg); t.R = R; t.wg_start = nullptr;
+        t.perm = reinterpret_cast<const long long*>(d_perm); t.pitch = pitch; t.out = d_out; t.status = c->d_status;
+        const int64_t per_wg = (int64_t)(K2T_THREADS / 64) * 64 * K2T_STEPS;
+        int64_t gt = (t.nchunks + per_wg - 1) / per_wg;
+        if (d_seg) {
+            if (c->wgplan_n < R + 1) {
+                if (c->d_wgplan) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_wgplan); c->d_wgplan = nullptr; c->wgplan_n = 0; }
+                HIPCHK(hipMalloc((void**)&c->d_wgplan, (size_t)(R + 1) * sizeof(int)));
+                c->wgplan_n = R + 1;
+            }
+            K2tPlanParams pl; pl.seg = t.seg; pl.R = R; pl.cpr = q.cpr; pl.wg_start = c->d_wgplan;
+            hipLaunchKernelGGL(k2t_plan, dim3(1), dim3(64), 0, c->stream, pl);
+            t.wg_start = c->d_wgplan;
+            gt += R;                                     // every group rounds its last workgroup up
+        }
+        {
+            Timed tm(c, 1);
+            hipLaunchKernelGGL(k2t_apply, dim3((unsigned)gt), dim3(K2T_THREADS), (size_t)t.lut_bytes, c->stream, t);
+        }
+        HIPCHK(hipGetLastError());
+        return KBBQ_OK;
+    }
     {
         Timed t(c, 1);
         if (nib) hipLaunchKernelGGL(k2v3_apply<true>, dim3((unsigned)std::max(gx, 1), (unsigned)slices, 1), dim3(K2V3_THREADS), lds, c->stream, q);

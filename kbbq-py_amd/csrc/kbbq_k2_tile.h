@@ -1,0 +1,158 @@
+// kbbq_k2_tile.h -- K2 with SHORT-LIVED workgroups (experiment of round 2; compare_reads.py:320-328 as kbbq_kernels_v3.h k2v3_apply).
+//
+// Why: the 2 read + 1 written traversal of persistent waves stops at 5.25-5.45 TB/s on this device, one short-lived wave per
+// KiB reaches 6.0-6.1 (profiles/r01_traversal_microbench.md); K2 is bound by that traversal (L1 request queue full 85 % of
+// the time, profiles/r02_pmc_packed.md).  Here a workgroup of 16 waves stages the pair LUT once, every wave takes K2T_STEPS
+// consecutive KiB-steps of chunks (all loads issued up front, counted waits), stores, and the workgroup ends.
+// Shapes: mate-pair rows on 4-bit sequence planes (what the layout pass writes for paired reads of one length), one read
+// group or rows grouped by read group (a workgroup never straddles two groups: k2t_plan gives every group its own run of
+// workgroups), optionally stored through the permutation.  Anything the fast path cannot serve is reported (ST_LUT)
+// exactly as k2v3_apply does for pair rows.  Measured (50 M reads, same device, `KBBQ_K2_TILE=0` A/B): 3.83 -> 3.53 ms;
+// 2 / 6 / 8 steps per wave 3.79 / 4.65 / 4.87 ms, 512-thread workgroups 3.56 ms.
+#pragma once
+#include "kbbq_kernels_v3.h"
+
+#ifndef K2T_THREADS
+#define K2T_THREADS 1024
+#endif
+#ifndef K2T_STEPS
+#define K2T_STEPS 4
+#endif
+
+struct K2tParams {
+    const uint8_t* seq; const uint8_t* qual; const u32* meta;
+    long long nchunks;             // rows * cpr
+    int cpr; u32 cpr_magic;        // ceil(2^32 / cpr): exact quotients for the small numerators used below
+    int Qt; int S2; int maxlen;
+    const int8_t* lut; int lut_bytes; u32 rb; u32 ctx_off;     // lut_bytes: ONE read group's rows
+    const long long* seg;          // rows grouped by read group (NULL: one group, all rows)
+    const int* wg_start;           // [R + 1]: first workgroup of every group (k2t_plan); workgroups >= wg_start[R] have nothing to do
+    int R;
+    const long long* perm;         // optional: row i is stored as row perm[i]
+    int pitch;
+    uint8_t* out; u64* status;
+};
+
+// first workgroup of every read group: group g owns ceil(its chunks / chunks per workgroup) workgroups
+struct K2tPlanParams { const long long* seg; int R; int cpr; int* wg_start; };
+__global__ void k2t_plan(K2tPlanParams p)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long per = (long long)(K2T_THREADS / 64) * 64 * K2T_STEPS;
+    long long run = 0;
+    for (int g = 0; g < p.R; ++g) {
+        p.wg_start[g] = (int)run;
+        run += ((p.seg[g + 1] - p.seg[g]) * p.cpr + per - 1) / per;
+    }
+    p.wg_start[p.R] = (int)run;
+}
+
+__global__ __launch_bounds__(K2T_THREADS) void k2t_apply(K2tParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = K2T_THREADS / 64;
+    // this workgroup's read group and chunk range (grouped rows), or everything
+    int g = 0;
+    long long chunk_lo = 0, chunk_hi = p.nchunks, wg = blockIdx.x;
+    if (p.seg) {
+        if ((int)blockIdx.x >= p.wg_start[p.R]) return;
+        int lo = 0, hi = p.R;                                       // largest g with wg_start[g] <= blockIdx.x
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.wg_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+        g = lo;
+        chunk_lo = p.seg[g] * p.cpr; chunk_hi = p.seg[g + 1] * p.cpr;
+        wg = (long long)blockIdx.x - p.wg_start[g];
+    }
+    const long long base = chunk_lo + (wg * nwaves + wave) * (64 * K2T_STEPS);
+    // chunk -> (row, chunk in row): ONE wave-uniform division for the wave's first chunk, small numerators per lane
+    const long long base_c = base < chunk_hi ? base : chunk_hi - 1;
+    const long long row0 = base_c / p.cpr;
+    const u32 rem0 = (u32)(base_c - row0 * p.cpr);
+    // 1. the wave's data loads, all of them, before anything else (clamped at the end of the planes: re-read the last chunk)
+    u32 sq[K2T_STEPS][2], ql[K2T_STEPS][4], mk[K2T_STEPS];
+    long long cidx[K2T_STEPS];
+#pragma unroll
+    for (int s = 0; s < K2T_STEPS; ++s) {
+        const long long c = base + 64 * s + lane;
+        const long long cc = c < chunk_hi ? c : chunk_hi - 1;
+        cidx[s] = c;
+        const uint2 sv = *reinterpret_cast<const uint2*>(p.seq + 8 * cc);
+        const uint4 qv = *reinterpret_cast<const uint4*>(p.qual + 16 * cc);
+        sq[s][0] = sv.x; sq[s][1] = sv.y;
+        ql[s][0] = qv.x; ql[s][1] = qv.y; ql[s][2] = qv.z; ql[s][3] = qv.w;
+        const u32 rel = rem0 + (u32)(cc - base_c);                    // < cpr + 64 * K2T_STEPS
+        mk[s] = p.meta[row0 + __umulhi(rel, p.cpr_magic)];
+    }
+    // the base before the wave's first chunk (its last nibble), for the context of the first base
+    const long long c0 = base < chunk_hi ? base : chunk_hi - 1;
+    const u32 before = c0 > 0 ? (u32)p.seq[8 * c0 - 1] >> 4 : 4u;
+    // 2. the LUT (L2-resident after the first workgroups), then one barrier
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.lut + (size_t)g * (size_t)(33 + p.Qt) * p.rb);
+        const int n16 = p.lut_bytes >> 4;
+        for (int i = threadIdx.x; i < n16; i += K2T_THREADS) reinterpret_cast<uint4*>(lds)[i] = src[i];
+        __syncthreads();
+    }
+    const u32 rb = p.rb;
+    const u32 hi_add = (u32)(0x80 - (p.Qt + 33)) * 0x01010101u;
+    u32 carry_code = 5u * before;
+#pragma unroll
+    for (int s = 0; s < K2T_STEPS; ++s) {
+        const long long c = cidx[s];
+        const bool act0 = c < chunk_hi;
+        const u32 rel = rem0 + (u32)((act0 ? c : chunk_hi - 1) - base_c);
+        const u32 drow = __umulhi(rel, p.cpr_magic);
+        const long long row = row0 + drow;
+        const int j = (int)(rel - drow * (u32)p.cpr);
+        const int len = (int)(mk[s] & 0xFFFFu);
+        const int nb = act0 ? len - 16 * j : 0;
+        u32 code[4], code5[4], hiq = 0u;
+        code[0] = nib_lo(sq[s][0]); code[1] = nib_hi(sq[s][0]); code[2] = nib_lo(sq[s][1]); code[3] = nib_hi(sq[s][1]);
+        const u32 badbits = nib_invalid(sq[s][0]) | nib_invalid(sq[s][1]);
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd) {
+            code5[wd] = (code[wd] << 2) + code[wd];
+            hiq |= ((ql[s][wd] & 0x7F7F7F7Fu) + hi_add) | ql[s][wd];
+        }
+        hiq &= 0x80808080u;
+        const u32 last_code5 = code5[3] >> 24;
+        u32 prev_code5 = wave_shr1(last_code5, carry_code);
+        carry_code = (u32)__builtin_amdgcn_readlane((int)last_code5, 63);
+        if (j == 0) prev_code5 = 20u;
+        if (act0) {
+            u32 o[4] = {0u, 0u, 0u, 0u};
+            if (nb > 0) {
+                const int rg = (int)((mk[s] >> 16) & 0x7FFFu);
+                if (hiq != 0u || rg != g || len > p.maxlen || badbits) {
+                    flag(p.status, ST_LUT, 0);                       // the caller re-runs on one-read-per-row planes
+                } else {
+                    u32 d5[4];
+                    u32 pc5 = prev_code5 << 24;
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) {
+                        d5[wd] = __builtin_amdgcn_alignbyte(code5[wd], pc5, 3) + code[wd];
+                        pc5 = code5[wd];
+                    }
+                    const u32 A = (u32)(16 * j), C = p.ctx_off;
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) {
+                        int v1[4], v2[4];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const u32 qb = (ql[s][wd] >> (8 * b)) & 0xFFu;
+                            const u32 rowq = __umul24(qb, rb);
+                            const u32 dd = (d5[wd] >> (8 * b)) & 0xFFu;
+                            v1[b] = *reinterpret_cast<const int8_t*>(reinterpret_cast<const char*>(lds) + (rowq + A + (u32)(4 * wd + b)));
+                            v2[b] = *reinterpret_cast<const int8_t*>(reinterpret_cast<const char*>(lds) + (rowq + C + dd));
+                        }
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) o[wd] |= (u32)(v1[b] + v2[b] + 33) << (8 * b);
+                    }
+                }
+            }
+            uint8_t* dst = p.perm ? p.out + p.perm[row] * p.pitch + 16 * j : p.out + 16 * c;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}

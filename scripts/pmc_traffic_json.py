@@ -20,7 +20,7 @@ for layout in sorted(os.listdir(root)):
     for f in glob.glob(d + '/p*/p*_counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name'].replace('void ', '')
-            name = 'k1_accumulate' if k.startswith('k1v3_accumulate') or k.startswith('k1_accumulate') else 'k2_apply' if k.startswith(('k2v3_apply', 'k2_apply')) else None
+            name = 'k1_accumulate' if k.startswith('k1v3_accumulate') or k.startswith('k1_accumulate') else 'k2_apply' if k.startswith(('k2v3_apply', 'k2_apply', 'k2t_apply')) else None
             if name and r['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
                 vals[name][r['Counter_Name']].append(float(r['Counter_Value']))
     entry = {}

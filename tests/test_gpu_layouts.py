@@ -214,3 +214,31 @@ def test_large_packed_batch_properties(dev):
     assert int(pt.sum()) == int(((b.qual[:n, :S] >= 33 + 6)).sum())
     lut, shape, _, _ = dev.solve(t1)
     assert torch.equal(dev.apply(laid, lut, shape), dev.apply(plain, lut, shape))
+
+
+@pytest.mark.parametrize('n,R', [(30_000_000, 8), (26_000_000, 1), (6002, 3), (130, 2)])
+def test_short_lived_k2_equals_the_persistent_k2(dev, n, R, monkeypatch):
+    """K2 with short-lived workgroups (csrc/kbbq_k2_tile.h, the default on mate-pair rows with 4-bit planes) against the
+    persistent kernel (KBBQ_K2_TILE=0) on the same batch: identical bytes, in grouped order and stored through the
+    permutation.  The large sizes put chunk numbers beyond 2^28 (the chunk -> row division must be exact there) and
+    every read group's run of workgroups to work."""
+    import torch
+    b = dev.ReadBatch.synthetic(0, n, n, seed=17, nrg=R)
+    laid = dev.lay_out(b, R, 150, packed=True)
+    assert laid.nib and isinstance(laid, dev.PairBatch)
+    del b
+    t = dev.Tables(R, 300)
+    dev.accumulate(laid, t)
+    lut, shape = dev.solve_lut(t)
+    ctx = dev.context()
+    for restore in (False, True):
+        if restore and laid.seg is None:
+            continue
+        monkeypatch.setenv('KBBQ_K2_TILE', '0')
+        want = dev.apply(laid, lut, shape, restore_order=restore)
+        monkeypatch.delenv('KBBQ_K2_TILE')
+        ctx.kernel_ms(1, reset=True); ctx.timing(True)
+        got = dev.apply(laid, lut, shape, restore_order=restore)
+        ctx.timing(False)
+        assert torch.equal(got, want)
+        del got, want
