@@ -384,6 +384,7 @@ def extra_aligned(torch, dev, n=4_000_000, L=150, G=200_000_000, ins=0.05, reps=
     trim[torch.rand(n, device='cuda') < 0.05] = (L - 20) | (L << 16)
     flags = torch.randint(0, 4, (n,), device='cuda', dtype=torch.int32)
     batch = dev.ReadBatch(n, pitch, with_corrected=True)
+    packed = dev.ReadBatch(n, pitch, with_corrected=True, nib=True)      # what gatk/bqsr.py puts between K6 and K1
     tables = dev.Tables(1, 2 * L)
     ctx, lib = dev.context(), N.load()
 
@@ -395,26 +396,31 @@ def extra_aligned(torch, dev, n=4_000_000, L=150, G=200_000_000, ins=0.05, reps=
     def k5(two_planes=False):
         N.check(lib.kbbq_count_q_dev(ctx.handle, N.ptr(qual), N.ptr(err), N.ptr(skip) if two_planes else None, N.ptr(lens), n, pitch, 0, N.ptr(counts)))
 
-    def k6(two_planes=False):
-        N.check(lib.kbbq_canonical_reads_dev(ctx.handle, N.ptr(seq), N.ptr(oq), N.ptr(err), N.ptr(skip) if two_planes else None, N.ptr(lens),
-                                             N.ptr(clip), N.ptr(trim), N.ptr(flags), n, pitch, L, 6, 6,
-                                             N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual), N.ptr(batch.meta)))
+    def k6(two_planes=False, to=packed):
+        N.check(lib.kbbq_canonical_reads_rows_dev(ctx.handle, N.ptr(seq), N.ptr(oq), N.ptr(err), N.ptr(skip) if two_planes else None,
+                                                  N.ptr(lens), N.ptr(clip), N.ptr(trim), N.ptr(flags), n, pitch, L, 6, 6,
+                                                  N.ROWS_NIBBLES if to.nib else 0,
+                                                  N.ptr(to.seq), N.ptr(to.cseq), N.ptr(to.qual), N.ptr(to.meta)))
 
-    def k1():
-        dev.accumulate(batch, tables, 6, check=False, dinuc_minscore=6)
+    def k1(of=packed):
+        dev.accumulate(of, tables, 6, check=False, dinuc_minscore=6)
 
     out = {'workload': '%d aligned reads x %d bp, %d Mb random genome, %.0f %% of the reads with a 2-base insertion, half '
                        'reverse-strand; HIP events on the launch stream, %d launches each' % (n, L, G // 1000000, ins * 100, reps),
            'bytes_per_base': 'algorithmic, by the arrays of the reference: K4 3 read (read, reference, site mask) + 2 written (errors, '
                              'skips); K5 3 read; K6 4 read + 3 written.  The product keeps errors and skips in ONE plane of flags between '
                              'these kernels (and the site mask in bit 7 of the reference bytes): each kernel moves 1 B/base less than its '
-                             'algorithmic count; the *_two_planes entries are the form with separate error / skip planes'}
+                             'algorithmic count; the *_two_planes entries are the form with separate error / skip planes.  K6 hands K1 '
+                             '4-bit sequence planes (2 B/base written / read instead of 3); the *_character_planes entries are the form '
+                             'with one byte per base (taken when a read holds a letter outside ACGTN)'}
     bases = n * L
     for name, fn, bpb in (('k4_find_errors', lambda: k4(flip), 5), ('k5_count_q', k5, 3),
                           ('k4_find_errors_tally', lambda: k4(noflip), 5), ('k6_canonical_reads', k6, 7),
                           ('k1_on_canonical_reads', k1, 3),
+                          ('k6_canonical_reads_character_planes', lambda: k6(False, batch), 7),
+                          ('k1_on_canonical_reads_character_planes', lambda: k1(batch), 3),
                           ('k4_find_errors_two_planes', lambda: k4(flip, True), 5), ('k5_count_q_two_planes', lambda: k5(True), 3),
-                          ('k6_canonical_reads_two_planes', lambda: k6(True), 7)):
+                          ('k6_canonical_reads_two_planes', lambda: k6(True, batch), 7)):
         fn()
         torch.cuda.synchronize()
         evs = []
@@ -485,7 +491,7 @@ def build_extra(torch, dev, parallel, args, headline_layout):
     for key, fn in (('config3_8rg', lambda: extra_config3(torch, dev, parallel, n, small, 1)),
                     ('layout_pairs', lambda: extra_layout(torch, dev, parallel, n, small, 1, 'pairs')),
                     ('layout_reads', lambda: extra_layout(torch, dev, parallel, n, small, 1, 'reads')),
-                    ('aligned_read_kernels', lambda: extra_aligned(torch, dev, n=min(4_000_000, n), G=min(200_000_000, 50 * n))),
+                    ('aligned_read_kernels', lambda: extra_aligned(torch, dev, n=min(16_000_000, n), G=min(200_000_000, 50 * n))),
                     ('file_path', lambda: extra_file_path(torch, dev, n=min(8_000_000, n)))):
         if key == 'layout_' + headline_layout:
             continue

@@ -278,6 +278,16 @@ int kbbq_canonical_reads_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t*
                              const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads, int pitch, int S,
                              int minscore, int dinuc_minscore, uint8_t* d_out_seq, uint8_t* d_out_cseq,
                              uint8_t* d_out_qual, uint32_t* d_out_meta);
+/* The same with the layout of the output rows chosen: 0 (character planes, as above) or KBBQ_ROWS_NIBBLES -- d_out_seq /
+ * d_out_cseq are then 4-bit planes of nreads * pitch / 2 bytes (the layout kbbq_accumulate_rows_dev takes with that
+ * flag; one byte per base less to write here and to read there).  A corrected base differs from its base in the low
+ * bit of its code (an N: code 5 in d_out_cseq only).  Rows that cannot be packed -- a letter outside ACGTN on a forward-strand read -- make
+ * kbbq_ctx_status return KBBQ_E_LUT: repeat the call with layout 0 (which is also where KBBQ_E_TYPE is decided). */
+int kbbq_canonical_reads_rows_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_oq, const uint8_t* d_err,
+                                  const uint8_t* d_skip, const uint32_t* d_len, const uint32_t* d_clip,
+                                  const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads, int pitch, int S,
+                                  int minscore, int dinuc_minscore, int layout, uint8_t* d_out_seq,
+                                  uint8_t* d_out_cseq, uint8_t* d_out_qual, uint32_t* d_out_meta);
 int kbbq_count_q_dev(kbbq_ctx* ctx, const uint8_t* d_qual, const uint8_t* d_err, const uint8_t* d_skip,
                      const uint32_t* d_len, int64_t nreads, int pitch, int qoffset, int64_t* d_counts512);
 

@@ -1161,7 +1161,18 @@ int kbbq_canonical_reads_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d
                              int minscore, int dinuc_minscore, uint8_t* d_out_seq, uint8_t* d_out_cseq,
                              uint8_t* d_out_qual, uint32_t* d_out_meta)
 {
+    return kbbq_canonical_reads_rows_dev(c, d_seq, d_oq, d_err, d_skip, d_len, d_clip, d_trim, d_flags, nreads, pitch, S,
+                                         minscore, dinuc_minscore, 0, d_out_seq, d_out_cseq, d_out_qual, d_out_meta);
+}
+
+int kbbq_canonical_reads_rows_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_oq, const uint8_t* d_err,
+                                  const uint8_t* d_skip, const uint32_t* d_len, const uint32_t* d_clip,
+                                  const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads, int pitch, int S,
+                                  int minscore, int dinuc_minscore, int layout, uint8_t* d_out_seq, uint8_t* d_out_cseq,
+                                  uint8_t* d_out_qual, uint32_t* d_out_meta)
+{
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (layout & ~KBBQ_ROWS_NIBBLES) return fail(KBBQ_E_ARG, "kbbq_canonical_reads_rows_dev: the output is one read per row (layout 0 or KBBQ_ROWS_NIBBLES)");
     if (nreads < 0 || pitch <= 0 || (pitch & 15) || S <= 0 || S > pitch || S > 65535)
         return fail(KBBQ_E_ARG, "kbbq_canonical_reads_dev: bad nreads/pitch/S");
     if (minscore < 0 || minscore > 94 || dinuc_minscore < 0 || dinuc_minscore > 94)
@@ -1180,7 +1191,8 @@ int kbbq_canonical_reads_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d
     p.status = c->d_status;
     const int rpb6 = (pitch / 16) <= 256 ? 256 / (pitch / 16) : 1;
     int gx = (int)std::min<int64_t>((nreads + rpb6 - 1) / rpb6, (int64_t)c->cus * 16);
-    hipLaunchKernelGGL(k6_canonical_reads, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    if (layout & KBBQ_ROWS_NIBBLES) hipLaunchKernelGGL(k6_canonical_reads<true>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    else hipLaunchKernelGGL(k6_canonical_reads<false>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
 }

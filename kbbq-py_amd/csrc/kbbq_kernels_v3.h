@@ -980,6 +980,13 @@ struct K6Item { long long rb; int j; };
 struct K6Meta { u32 fl, clip, trim; bool valid; };
 struct K6Win { u32 s[4], q[4], e[4], k[4]; int cnt, i0; bool has; };
 
+// NIB: out_seq / out_cseq are 4-bit planes (pitch / 2 bytes per row, the layout of KBBQ_ROWS_NIBBLES): K6 writes 2 B/base
+// instead of 3 and K1 reads 2 instead of 3.  A corrected base differs from its base in the low code bit (an N of a
+// reverse-strand read that was another letter IS counted by cycle and quality: its corrected code is 5, which only K1's
+// comparison ever sees).  A letter outside ACGTN (only a forward-strand read can carry one into the output) cannot be
+// packed: ST_LUT, and the caller repeats the pass with character planes -- which is also where the reference's
+// TypeError is decided, so this form does not look for it.
+template <bool NIB>
 __global__ __launch_bounds__(256) void k6_canonical_reads(K6Params p)
 {
     const int cpr = p.pitch >> 4;
@@ -1056,7 +1063,9 @@ __global__ __launch_bounds__(256) void k6_canonical_reads(K6Params p)
                     oc[w] = os[w] ^ (nonzero_bytes(e[w]) << 7);                    // an error: cseq differs from seq
                     oqv[w] = q[w] & ~sk;
                 }
-                if (odd && !rev) {
+                if (NIB) {
+                    if (odd && !rev) flag(p.status, ST_LUT, r);
+                } else if (odd && !rev) {
                     // the reference's TypeError (compare_reads.py:281-293 via bqsr.py:43-45) is decided on the
                     // ORIGINAL qualities, before any skipping: a looked-up pair with a letter outside ACGT
                     u32 prev = (c0 >= 1) ? p.seq[row + i0 - 1] : 'N';
@@ -1082,8 +1091,20 @@ __global__ __launch_bounds__(256) void k6_canonical_reads(K6Params p)
                 }
             }
             const size_t off = row + (size_t)16 * j;
-            *reinterpret_cast<uint4*>(p.out_seq + off) = make_uint4(os[0], os[1], os[2], os[3]);
-            *reinterpret_cast<uint4*>(p.out_cseq + off) = make_uint4(oc[0], oc[1], oc[2], oc[3]);
+            if (NIB) {
+                u32 cs[4], cc[4], bad = 0u;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    cs[w] = chars_to_codes(os[w], bad);
+                    cc[w] = cs[w] ^ nonzero_bytes(os[w] ^ oc[w]);
+                }
+                const size_t noff = (row >> 1) + (size_t)8 * j;
+                *reinterpret_cast<uint2*>(p.out_seq + noff) = make_uint2(cs[0] | (cs[1] << 4), cs[2] | (cs[3] << 4));
+                *reinterpret_cast<uint2*>(p.out_cseq + noff) = make_uint2(cc[0] | (cc[1] << 4), cc[2] | (cc[3] << 4));
+            } else {
+                *reinterpret_cast<uint4*>(p.out_seq + off) = make_uint4(os[0], os[1], os[2], os[3]);
+                *reinterpret_cast<uint4*>(p.out_cseq + off) = make_uint4(oc[0], oc[1], oc[2], oc[3]);
+            }
             *reinterpret_cast<uint4*>(p.out_qual + off) = make_uint4(oqv[0], oqv[1], oqv[2], oqv[3]);
         }
         it0 = it1; m0 = m1; w0 = w1;

@@ -105,6 +105,7 @@ PROTOTYPES = {
     'kbbq_sam_text': (_i, [_vp, _i, _i64, _vp, _vp]),
     'kbbq_sam_match_fastq': (_i, [_vp, _vp, _vp]),
     'kbbq_canonical_reads_dev': (_i, [_vp] * 9 + [_i64, _i, _i, _i, _i] + [_vp] * 4),
+    'kbbq_canonical_reads_rows_dev': (_i, [_vp] * 9 + [_i64, _i, _i, _i, _i, _i] + [_vp] * 4),
     'kbbq_fastq_open': (_i, [_c.c_char_p, _c.POINTER(_vp)]),
     'kbbq_fastq_close': (_i, [_vp]),
     'kbbq_fastq_open_range': (_i, [_c.c_char_p, _i64, _i64, _c.POINTER(_vp)]),

@@ -3,12 +3,14 @@ import atexit
 import contextlib
 import os
 import sys
+import threading
 import time
 
 ON = bool(os.environ.get('KBBQ_TIMING'))
 TIMELINE = os.environ.get('KBBQ_TIMING') == '2'      # also every stage's start / end since the process started
 _acc = {}
 _events = []
+_lock = threading.Lock()
 
 
 def _process_start():
@@ -35,8 +37,9 @@ def stage(name, sync=False):
             import torch
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
-        s, k = _acc.get(name, (0.0, 0))
-        _acc[name] = (s + time.perf_counter() - t0, k + 1)
+        with _lock:                       # several threads may close the same stage (the positioned writers)
+            s, k = _acc.get(name, (0.0, 0))
+            _acc[name] = (s + time.perf_counter() - t0, k + 1)
         if TIMELINE:
             _events.append((w0, time.time(), name))
 

@@ -219,14 +219,23 @@ def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxsc
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
         d_seq, d_oq = kept['seq'], up(oq)
         d_len, d_clip, d_trim, d_flags = (up(x[lo:hi].view(np.int32)) for x in (lens, clip, trim, flags))
-        batch = dev.ReadBatch(m, pitch, with_corrected=True)
         ctx = dev.context()
-        N.check(N.load().kbbq_canonical_reads_dev(
-            ctx.handle, N.ptr(d_seq), N.ptr(d_oq), N.ptr(err), N.ptr(skip), N.ptr(d_len), N.ptr(d_clip),
-            N.ptr(d_trim), N.ptr(d_flags), m, pitch, S, minscore, 6,
-            N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual), N.ptr(batch.meta)))
-        ctx.status()
-        dev.accumulate(batch, tables, minscore, dinuc_minscore=6)
+
+        def canonical(nib):
+            batch = dev.ReadBatch(m, pitch, with_corrected=True, nib=nib)
+            N.check(N.load().kbbq_canonical_reads_rows_dev(
+                ctx.handle, N.ptr(d_seq), N.ptr(d_oq), N.ptr(err), N.ptr(skip), N.ptr(d_len), N.ptr(d_clip),
+                N.ptr(d_trim), N.ptr(d_flags), m, pitch, S, minscore, 6, N.ROWS_NIBBLES if nib else 0,
+                N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual), N.ptr(batch.meta)))
+            ctx.status()
+            return batch
+        # 4-bit sequence planes between K6 and K1 (one byte per base less to write and to read) unless a forward read
+        # carries a letter outside ACGTN, the reads are longer than K1's packed form takes, or K1's tables for this
+        # minscore do not fit beside it (both refusals come before anything is counted)
+        try:
+            dev.accumulate(canonical(S <= dev.LONG_READS), tables, minscore, dinuc_minscore=6)
+        except N.LutNeedsCheckedApply:
+            dev.accumulate(canonical(False), tables, minscore, dinuc_minscore=6)
     benchmark._on_all_ranks(shard if m else (lambda: None), lo)
     if world > 1:
         parallel.allreduce_tables(tables.buf)

@@ -87,10 +87,18 @@ def k6f():
     N.check(lib.kbbq_canonical_reads_dev(ctx.handle, N.ptr(seq), N.ptr(oq), N.ptr(err), None, N.ptr(lens),
                                          N.ptr(clip), N.ptr(trim), N.ptr(flags), n, pitch, L, 6, 6,
                                          N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual), N.ptr(batch.meta)))
+packed = dev.ReadBatch(n, pitch, with_corrected=True, nib=True)
+def k6p():
+    N.check(lib.kbbq_canonical_reads_rows_dev(ctx.handle, N.ptr(seq), N.ptr(oq), N.ptr(err), None, N.ptr(lens),
+                                              N.ptr(clip), N.ptr(trim), N.ptr(flags), n, pitch, L, 6, 6, N.ROWS_NIBBLES,
+                                              N.ptr(packed.seq), N.ptr(packed.cseq), N.ptr(packed.qual), N.ptr(packed.meta)))
+def k1p():
+    dev.accumulate(packed, tables, 6, check=False, dinuc_minscore=6)
 for f, name, bpb in ((k4, 'K4 find_errors', 5), (k5, 'K5 count_q', 3), (k4n, 'K4 (no flip)', 5),
                      (k6, 'K6 canonical_reads', 7), (k1, 'K1 on canonical reads', 3),
                      (k4f, 'K4 find_errors -> flags plane', 4), (k5f, 'K5 count_q <- flags plane', 2),
-                     (k4nf, 'K4 (no flip) -> flags plane', 4), (k6f, 'K6 canonical_reads <- flags plane', 6)):
+                     (k4nf, 'K4 (no flip) -> flags plane', 4), (k6f, 'K6 canonical_reads <- flags plane', 6),
+                     (k6p, 'K6 <- flags plane -> 4-bit planes', 5), (k1p, 'K1 on 4-bit canonical reads', 2)):
     f(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5): f()
