@@ -67,6 +67,20 @@ static int run_pair(const char* pa, const char* pb, int infer)
         if (ra) kbbq_fastq_close(ra);
         if (rb) kbbq_fastq_close(rb);
     }
+    if (kbbq_fastq_is_plain(a)) {
+        // a rank's cut points (multi-GPU ingest without a whole-file index): every offset of a small file, a stride of a
+        // large one, and offsets at / past the end; whatever the file holds, the answer is an offset inside it or -1
+        const int64_t size = kbbq_fastq_sync_offset(pa, (int64_t)1 << 60);
+        const int64_t stride = size > 4096 ? size / 997 + 1 : 1;
+        long long found = 0, bad = 0;
+        for (int64_t off = 0; off <= size + 2; off += stride)
+            for (int second = 0; second < 2; ++second) {
+                const int64_t at = kbbq_fastq_sync_offset_ex(pa, off, second);
+                if (at >= 0) ++found;
+                if (at < -1 || at > size || (at >= 0 && at < off && off <= size)) ++bad;
+            }
+        printf("sync size=%lld found=%lld bad=%lld negative=%lld\n", (long long)size, found, bad, (long long)kbbq_fastq_sync_offset(pa, -5));
+    }
     for (int i = 0; i < kbbq_fastq_rg_count(a); ++i) printf("rg %d = %s\n", i, kbbq_fastq_rg_name(a, i));
     const char* nm; int nl;
     if (kbbq_fastq_count(a) > 0 && kbbq_fastq_name(a, kbbq_fastq_count(a) - 1, &nm, &nl) == 0) printf("last name %.*s\n", nl, nm);
@@ -118,6 +132,22 @@ int main(int argc, char** argv)
         std::vector<double> x = {0.5, 1, 2, 12.5, 13, 999, 1e8, 1e300, -1, 0};
         std::vector<double> g(x.size());
         printf("gammaln rc=%d %.6f\n", kbbq_gammaln_host(x.data(), (int64_t)x.size(), g.data()), g[3]);
+        // the restated log / gammaln over the constants read out of the mapped libm: short buffers are refused, and on
+        // the counts a solve produces the restatement equals the libm-backed routine bit for bit
+        std::vector<double> logtab(263), small(10);
+        printf("logtab short rc=%d\n", kbbq_libm_log_data(small.data(), 10));
+        const int lrc = kbbq_libm_log_data(logtab.data(), 263);
+        std::vector<double> cx, want, got;
+        for (double v = 1; v < 3e6; v = v < 5000 ? v + 1 : v * 1.37 + 1) cx.push_back((double)(int64_t)v);
+        want.resize(cx.size()); got.resize(cx.size());
+        kbbq_gammaln_host(cx.data(), (int64_t)cx.size(), want.data());
+        long long differ = -1;
+        if (!lrc) {
+            kbbq_gammaln_restated_host(cx.data(), (int64_t)cx.size(), logtab.data(), got.data());
+            differ = 0;
+            for (size_t i = 0; i < cx.size(); ++i) differ += memcmp(&want[i], &got[i], sizeof(double)) != 0;
+        }
+        printf("logtab rc=%d restated differ=%lld of %zu\n", lrc, differ, cx.size());
         // the fused solve prep over a table buffer of 3 read groups x 43 x 150 cycles (+ 16 contexts), on the pool
         const int R = 3, S2 = 150; const int64_t npos = (int64_t)R * 43 * S2, ndn = (int64_t)R * 43 * 16;
         std::vector<int64_t> tab((size_t)(2 * npos + 2 * ndn));

@@ -47,6 +47,7 @@ def test_wellformed_pairs(harness, oracle, tmp_path):
     oracle.write_fastq(fb, names, cseq, qual, meta)
     out = harness('pair', fa, fb, '1')
     assert 'scan rc=0 n=%d' % n in out and 'fill rc=0' in out and out.count('rc=0 bytes=') == 2
+    assert 'bad=0 negative=' in out and 'found=0' not in out
     assert 'shard rc=0 records=%d/%d' % (2 * n // 3 - n // 3, 2 * n // 3 - n // 3) in out and 'misaligned rc=-4' in out
     assert 'job rc=0 n=%d' % n in out and out.split('job ')[1].split('\n')[0].split(' ', 1)[1].startswith(out.split('scan ')[1].split('\n')[0].split(' ', 1)[1])
     out = harness('pair', fa, '-', '0')
@@ -91,7 +92,8 @@ def test_malformed_inputs_do_not_touch_memory_they_do_not_own(harness, tmp_path)
 
 def test_gammaln_pool(harness):
     out = harness('combiln')
-    assert out.count('rc=0') == 9
+    assert out.count('rc=0') == 10 and 'logtab short rc=0' not in out
+    assert 'logtab rc=0 restated differ=0 of' in out         # the restated log over the mapped libm's constants: bit for bit
 
 
 def test_sam_reader(harness, oracle, tmp_path):
