@@ -688,6 +688,19 @@ int kbbq_gammaln_dev(kbbq_ctx* c, const double* d_x, int64_t n, const double* d_
     return KBBQ_OK;
 }
 
+// workgroups of a streaming kernel with a grid-stride loop: `per_cu` per CU, or what the environment variable says (timing
+// experiments; 0 = no bound, i.e. one work item per thread).  Measured in three interleaved rounds (scripts/gpu_grids.sh,
+// DESIGN.md section 6): 64 per CU -- four generations of workgroups per CU slot -- beat the 8-16 these kernels
+// started with by 6-13 % (K4 1.95 -> 1.83 ms, K5 1.12 -> 0.98, K6 2.66 -> 2.37 per 16 M reads), 256 did for the layout pass
+// (9.46 -> 8.42 ms per 50 M reads); one item per thread loses again where a workgroup has set-up work (K4's queue, K5's
+// LDS counters and their flush: 13 ms).
+static int bounded_grid(int64_t want, const kbbq_ctx* c, int per_cu, const char* env)
+{
+    if (const char* v = getenv(env)) per_cu = atoi(v);
+    const int64_t cap = per_cu > 0 ? (int64_t)c->cus * per_cu : (int64_t)0x7FFFFFFF;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(want, cap));
+}
+
 // ---- mate-pair rows ---------------------------------------------------------
 int kbbq_pair_pitch(int S2) { return pair_pitch(S2); }
 size_t kbbq_pair_lut_bytes(int R, int Qt, int S2) { return (size_t)R * (33 + Qt) * pair_lut_row_bytes(S2); }
@@ -718,8 +731,8 @@ int kbbq_pack_pairs_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq
     p.fill[0] = 'N'; p.fill[1] = 'N'; p.fill[2] = 0;
     p.meta = d_meta; p.pmeta = d_pmeta; p.npairs = npairs; p.pitch = pitch; p.ppitch = pair_pitch(S2); p.S = S2 / 2; p.unpack = 0;
     const int64_t nchunks = npairs * (p.ppitch / 16);
-    int gx = (int)std::min<int64_t>((nchunks + 255) / 256, (int64_t)c->cus * 16);
-    hipLaunchKernelGGL(k7_pack_pairs, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    const int gx = bounded_grid((nchunks + 255) / 256, c, 256, "KBBQ_K7_GRID");
+    hipLaunchKernelGGL(k7_pack_pairs, dim3((unsigned)gx), dim3(256), 0, c->stream, p);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
 }
@@ -738,8 +751,8 @@ int kbbq_unpack_pairs_dev(kbbq_ctx* c, const uint8_t* d_pplane, int64_t npairs, 
     p.fill[0] = p.fill[1] = p.fill[2] = 0;
     p.meta = nullptr; p.pmeta = nullptr; p.npairs = npairs; p.pitch = pitch; p.ppitch = pair_pitch(S2); p.S = S2 / 2; p.unpack = 1;
     const int64_t nchunks = 2 * npairs * (pitch / 16);
-    int gx = (int)std::min<int64_t>((nchunks + 255) / 256, (int64_t)c->cus * 16);
-    hipLaunchKernelGGL(k7_pack_pairs, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    const int gx = bounded_grid((nchunks + 255) / 256, c, 256, "KBBQ_K7_GRID");
+    hipLaunchKernelGGL(k7_pack_pairs, dim3((unsigned)gx), dim3(256), 0, c->stream, p);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
 }
@@ -1077,7 +1090,7 @@ int kbbq_lay_out_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq, c
     p.nrows = pairs ? nreads / 2 : nreads; p.pitch = pitch; p.dpitch = pairs ? pair_pitch(S2) : pitch; p.S = pairs ? S2 / 2 : 0;
     p.pairs = pairs; p.nib = nib; p.status = c->d_status;
     const int rpb7 = (p.dpitch / 16) <= 256 ? 256 / (p.dpitch / 16) : 1;      // destination rows per workgroup iteration
-    int gx = (int)std::min<int64_t>((p.nrows + rpb7 - 1) / rpb7, (int64_t)c->cus * 16);
+    const int gx = bounded_grid((p.nrows + rpb7 - 1) / rpb7, c, 256, "KBBQ_K7_GRID");
     hipLaunchKernelGGL(k7_lay_out, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
@@ -1129,7 +1142,7 @@ int kbbq_find_errors_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint32_t* d_le
     if (((uintptr_t)d_seq | (uintptr_t)d_err | (uintptr_t)d_skip) & 15)
         return fail(KBBQ_E_ARG, "kbbq_find_errors_dev: planes must be 16-byte aligned");
     const int rpb4 = (pitch / 16) <= 256 ? 256 / (pitch / 16) : 1;              // reads per workgroup iteration
-    int gx = (int)std::min<int64_t>((nreads + rpb4 - 1) / rpb4, (int64_t)c->cus * 16);
+    const int gx = bounded_grid((nreads + rpb4 - 1) / rpb4, c, 64, "KBBQ_K4_GRID");
     const char* force = getenv("KBBQ_K4");              // "v1" forces the first form (A/B timing): needs both output planes
     if (force && !strcmp(force, "v1") && d_skip) {
         if (d_skipmask) hipLaunchKernelGGL(k4_find_errors<false>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
@@ -1190,7 +1203,7 @@ int kbbq_canonical_reads_rows_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8
     p.out_seq = d_out_seq; p.out_cseq = d_out_cseq; p.out_qual = d_out_qual; p.out_meta = d_out_meta;
     p.status = c->d_status;
     const int rpb6 = (pitch / 16) <= 256 ? 256 / (pitch / 16) : 1;
-    int gx = (int)std::min<int64_t>((nreads + rpb6 - 1) / rpb6, (int64_t)c->cus * 16);
+    const int gx = bounded_grid((nreads + rpb6 - 1) / rpb6, c, 64, "KBBQ_K6_GRID");
     if (layout & KBBQ_ROWS_NIBBLES) hipLaunchKernelGGL(k6_canonical_reads<true>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     else hipLaunchKernelGGL(k6_canonical_reads<false>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     HIPCHK(hipGetLastError());
@@ -1211,7 +1224,7 @@ int kbbq_count_q_dev(kbbq_ctx* c, const uint8_t* d_qual, const uint8_t* d_err, c
     p.cpr = pitch / 16; p.cpr_magic = magic_for(p.cpr); p.qoffset = qoffset;
     p.counts = reinterpret_cast<u64*>(d_counts512); p.status = c->d_status;
     const int64_t nchunks = nreads * p.cpr;
-    int gx = (int)std::min<int64_t>((nchunks + 255) / 256, (int64_t)c->cus * 8);
+    const int gx = bounded_grid((nchunks + 255) / 256, c, 64, "KBBQ_K5_GRID");
     hipLaunchKernelGGL(k5_count_q, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
