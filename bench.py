@@ -342,6 +342,69 @@ def extra_layout(torch, dev, parallel, n, steps, warmup, layout):
             'k1_accumulate': kernel_entry(k1, n1, bases), 'k2_apply': kernel_entry(k2, n2, bases)}
 
 
+def extra_mixed_lengths(torch, dev, n, steps, warmup, lo=36, hi=300):
+    """BASELINE config 5, the recalibration half, device-resident: n reads of lo..hi bases in the length bands the file
+    path cuts (kbbq/fastx.py BAND_CLASSES: every band at its own pitch), each band in the layout the product picks for
+    it (kbbq.recalibrate._lay_out: 4-bit planes up to 160 bases, one read per row), count tables of 2 x hi columns.
+    A step = K1 over every band (into a band's own tables, added to the file's: recalibrate._tally_local) -> solve ->
+    K2 over every band."""
+    from kbbq import fastx, recalibrate
+    bands, at = [], lo
+    for c in fastx.BAND_CLASSES:
+        if c >= at:
+            bands.append((at, min(c, hi)))
+            at = min(c, hi) + 1
+        if at > hi:
+            break
+    per = max(2, (n // len(bands)) & ~1)
+    tables, part = dev.Tables(1, 2 * hi), dev.Tables(1, 2 * hi)
+    items, bases, padded = [], 0, 0
+    for k, (blo, bhi) in enumerate(bands):
+        batch = dev.ReadBatch.synthetic(k * per, per, per * len(bands), seed=1, len_lo=blo, len_hi=bhi)
+        st = dev.meta_stats(batch)
+        laid = recalibrate._lay_out(batch, 1, st['longest'], hi)
+        rows = laid if laid is not None else batch
+        bases += int(batch.lengths_host().sum())
+        padded += rows.n * rows.pitch
+        items.append({'rows': rows, 'S': st['longest'], 'Smin': st['shortest'], 'out': torch.empty_like(rows.qual)})
+        del batch, laid
+    torch.cuda.empty_cache()
+    ctx = dev.context()
+
+    def step():
+        tables.buf.zero_()
+        for it in items:
+            part.buf.zero_()
+            dev.accumulate(it['rows'], part, check=False, s_band=it['S'], s_min=it['Smin'])
+            tables.add(part)
+        lut, shape = dev.solve_lut(tables, check=False)
+        for it in items:
+            dev.apply(it['rows'], lut, shape, out=it['out'], check=False)
+    for _ in range(warmup):
+        step()
+    ctx.status()
+    ctx.kernel_ms(0, reset=True); ctx.kernel_ms(1, reset=True)
+    ctx.timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ctx.timing(False)
+    ctx.status()
+    k1_ms, k1_n = ctx.kernel_ms(0)
+    k2_ms, k2_n = ctx.kernel_ms(1)
+    return {'workload': '%d synthetic reads of %d-%d bases in %d length bands of %d reads (BASELINE config 5, recalibration half), '
+                        '1 read group, tables of %d cycle columns' % (per * len(bands), lo, hi, len(bands), per, 2 * hi),
+            'layout': '; '.join('%d-%d: %s' % (b[0], b[1], it['rows'].describe()) for b, it in zip(bands, items)),
+            'bases_per_step': bases, 'padded_row_bytes_per_plane': padded,
+            'value': bases * steps / elapsed, 'unit': 'bases/s', 'ms_per_step': elapsed / steps * 1e3,
+            'k1_accumulate_all_bands': kernel_entry(k1_ms / steps, k1_n, bases),
+            'k2_apply_all_bands': kernel_entry(k2_ms / steps, k2_n, bases),
+            'outside_the_kernels_ms': (elapsed * 1e3 - k1_ms - k2_ms) / steps}
+
+
 def extra_aligned(torch, dev, n=4_000_000, L=150, G=200_000_000, ins=0.05, reps=5):
     """K4 find_errors / K5 count_q / K6 canonical_reads on synthetic aligned reads built as arrays: n reads x L bases
     against a random genome, `ins` of the reads with a 2-base insertion (3 CIGAR operations), half of them on the
@@ -491,6 +554,7 @@ def build_extra(torch, dev, parallel, args, headline_layout):
     for key, fn in (('config3_8rg', lambda: extra_config3(torch, dev, parallel, n, small, 1)),
                     ('layout_pairs', lambda: extra_layout(torch, dev, parallel, n, small, 1, 'pairs')),
                     ('layout_reads', lambda: extra_layout(torch, dev, parallel, n, small, 1, 'reads')),
+                    ('config5_mixed_lengths', lambda: extra_mixed_lengths(torch, dev, min(20_000_000, n), small, 1)),
                     ('aligned_read_kernels', lambda: extra_aligned(torch, dev, n=min(16_000_000, n), G=min(200_000_000, 50 * n))),
                     ('file_path', lambda: extra_file_path(torch, dev, n=min(8_000_000, n)))):
         if key == 'layout_' + headline_layout:
