@@ -51,6 +51,8 @@ struct kbbq_ctx {
     int wgplan_n = 0;
     void* d_ops4 = nullptr;           // K4: one 32-byte record of the first CIGAR operations per read (grown on demand)
     size_t ops4_bytes = 0;
+    void* d_rowlut = nullptr;         // K2 on one-read-per-row planes: the LUT narrowed to the rows' pitch (grown on demand)
+    size_t rowlut_bytes = 0;
     bool timing = false;
     // per-kernel event pairs recorded while timing is on
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];
@@ -129,6 +131,7 @@ int kbbq_ctx_destroy(kbbq_ctx* c)
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_ops4) (void)hipFree(c->d_ops4);
+    if (c->d_rowlut) (void)hipFree(c->d_rowlut);
     if (c->d_wgplan) (void)hipFree(c->d_wgplan);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -465,6 +468,29 @@ int kbbq_build_lut(int R, int Qt, int S2, int D, int minscore, const int64_t* me
     return KBBQ_OK;
 }
 
+// K2 on one-read-per-row planes: when the rows are narrower than the tables' S2 columns, the LUT of the columns they
+// can reach (k3_fill_row_lut) in context-owned scratch, written on the launch stream in front of the apply kernel.
+// Returns the cycle width Sb the LUT was built for (S2: the blob's own full LUT is used, *lut untouched).
+static int narrowed_row_lut(kbbq_ctx* c, const void* d_lut_blob, int R, int Qt, int S2, int pitch, int minscore, const int8_t** lut)
+{
+    const char* off = getenv("KBBQ_K2_ROWLUT");                                    // "0": the full LUT (A/B timing)
+    const int Sb = std::min(pitch, S2);
+    if (Sb >= S2 || (off && !strcmp(off, "0"))) return S2;
+    const size_t need = (size_t)R * (33 + Qt) * full_lut_row_bytes(Sb);
+    if (c->rowlut_bytes < need) {
+        if (c->d_rowlut) { if (hipStreamSynchronize(c->stream) != hipSuccess) return S2; (void)hipFree(c->d_rowlut); c->d_rowlut = nullptr; c->rowlut_bytes = 0; }
+        if (hipMalloc(&c->d_rowlut, need) != hipSuccess) { c->d_rowlut = nullptr; return S2; }
+        c->rowlut_bytes = need;
+    }
+    RowLutParams f;
+    f.lut16 = reinterpret_cast<const int16_t*>(d_lut_blob); f.rs16 = lut_row_stride(S2); f.R = R; f.Qt = Qt; f.S2 = S2; f.Sb = Sb;
+    f.minscore = std::min(std::max(minscore, 0), Qt);
+    f.out = reinterpret_cast<int8_t*>(c->d_rowlut);
+    hipLaunchKernelGGL(k3_fill_row_lut, dim3((unsigned)(R * (33 + Qt))), dim3(256), 0, c->stream, f);
+    *lut = f.out;
+    return Sb;
+}
+
 int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta,
                    int64_t nreads, int pitch, int R, int Qt, int S2, int minscore,
                    const void* d_lut, int mode, uint8_t* d_out)
@@ -482,7 +508,9 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
     const int64_t nblocks = (nreads + 63) / 64;
     const char* force = getenv("KBBQ_K2");              // "v1" forces the first kernel (A/B timing)
 
-    const size_t full_bytes = kbbq_full_lut_bytes(R, Qt, S2);
+    // the LUT of the columns rows of this pitch can reach (narrowed_row_lut): a band of short reads under wide tables
+    const int Sb0 = (getenv("KBBQ_K2_ROWLUT") && !strcmp(getenv("KBBQ_K2_ROWLUT"), "0")) ? S2 : std::min(pitch, S2);
+    const size_t full_bytes = (size_t)R * (33 + Qt) * full_lut_row_bytes(Sb0);
     if (mode == KBBQ_APPLY_FAST && full_bytes <= (size_t)c->lds_bytes && !(force && !strcmp(force, "v1"))) {
         K2v3Params q;
         q.seq = d_seq; q.qual = d_qual; q.meta = d_meta; q.nreads = nreads; q.pitch = pitch;
@@ -490,9 +518,11 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
         q.R = R; q.Qt = Qt; q.S2 = S2; q.minscore = minscore; q.qlo = 33u + (u32)minscore;
         q.lut16 = reinterpret_cast<const int16_t*>(d_lut); q.rs16 = lut_row_stride(S2);
         q.full = reinterpret_cast<const int8_t*>(d_lut) + lut_full_offset(R, Qt, S2);
+        const int Sb = narrowed_row_lut(c, d_lut, R, Qt, S2, pitch, minscore, &q.full);
+        if (Sb != Sb0) return fail(KBBQ_E_HIP, "kbbq_apply_dev: no scratch for the narrowed LUT");
         q.full_bytes = (int)full_bytes;
-        q.rb = (u32)full_lut_row_bytes(S2); q.W = (u32)full_lut_width(S2); q.ctx_off = 2u * q.W;
-        q.maxlen = S2; q.pairs = 0; q.seg = nullptr; q.rpb = 64; q.perm = nullptr;
+        q.rb = (u32)full_lut_row_bytes(Sb); q.W = (u32)full_lut_width(Sb); q.ctx_off = 2u * q.W;
+        q.maxlen = Sb; q.pairs = 0; q.seg = nullptr; q.rpb = 64; q.perm = nullptr;
         q.out = d_out; q.status = c->d_status;
 #ifdef K2V3_PER_CU
         int per_cu = K2V3_PER_CU;
@@ -894,7 +924,9 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
     if (minscore < 0 || minscore > 222) return fail(KBBQ_E_ARG, "%s: minscore out of range", who);
     if (pairs && pitch != pair_pitch(S2)) return fail(KBBQ_E_ARG, "%s: mate-pair rows of %d-base reads have pitch %d, not %d", who, S2 / 2, pair_pitch(S2), pitch);
     K2v3Params q;
-    q.rb = (u32)(pairs ? pair_lut_row_bytes(S2) : full_lut_row_bytes(S2));
+    // one read per row: the LUT of the columns rows of this pitch can reach (narrowed_row_lut)
+    const int Sb = pairs || (getenv("KBBQ_K2_ROWLUT") && !strcmp(getenv("KBBQ_K2_ROWLUT"), "0")) ? S2 : std::min(pitch, S2);
+    q.rb = (u32)(pairs ? pair_lut_row_bytes(S2) : full_lut_row_bytes(Sb));
     const size_t rg_bytes = (size_t)(33 + KQ) * q.rb;
     const size_t all_bytes = rg_bytes * (size_t)R;
     const size_t lds = d_seg ? rg_bytes : all_bytes;
@@ -910,7 +942,10 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
                    : reinterpret_cast<const int8_t*>(d_lut_blob) + lut_full_offset(R, KQ, S2);
     q.full_bytes = (int)all_bytes;
     if (pairs) { q.W = 0u; q.ctx_off = (u32)pair_pitch(S2); q.maxlen = S2 + 1; }
-    else { q.W = (u32)full_lut_width(S2); q.ctx_off = 2u * q.W; q.maxlen = S2; }
+    else {
+        if (narrowed_row_lut(c, d_lut_blob, R, KQ, S2, pitch, minscore, &q.full) != Sb) return fail(KBBQ_E_HIP, "%s: no scratch for the narrowed LUT", who);
+        q.W = (u32)full_lut_width(Sb); q.ctx_off = 2u * q.W; q.maxlen = Sb;
+    }
     q.pairs = pairs; q.seg = reinterpret_cast<const long long*>(d_seg);
     q.perm = reinterpret_cast<const long long*>(d_perm);
     q.out = d_out; q.status = c->d_status;
@@ -924,12 +959,13 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
     // mate-pair rows on 4-bit planes: short-lived workgroups (kbbq_k2_tile.h) unless KBBQ_K2_TILE=0 (A/B timing); everything
     // else, and LUTs of one group beyond a third of the LDS, keeps the persistent kernel
     const char* tile = getenv("KBBQ_K2_TILE");
-    if (!(tile && !strcmp(tile, "0")) && pairs && nib && (R == 1 || d_seg) && q.cpr >= 2 && q.cpr <= 4096
-        && rg_bytes * 3 <= (size_t)c->lds_bytes) {
+    // (one read per row: while the narrowed LUT is no bigger than a third of what a workgroup streams)
+    if (!(tile && !strcmp(tile, "0")) && nib && (R == 1 || d_seg) && q.cpr >= 2 && q.cpr <= 4096
+        && (pairs ? rg_bytes * 3 <= (size_t)c->lds_bytes : rg_bytes <= (size_t)32 << 10)) {
         K2tParams t;
         t.seq = d_seq; t.qual = d_qual; t.meta = d_meta; t.nchunks = nrows * q.cpr; t.cpr = q.cpr; t.cpr_magic = q.cpr_magic;
         t.Qt = KQ; t.S2 = S2; t.maxlen = q.maxlen; t.lut = q.full; t.lut_bytes = (int)((rg_bytes + 15) & ~(size_t)15);
-        t.rb = q.rb; t.ctx_off = q.ctx_off; t.seg = reinterpret_cast<const long long*>(d_seg); t.R = R; t.wg_start = nullptr;
+        t.rb = q.rb; t.ctx_off = q.ctx_off; t.W = q.W; t.seg = reinterpret_cast<const long long*>(d_seg); t.R = R; t.wg_start = nullptr;
         t.perm = reinterpret_cast<const long long*>(d_perm); t.pitch = pitch; t.out = d_out; t.status = c->d_status;
         const int64_t per_wg = (int64_t)(K2T_THREADS / 64) * 64 * K2T_STEPS;
         int64_t gt = (t.nchunks + per_wg - 1) / per_wg;

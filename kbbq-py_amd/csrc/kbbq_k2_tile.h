@@ -4,7 +4,8 @@
 // KiB reaches 6.0-6.1 (profiles/r01_traversal_microbench.md); K2 is bound by that traversal (L1 request queue full 85 % of
 // the time, profiles/r02_pmc_packed.md).  Here a workgroup of 16 waves stages the pair LUT once, every wave takes K2T_STEPS
 // consecutive KiB-steps of chunks (all loads issued up front, counted waits), stores, and the workgroup ends.
-// Shapes: mate-pair rows on 4-bit sequence planes (what the layout pass writes for paired reads of one length), one read
+// Shapes: 4-bit sequence planes -- mate-pair rows (what the layout pass writes for paired reads of one length) or one read
+// per row with the LUT narrowed to the row's pitch (k3_fill_row_lut) as long as that LUT stays small --, one read
 // group or rows grouped by read group (a workgroup never straddles two groups: k2t_plan gives every group its own run of
 // workgroups), optionally stored through the permutation.  Anything the fast path cannot serve is reported (ST_LUT)
 // exactly as k2v3_apply does for pair rows.  Measured (50 M reads, same device, `KBBQ_K2_TILE=0` A/B): 3.83 -> 3.53 ms;
@@ -25,6 +26,7 @@ struct K2tParams {
     int cpr; u32 cpr_magic;        // ceil(2^32 / cpr): exact quotients for the small numerators used below
     int Qt; int S2; int maxlen;
     const int8_t* lut; int lut_bytes; u32 rb; u32 ctx_off;     // lut_bytes: ONE read group's rows
+    u32 W;                         // one read per row: offset of the mirrored cycle entries second-in-pair reads use (0 on mate-pair rows)
     const long long* seg;          // rows grouped by read group (NULL: one group, all rows)
     const int* wg_start;           // [R + 1]: first workgroup of every group (k2t_plan); workgroups >= wg_start[R] have nothing to do
     int R;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(K2T_THREADS) void k2t_apply(K2tParams p)
                         d5[wd] = __builtin_amdgcn_alignbyte(code5[wd], pc5, 3) + code[wd];
                         pc5 = code5[wd];
                     }
-                    const u32 A = (u32)(16 * j), C = p.ctx_off;
+                    const u32 A = ((mk[s] >> 31) ? p.W : 0u) + (u32)(16 * j), C = p.ctx_off;
 #pragma unroll
                     for (int wd = 0; wd < 4; ++wd) {
                         int v1[4], v2[4];

@@ -697,6 +697,36 @@ __global__ __launch_bounds__(256) void k3_fill_full_lut(LutFillParams p)
     if (bad) { atomicOr(p.flags, bad); atomicMin(&p.status[ST_LUT], 0ull); }
 }
 
+// The full LUT narrowed to the cycle columns rows of one pitch can reach (K2 on one-read-per-row planes): a read in a
+// row of `pitch` bytes has at most Sb = min(pitch, S2) bases, so of a model row's S2 cycle entries only [0, Sb) (first
+// in pair) and [S2 - Sb, S2) (second in pair: column S2 - 1 - pos) are ever indexed.  Same geometry as the full LUT with
+// Sb in place of S2 (full_lut_width / full_lut_row_bytes): W = Sb + 16, [0, W) forward, [W, 2W) mirrored, 25 contexts at
+// 2W.  A length band of a mixed-length input (tables of 600 columns, rows of 48 bytes) stages 12 KB instead of 96 KB:
+// the LDS then holds several workgroups per CU again, and the short-lived K2 (kbbq_k2_tile.h) can afford the staging.
+struct RowLutParams { const int16_t* lut16; int rs16; int R; int Qt; int S2; int Sb; int minscore; int8_t* out; };
+
+__global__ __launch_bounds__(256) void k3_fill_row_lut(RowLutParams p)
+{
+    const int rb = full_lut_row_bytes(p.Sb), W = full_lut_width(p.Sb);
+    const int NR = 33 + p.Qt;
+    const int row = blockIdx.x;                       // r * NR + qb
+    const int r = row / NR, qb = row - r * NR;
+    const bool model = qb >= 33 + p.minscore;
+    const int16_t* src = p.lut16 + ((size_t)r * p.Qt + (qb >= 33 ? qb - 33 : 0)) * p.rs16;
+    int8_t* dst = p.out + (size_t)row * rb;
+    for (int x = threadIdx.x; x < rb; x += blockDim.x) {
+        int v = 0;
+        if (!model) {
+            if (x < 2 * W) v = qb == 0 ? -33 : qb - 33;                   // padding -> 0 ; uncounted -> unchanged
+        } else {
+            if (x < p.Sb) v = src[x];
+            else if (x >= W && x < W + p.Sb) v = src[p.S2 - 1 - (x - W)];   // second in pair: column S2 - 1 - pos
+            else if (x >= 2 * W && x < 2 * W + 25) v = src[p.S2 + (x - 2 * W)];
+        }
+        dst[x] = (int8_t)v;                            // the blob's flags said every value fits (FAST mode only)
+    }
+}
+
 // ---------------------------------------------------------------- K4 / K5: benchmark path
 // (SURVEY.md 8(f) #1).  K4 restates compare_reads.find_read_errors (compare_reads.py:84-139):
 // a CIGAR walk that compares the read with the reference and marks sites to skip; K5 is the

@@ -11,12 +11,13 @@ ap.add_argument('--len', type=int, default=150)
 ap.add_argument('--pairs', action='store_true', help='mate-pair rows instead of one read per row')
 ap.add_argument('--group', action='store_true', help='rows grouped by read group')
 ap.add_argument('--packed', action='store_true', help='the bench layout: dev.lay_out (mate-pair rows, 4-bit sequence planes, grouped by read group)')
+ap.add_argument('--single', action='store_true', help='with --packed: one read per row on 4-bit planes (what single-end and mixed-length inputs get)')
 args = ap.parse_args()
 import torch
 from kbbq import _device as dev
 b = dev.ReadBatch.synthetic(0, args.reads, args.reads, seed=1, nrg=args.rgs, len_lo=args.len, len_hi=args.len)
 if args.packed:
-    b = dev.lay_out(b, args.rgs, args.len, packed=True)
+    b = dev.lay_out(b, args.rgs, args.len, packed=True, pairs=False if args.single else None)
 else:
     if args.pairs:
         b = dev.PairBatch.from_reads(b)
