@@ -242,3 +242,41 @@ def test_short_lived_k2_equals_the_persistent_k2(dev, n, R, monkeypatch):
         ctx.timing(False)
         assert torch.equal(got, want)
         del got, want
+
+
+@pytest.mark.parametrize('lo,hi,R,packed', [(36, 48, 1, True), (20, 64, 3, True), (100, 150, 1, True), (161, 200, 2, False),
+                                            (1, 16, 1, True), (250, 300, 1, False)])
+def test_apply_with_the_lut_narrowed_to_the_rows_pitch(dev, oracle, lo, hi, R, packed, monkeypatch):
+    """K2 on a length band whose rows are narrower than the tables (a band of a mixed-length input: tables of 2 x 300
+    columns): the LUT holds only the columns such rows reach (k3_fill_row_lut) and 4-bit rows take the short-lived
+    kernel.  Same bytes as the full LUT (KBBQ_K2_ROWLUT=0), as the persistent kernel (KBBQ_K2_TILE=0), and as the oracle
+    -- for first- and second-in-pair reads (the mirrored half), grouped or not, with and without 4-bit planes."""
+    import torch
+    n, S = 6000, 300
+    band = dev.ReadBatch.synthetic(0, n, 2 * n, seed=71 + lo, len_lo=lo, len_hi=hi, nrg=R)
+    wide = dev.ReadBatch.synthetic(n, n, 2 * n, seed=71 + lo, len_lo=S - 40, len_hi=S, nrg=R)     # fills the far columns
+    t = dev.Tables(R, 2 * S)
+    dev.accumulate(band, t, s_band=hi)
+    dev.accumulate(wide, t)
+    lut, shape = dev.solve_lut(t)
+    parts = [_host(b, n) for b in (band, wide)]
+    pitch = wide.pitch
+    pad = lambda a, fill: np.pad(a, ((0, 0), (0, pitch - a.shape[1])), constant_values=fill)
+    seq = np.concatenate([pad(parts[0][0], ord('N')), parts[1][0]]); cseq = np.concatenate([pad(parts[0][1], ord('N')), parts[1][1]])
+    qual = np.concatenate([pad(parts[0][2], 0), parts[1][2]]); meta = np.concatenate([parts[0][3], parts[1][3]])
+    _, ref = _oracle_run(oracle, seq, cseq, qual, meta, R, S)
+    inside = np.arange(band.pitch)[None, :] < (parts[0][3] & 0xFFFF)[:, None]      # the oracle's values are qualities, ours bytes
+    want = np.where(inside, ref[:n, :band.pitch] + 33, 0).astype(np.uint8)
+    rows = dev.lay_out(band, R, hi, packed=packed, pairs=False)
+    assert rows.nib == packed and (R == 1 or rows.seg is not None)
+    outs = {}
+    for name, env in (('narrowed', {}), ('persistent', {'KBBQ_K2_TILE': '0'}), ('full', {'KBBQ_K2_ROWLUT': '0', 'KBBQ_K2_TILE': '0'})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        outs[name] = dev.apply(rows, lut, shape, restore_order=True).cpu().numpy()
+        plain = dev.apply(band, lut, shape).cpu().numpy()              # character planes, input order: kbbq_apply_dev
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(plain[:n], want), name
+        assert np.array_equal(outs[name][:n], want), name
+    torch.cuda.synchronize()
