@@ -965,20 +965,30 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
         K2tParams t;
         t.seq = d_seq; t.qual = d_qual; t.meta = d_meta; t.nchunks = nrows * q.cpr; t.cpr = q.cpr; t.cpr_magic = q.cpr_magic;
         t.Qt = KQ; t.S2 = S2; t.maxlen = q.maxlen; t.lut = q.full; t.lut_bytes = (int)((rg_bytes + 15) & ~(size_t)15);
-        t.rb = q.rb; t.ctx_off = q.ctx_off; t.W = q.W; t.seg = reinterpret_cast<const long long*>(d_seg); t.R = R; t.wg_start = nullptr;
+        t.rb = q.rb; t.ctx_off = q.ctx_off; t.W = q.W; t.seg = reinterpret_cast<const long long*>(d_seg); t.R = R; t.wg_start = nullptr; t.order = nullptr;
         t.perm = reinterpret_cast<const long long*>(d_perm); t.pitch = pitch; t.out = d_out; t.status = c->d_status;
         const int64_t per_wg = (int64_t)(K2T_THREADS / 64) * 64 * K2T_STEPS;
         int64_t gt = (t.nchunks + per_wg - 1) / per_wg;
         if (d_seg) {
-            if (c->wgplan_n < R + 1) {
+            gt += R;                                     // every group rounds its last workgroup up
+            const char* ord = getenv("KBBQ_K2_ORDER");  // "0": group after group (A/B timing)
+            const bool interleave = d_perm && R > 1 && !(ord && !strcmp(ord, "0"));
+            const int64_t ints = (int64_t)(R + 1) + 1 + (interleave ? 2 * gt : 0);
+            if (ints > 0x7FFFFFFF) return fail(KBBQ_E_ARG, "%s: too many workgroups", who);
+            if (c->wgplan_n < (int)ints) {
                 if (c->d_wgplan) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_wgplan); c->d_wgplan = nullptr; c->wgplan_n = 0; }
-                HIPCHK(hipMalloc((void**)&c->d_wgplan, (size_t)(R + 1) * sizeof(int)));
-                c->wgplan_n = R + 1;
+                HIPCHK(hipMalloc((void**)&c->d_wgplan, (size_t)ints * sizeof(int)));
+                c->wgplan_n = (int)ints;
             }
             K2tPlanParams pl; pl.seg = t.seg; pl.R = R; pl.cpr = q.cpr; pl.wg_start = c->d_wgplan;
             hipLaunchKernelGGL(k2t_plan, dim3(1), dim3(64), 0, c->stream, pl);
             t.wg_start = c->d_wgplan;
-            gt += R;                                     // every group rounds its last workgroup up
+            if (interleave) {
+                K2tOrderParams op; op.wg_start = c->d_wgplan; op.R = R;
+                op.order = reinterpret_cast<int2*>(c->d_wgplan + ((R + 2) & ~1));           // 8-byte aligned behind the starts
+                hipLaunchKernelGGL(k2t_order, dim3((unsigned)((gt + 255) / 256)), dim3(256), 0, c->stream, op);
+                t.order = op.order;
+            }
         }
         {
             Timed tm(c, 1);

@@ -29,6 +29,7 @@ struct K2tParams {
     u32 W;                         // one read per row: offset of the mirrored cycle entries second-in-pair reads use (0 on mate-pair rows)
     const long long* seg;          // rows grouped by read group (NULL: one group, all rows)
     const int* wg_start;           // [R + 1]: first workgroup of every group (k2t_plan); workgroups >= wg_start[R] have nothing to do
+    const int2* order;             // optional (stores through perm): workgroup b works as order[b] = (group, workgroup of the group), k2t_order
     int R;
     const long long* perm;         // optional: row i is stored as row perm[i]
     int pitch;
@@ -49,6 +50,33 @@ __global__ void k2t_plan(K2tPlanParams p)
     p.wg_start[p.R] = (int)run;
 }
 
+// Stores through the permutation put the rows of every group back between the rows of the others: a group's rows are
+// 1 / R of every stretch of the output.  Launched group after group, the output's cache lines are written R times, each
+// time in part, long after the previous part has left the memory-side cache.  k2t_order lets the groups advance
+// TOGETHER: workgroup (g, i) gets the rank of its relative position (2 i + 1) / (2 n_g) among all workgroups (ties by
+// group), so that at any moment the running workgroups of all groups store into the same stretch of the output and
+// their partial lines meet in the cache.  One thread per workgroup, R comparisons each.
+struct K2tOrderParams { const int* wg_start; int R; int2* order; };
+__global__ __launch_bounds__(256) void k2t_order(K2tOrderParams p)
+{
+    const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (b >= p.wg_start[p.R]) return;
+    int lo = 0, hi = p.R;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.wg_start[mid] <= b) lo = mid; else hi = mid; }
+    const int g = lo, i = b - p.wg_start[g];
+    const long long ng = p.wg_start[g + 1] - p.wg_start[g];
+    long long rank = 0;
+    for (int h = 0; h < p.R; ++h) {
+        const long long nh = p.wg_start[h + 1] - p.wg_start[h];
+        if (nh == 0) continue;
+        const long long A = (2ll * i + 1) * nh;                       // odd k = 2 j + 1 of group h with k * ng < A (<= A when h < g)
+        const long long M = h < g ? A / ng : (A + ng - 1) / ng - 1;   // largest admissible k
+        long long cnt = (M + 1) / 2;
+        rank += cnt < nh ? cnt : nh;
+    }
+    p.order[rank] = make_int2(g, i);
+}
+
 __global__ __launch_bounds__(K2T_THREADS) void k2t_apply(K2tParams p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -60,11 +88,16 @@ __global__ __launch_bounds__(K2T_THREADS) void k2t_apply(K2tParams p)
     long long chunk_lo = 0, chunk_hi = p.nchunks, wg = blockIdx.x;
     if (p.seg) {
         if ((int)blockIdx.x >= p.wg_start[p.R]) return;
-        int lo = 0, hi = p.R;                                       // largest g with wg_start[g] <= blockIdx.x
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.wg_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
-        g = lo;
+        if (p.order) {
+            const int2 o = p.order[blockIdx.x];
+            g = o.x; wg = o.y;
+        } else {
+            int lo = 0, hi = p.R;                                   // largest g with wg_start[g] <= blockIdx.x
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.wg_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+            g = lo;
+            wg = (long long)blockIdx.x - p.wg_start[g];
+        }
         chunk_lo = p.seg[g] * p.cpr; chunk_hi = p.seg[g + 1] * p.cpr;
-        wg = (long long)blockIdx.x - p.wg_start[g];
     }
     const long long base = chunk_lo + (wg * nwaves + wave) * (64 * K2T_STEPS);
     // chunk -> (row, chunk in row): ONE wave-uniform division for the wave's first chunk, small numerators per lane

@@ -12,6 +12,7 @@ ap.add_argument('--pairs', action='store_true', help='mate-pair rows instead of 
 ap.add_argument('--group', action='store_true', help='rows grouped by read group')
 ap.add_argument('--packed', action='store_true', help='the bench layout: dev.lay_out (mate-pair rows, 4-bit sequence planes, grouped by read group)')
 ap.add_argument('--single', action='store_true', help='with --packed: one read per row on 4-bit planes (what single-end and mixed-length inputs get)')
+ap.add_argument('--restore', action='store_true', help='K2 stores through the permutation (rows grouped by read group go back into input order)')
 args = ap.parse_args()
 import torch
 from kbbq import _device as dev
@@ -28,12 +29,12 @@ t = dev.Tables(args.rgs, 2 * args.len)
 ctx = dev.context()
 dev.accumulate(b, t, check=False)
 lut, shape, _, _ = dev.solve(t)
-dev.apply(b, lut, shape, out=out, check=False)
+dev.apply(b, lut, shape, out=out, check=False, restore_order=args.restore)
 torch.cuda.synchronize()
 ctx.kernel_ms(0, reset=True); ctx.kernel_ms(1, reset=True); ctx.timing(True)
 for _ in range(args.reps):
     dev.accumulate(b, t, check=False)
-    dev.apply(b, lut, shape, out=out, check=False)
+    dev.apply(b, lut, shape, out=out, check=False, restore_order=args.restore)
 torch.cuda.synchronize()
 k1, n1 = ctx.kernel_ms(0); k2, n2 = ctx.kernel_ms(1)
 bases = args.reads * args.len
