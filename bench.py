@@ -228,6 +228,8 @@ class Resident:
         self.name = 'one read per row, pitch %d' % batch.pitch
         ev = lambda: torch.cuda.Event(enable_timing=True)
         if layout != 'reads':
+            first = dev.lay_out(batch, R, S, packed=(layout == 'packed'))       # the process's first launches: code load, allocations
+            del first
             a, b = ev(), ev()
             a.record()
             batch = dev.lay_out(batch, R, S, packed=(layout == 'packed'))
@@ -643,6 +645,8 @@ def run_rank(args):
                                    'accumulate + solve + apply end-to-end, device-resident' % (n, R),
                        'reads_per_gpu': n, 'read_len': S, 'read_groups': R, 'layout': layout_name,
                        'layout_pass_ms_before_the_timed_region': layout_pass_ms,
+                       'layout_inclusive_bases_per_s': (None if layout_pass_ms is None else
+                                                        bases_per_rank * world / ((step_ms + layout_pass_ms) * 1e-3)),
                        'parallelism': 'reads sharded x%d, 1 allreduce of count tables' % world},
             'ranks_seen': ranks_seen, 'backend': backend,
             'allreduce_ms_per_step': ar_ms,
