@@ -505,12 +505,21 @@ int kbbq_fastq_length_runs(const kbbq_fastq* f, int64_t first, int64_t n, const 
     auto cls = [&](uint32_t len) { return (int)(std::lower_bound(classes, classes + nclasses, std::max<uint32_t>(len, 1)) - classes); };
     int runs = 0, cur = -1;
     uint32_t all_long = 0, all_short = 0;
+    uint32_t above = 1, upto = 0;                              // the current class holds lengths in (above, upto]: empty at first
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t L = f->slen[first + i];
         all_long = std::max(all_long, L);
         if (L && (all_short == 0 || L < all_short)) all_short = L;
         if (runs > max_runs) continue;                         // too many: only the overall figures are still needed
-        const int c = cls(L);
+        const uint32_t L1 = std::max<uint32_t>(L, 1);
+        int c = cur;
+        if (!(L1 > above && L1 <= upto)) {                     // sorted input: almost every read stays in its neighbour's class
+            c = cls(L);
+            if (c != cur) {
+                above = c > 0 ? classes[c - 1] : 0u;
+                upto = c < nclasses ? classes[c] : 0xFFFFFFFFu;
+            }
+        }
         if (c != cur) {
             cur = c;
             if (++runs > max_runs) continue;
