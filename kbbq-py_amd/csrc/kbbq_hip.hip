@@ -950,7 +950,7 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
     q.perm = reinterpret_cast<const long long*>(d_perm);
     q.out = d_out; q.status = c->d_status;
     int per_cu = std::max(1, std::min<int>((int)(c->lds_bytes / lds), (K2V3_WAVES * 4 * 64) / K2V3_THREADS));
-    q.rpb = 64;      // smaller wave blocks / short-lived workgroups were measured slower (profiles/r01_traversal_microbench.md)
+    q.rpb = 64;      // the persistent kernel's wave block; smaller blocks were measured slower (profiles/r01_traversal_microbench.md)
     const int64_t nblocks = (nrows + q.rpb - 1) / q.rpb;
     const int64_t want = (nblocks + (K2V3_THREADS / 64) - 1) / (K2V3_THREADS / 64);
     const int slices = d_seg ? R : 1;

@@ -1,4 +1,4 @@
-// kbbq_k2_tile.h -- K2 with SHORT-LIVED workgroups (experiment of round 2; compare_reads.py:320-328 as kbbq_kernels_v3.h k2v3_apply).
+// kbbq_k2_tile.h -- K2 with SHORT-LIVED workgroups: what 4-bit planes run since round 2 (compare_reads.py:320-328 as kbbq_kernels_v3.h k2v3_apply).
 //
 // Why: the 2 read + 1 written traversal of persistent waves stops at 5.25-5.45 TB/s on this device, one short-lived wave per
 // KiB reaches 6.0-6.1 (profiles/r01_traversal_microbench.md); K2 is bound by that traversal (L1 request queue full 85 % of
