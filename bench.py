@@ -347,7 +347,7 @@ def extra_layout(torch, dev, parallel, n, steps, warmup, layout):
 def extra_mixed_lengths(torch, dev, n, steps, warmup, lo=36, hi=300):
     """BASELINE config 5, the recalibration half, device-resident: n reads of lo..hi bases in the length bands the file
     path cuts (kbbq/fastx.py BAND_CLASSES: every band at its own pitch), each band in the layout the product picks for
-    it (kbbq.recalibrate._lay_out: 4-bit planes up to 160 bases, one read per row), count tables of 2 x hi columns.
+    it (kbbq.recalibrate._lay_out: 4-bit planes, one read per row), count tables of 2 x hi columns.
     A step = K1 over every band (into a band's own tables, added to the file's: recalibrate._tally_local) -> solve ->
     K2 over every band."""
     from kbbq import fastx, recalibrate

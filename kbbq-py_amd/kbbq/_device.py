@@ -5,6 +5,7 @@ RCCL process group; every computation is a libkbbq_hip kernel reached through
 the C ABI (kbbq._native).  No CPU fallback exists.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -454,6 +455,7 @@ def _row_flags(batch):
 
 
 LONG_READS = 160         # beyond this a band's shortest read decides whether K1's LDS tables fit (kbbq_accumulate_band_dev)
+PACKED_READS = int(os.environ.get('KBBQ_PACKED_READS', '320'))      # longest read the file path still lays out on 4-bit planes
 
 
 def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None, s_band=0, s_min=0):

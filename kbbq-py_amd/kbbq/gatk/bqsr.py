@@ -233,7 +233,7 @@ def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxsc
         # carries a letter outside ACGTN, the reads are longer than K1's packed form takes, or K1's tables for this
         # minscore do not fit beside it (both refusals come before anything is counted)
         try:
-            dev.accumulate(canonical(S <= dev.LONG_READS), tables, minscore, dinuc_minscore=6)
+            dev.accumulate(canonical(S <= dev.PACKED_READS), tables, minscore, dinuc_minscore=6)
         except N.LutNeedsCheckedApply:
             dev.accumulate(canonical(False), tables, minscore, dinuc_minscore=6)
     benchmark._on_all_ranks(shard if m else (lambda: None), lo)

@@ -53,7 +53,7 @@ def _lay_out(batch, R, S, S_global=None):
     it is.  Mate-pair rows need count tables of exactly 2S columns, so a band shorter than the input's longest read
     keeps one read per row."""
     pairs = None if S_global in (None, S) else False
-    laid = dev.lay_out(batch, R, S, packed=S <= dev.LONG_READS, pairs=pairs)
+    laid = dev.lay_out(batch, R, S, packed=S <= dev.PACKED_READS, pairs=pairs)
     return None if laid is batch else laid
 
 
