@@ -959,9 +959,10 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
     // mate-pair rows on 4-bit planes: short-lived workgroups (kbbq_k2_tile.h) unless KBBQ_K2_TILE=0 (A/B timing); everything
     // else, and LUTs of one group beyond a third of the LDS, keeps the persistent kernel
     const char* tile = getenv("KBBQ_K2_TILE");
-    // (one read per row: while the narrowed LUT is no bigger than a third of what a workgroup streams)
+    // (one read per row: while two workgroups' copies of the narrowed LUT fit a CU -- rows of up to ~300 bases; measured up to
+    //  there, scripts/gpu_tilekb.sh: config 5's K2 0.651 -> 0.687 of roofline going from a 32 KB to a 52 KB limit)
     if (!(tile && !strcmp(tile, "0")) && nib && (R == 1 || d_seg) && q.cpr >= 2 && q.cpr <= 4096
-        && (pairs ? rg_bytes * 3 <= (size_t)c->lds_bytes : rg_bytes <= (size_t)32 << 10)) {
+        && (pairs ? rg_bytes * 3 <= (size_t)c->lds_bytes : rg_bytes <= (size_t)(getenv("KBBQ_K2_TILE_LUT_KB") ? atoi(getenv("KBBQ_K2_TILE_LUT_KB")) : 52) << 10)) {
         K2tParams t;
         t.seq = d_seq; t.qual = d_qual; t.meta = d_meta; t.nchunks = nrows * q.cpr; t.cpr = q.cpr; t.cpr_magic = q.cpr_magic;
         t.Qt = KQ; t.S2 = S2; t.maxlen = q.maxlen; t.lut = q.full; t.lut_bytes = (int)((rg_bytes + 15) & ~(size_t)15);
