@@ -245,7 +245,7 @@ def test_short_lived_k2_equals_the_persistent_k2(dev, n, R, monkeypatch):
 
 
 @pytest.mark.parametrize('lo,hi,R,packed', [(36, 48, 1, True), (20, 64, 3, True), (100, 150, 1, True), (161, 200, 2, False),
-                                            (1, 16, 1, True), (250, 300, 1, False)])
+                                            (1, 16, 1, True), (250, 300, 1, False), (161, 208, 2, True), (257, 300, 1, True)])
 def test_apply_with_the_lut_narrowed_to_the_rows_pitch(dev, oracle, lo, hi, R, packed, monkeypatch):
     """K2 on a length band whose rows are narrower than the tables (a band of a mixed-length input: tables of 2 x 300
     columns): the LUT holds only the columns such rows reach (k3_fill_row_lut) and 4-bit rows take the short-lived
@@ -269,6 +269,11 @@ def test_apply_with_the_lut_narrowed_to_the_rows_pitch(dev, oracle, lo, hi, R, p
     want = np.where(inside, ref[:n, :band.pitch] + 33, 0).astype(np.uint8)
     rows = dev.lay_out(band, R, hi, packed=packed, pairs=False)
     assert rows.nib == packed and (R == 1 or rows.seg is not None)
+    # K1 on the laid-out band (4-bit planes of long reads: the table-driven kernel with the shortest-read promise)
+    t2 = dev.Tables(R, 2 * S)
+    dev.accumulate(rows, t2, s_band=hi)
+    dev.accumulate(wide, t2)
+    assert torch.equal(t2.buf, t.buf)
     outs = {}
     for name, env in (('narrowed', {}), ('persistent', {'KBBQ_K2_TILE': '0'}), ('full', {'KBBQ_K2_ROWLUT': '0', 'KBBQ_K2_TILE': '0'})):
         for k, v in env.items():
