@@ -1,4 +1,6 @@
 # usage (GPU box): bash scripts/gpu_k1threads.sh -- K1 with 512- / 768-thread workgroups (second builds) against 1024
+# (the second builds: a copy of kbbq-py_amd/csrc with K1V3_THREADS edited, `make OUT=.../kbbq/libkbbq_hip_t512.so` / `_t768.so`, before gpurun;
+#  KBBQ_HIP_LIB selects the library a process loads)
 R=$GRAFT_REPO_ROOT
 cd $R
 for T in 512 768; do

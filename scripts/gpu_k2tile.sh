@@ -1,3 +1,4 @@
+# usage (GPU box): bash scripts/gpu_k2tile.sh -- K2 with short-lived workgroups against the persistent kernel (KBBQ_K2_TILE=0): layout tests, kernel timings at 1 / 8 read groups, bench line both ways
 R=$GRAFT_REPO_ROOT
 cd $R
 timeout -k 10 900 python -m pytest tests/test_gpu_layouts.py tests/test_gpu_pairs.py -x -q -m gpu > gpurun_out/gputests_k2t.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/gputests_k2t.log

@@ -1,3 +1,4 @@
+# usage (GPU box): bash scripts/gpu_r2g.sh -- mid-round check: layout / pair tests and kernel timings
 TAG=${1:-r2g}
 R=$GRAFT_REPO_ROOT
 cd $R
