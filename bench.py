@@ -219,10 +219,12 @@ def gbs(nbytes, ms):
 class Resident:
     """A device-resident synthetic batch in the layout the product would pick, with the cost of the layout passes."""
 
-    def __init__(self, dev, torch, rank, n, world, R, layout):
+    def __init__(self, dev, torch, rank, n, world, R, layout, single_end=False):
         S = READ_LEN
         self.dev, self.torch, self.R, self.S, self.n = dev, torch, R, S, n
         batch = dev.ReadBatch.synthetic(rank * n, n, world * n, seed=1, nrg=R)
+        if single_end:
+            batch.meta.bitwise_and_(0x7FFFFFFF)      # no read is second in pair (compare_reads.py:304-306): single-end input
         self.rows = batch                    # one read per row, input order: what the packer hands over
         self.layout_ms = {}
         self.name = 'one read per row, pitch %d' % batch.pitch
@@ -334,12 +336,13 @@ def extra_config3(torch, dev, parallel, n, steps, warmup):
                                          'them as they are; unpack_pairs_ms is the pass to one read per row for callers that want it)' % (lay, step_r_ms)}}
 
 
-def extra_layout(torch, dev, parallel, n, steps, warmup, layout):
-    res = Resident(dev, torch, 0, n, 1, 1, layout)
+def extra_layout(torch, dev, parallel, n, steps, warmup, layout, single_end=False):
+    res = Resident(dev, torch, 0, n, 1, 1, layout, single_end=single_end)
     res.free_rows()
     elapsed, k1, k2, n1, n2, _ = timed_steps(torch, None, False, dev, parallel, res, steps, warmup, False)
     bases = n * READ_LEN
-    return {'workload': '%d synthetic 2x150 bp reads, 1 read group' % n, 'layout': res.name,
+    return {'workload': ('%d synthetic single-end 150 bp reads, 1 read group' if single_end else '%d synthetic 2x150 bp reads, 1 read group') % n,
+            'layout': res.name,
             'value': bases * steps / elapsed, 'unit': 'bases/s', 'ms_per_step': elapsed / steps * 1e3,
             'k1_accumulate': kernel_entry(k1, n1, bases), 'k2_apply': kernel_entry(k2, n2, bases)}
 
@@ -556,6 +559,7 @@ def build_extra(torch, dev, parallel, args, headline_layout):
     for key, fn in (('config3_8rg', lambda: extra_config3(torch, dev, parallel, n, small, 1)),
                     ('layout_pairs', lambda: extra_layout(torch, dev, parallel, n, small, 1, 'pairs')),
                     ('layout_reads', lambda: extra_layout(torch, dev, parallel, n, small, 1, 'reads')),
+                    ('single_end_150', lambda: extra_layout(torch, dev, parallel, n, small, 1, 'packed', single_end=True)),
                     ('config5_mixed_lengths', lambda: extra_mixed_lengths(torch, dev, min(20_000_000, n), small, 1)),
                     ('aligned_read_kernels', lambda: extra_aligned(torch, dev, n=min(16_000_000, n), G=min(200_000_000, 50 * n))),
                     ('file_path', lambda: extra_file_path(torch, dev, n=min(8_000_000, n)))):

@@ -316,6 +316,8 @@ int    kbbq_accumulate_pairs_dev(kbbq_ctx* ctx, const uint8_t* d_pseq, const uin
                                  const uint32_t* d_pmeta, int64_t npairs, int R, int S2, int minscore,
                                  int dinuc_minscore, int64_t* d_tables);
 int    kbbq_pair_lut_dev(kbbq_ctx* ctx, const void* d_lut_blob, int R, int S2, int minscore, void* d_pair_lut);
+/* the same for rows described by layout flags (below): KBBQ_ROWS_PAIRS [| KBBQ_ROWS_NIBBLES] [| KBBQ_ROWS_TWINS] */
+int    kbbq_pair_lut_rows_dev(kbbq_ctx* ctx, const void* d_lut_blob, int R, int S2, int minscore, int flags, void* d_pair_lut);
 int    kbbq_apply_pairs_dev(kbbq_ctx* ctx, const uint8_t* d_pseq, const uint8_t* d_pqual, const uint32_t* d_pmeta,
                             int64_t npairs, int R, int S2, int minscore, const void* d_lut_blob,
                             const void* d_pair_lut, uint8_t* d_pout);
@@ -350,7 +352,8 @@ int    kbbq_apply_grouped_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t
  * straight back into the order they had before kbbq_group_rows_dev, no separate pass.
  * kbbq_meta_stats_dev: one pass over the sidecars (synchronises): h_stats8[0] shortest non-empty read, [1] longest
  * read, [2] largest read-group id, [3] violations of the mate-pair preconditions (0 = uniform first / second pairs
- * of one length and read group), [4] empty reads.
+ * of one length and read group), [4] empty reads, [5] violations of the KBBQ_ROWS_TWINS preconditions (0 = single-end reads of one
+ * length whose neighbours 2p / 2p+1 share a read group).
  * kbbq_group_rows_dev: stable counting sort of the rows (pairs != 0: of the PAIRS, by the first mate's sidecar)
  * by read group, R <= 256: d_perm[nrows] (row i of the grouped order is row d_perm[i]) and d_seg[R + 1];
  * d_work: kbbq_group_rows_work_bytes(nrows, R) bytes.  A sidecar with read group >= R -> KBBQ_E_RANGE (status).
@@ -359,6 +362,14 @@ int    kbbq_apply_grouped_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t
  * KBBQ_ROWS_NIBBLES), nrows = nreads / 2 and dpitch = kbbq_pair_pitch(S2) with KBBQ_ROWS_PAIRS, else nreads and pitch.  */
 #define KBBQ_ROWS_PAIRS    1
 #define KBBQ_ROWS_NIBBLES  2
+/* KBBQ_ROWS_TWINS (with KBBQ_ROWS_PAIRS): the two reads of every row are BOTH first in pair -- single-end input of one
+ * length packed two reads to a mate-pair row (same planes, same sidecar, same 5 % fewer bytes); the second half of a row
+ * then counts into / looks up the forward cycle columns [0, S) like the first half instead of the mirrored ones
+ * (compare_reads.py:304-306: no "/2" in the name).  Precondition (kbbq_meta_stats_dev h_stats8[5] == 0): no read is second
+ * in pair, reads 2p and 2p+1 share their read group, all reads have one length.  kbbq_accumulate_rows_dev and
+ * kbbq_pair_lut_rows_dev take the flag (the apply kernel reads it out of the LUT); kbbq_lay_out_dev packs such rows as any
+ * other pair rows.  */
+#define KBBQ_ROWS_TWINS    4
 int    kbbq_accumulate_rows_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                                 const uint32_t* d_meta, int64_t nrows, int pitch, int flags, int R, int S2, int S_band,
                                 int S_min, int minscore, int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables);

@@ -333,7 +333,8 @@ int kbbq_accumulate_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq
 
 static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                            const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
-                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band = 0, int S_min = 0, int nib = 0);
+                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band = 0, int S_min = 0, int nib = 0,
+                           int twins = 0);
 
 int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq,
                            const uint8_t* d_qual, const uint32_t* d_meta,
@@ -790,7 +791,7 @@ int kbbq_unpack_pairs_dev(kbbq_ctx* c, const uint8_t* d_pplane, int64_t npairs, 
 // K1 (table-driven kernel) on one-read-per-row or mate-pair rows, optionally grouped by read group
 static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                            const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
-                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band, int S_min, int nib)
+                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band, int S_min, int nib, int twins)
 {
     if (fits) *fits = true;
     if (S_band < 0 || S_band > S2 / 2 || (pairs && S_band)) return fail(KBBQ_E_ARG, "%s: S_band out of range (%d)", who, S_band);
@@ -811,7 +812,7 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     q.R = R; q.S = S; q.gS2 = S2; q.minscore = minscore; q.type_minscore = dinuc_minscore;
     q.qlo_m1 = 32u + (u32)minscore; q.dlo = 33u + (u32)dinuc_minscore;
     q.nrows = KQ + 1 - minscore;
-    q.maxlen = pairs ? S2 + 1 : S; q.gap = pairs ? 1 : 0;
+    q.maxlen = pairs ? S2 + 1 : S; q.gap = pairs ? 1 : 0; q.twins = (pairs && twins) ? 1 : 0;
     q.seg = reinterpret_cast<const long long*>(d_seg);
     q.tables = reinterpret_cast<u64*>(d_tables); q.status = c->d_status;
     // LDS geometry.  A cycle row has one word per first-in-pair position [0, S) and per second-in-pair index
@@ -898,14 +899,22 @@ int kbbq_accumulate_grouped_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t
 
 int kbbq_pair_lut_dev(kbbq_ctx* c, const void* d_lut_blob, int R, int S2, int minscore, void* d_pair_lut)
 {
+    return kbbq_pair_lut_rows_dev(c, d_lut_blob, R, S2, minscore, KBBQ_ROWS_PAIRS, d_pair_lut);
+}
+
+int kbbq_pair_lut_rows_dev(kbbq_ctx* c, const void* d_lut_blob, int R, int S2, int minscore, int flags, void* d_pair_lut)
+{
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
     int rc = check_pairs("kbbq_pair_lut_dev", 0, S2);
     if (rc) return rc;
+    if (!(flags & KBBQ_ROWS_PAIRS) || (flags & ~(KBBQ_ROWS_PAIRS | KBBQ_ROWS_NIBBLES | KBBQ_ROWS_TWINS)))
+        return fail(KBBQ_E_ARG, "kbbq_pair_lut_rows_dev: flags 0x%x are not those of mate-pair rows", flags);
     if (R <= 0 || R > 32767 || !d_lut_blob || !d_pair_lut) return fail(KBBQ_E_ARG, "kbbq_pair_lut_dev: bad argument");
     HIPCHK(hipSetDevice(c->device));
     PairLutParams f;
     f.lut16 = reinterpret_cast<const int16_t*>(d_lut_blob); f.rs16 = lut_row_stride(S2); f.R = R; f.Qt = KQ; f.S2 = S2;
     f.minscore = std::min(std::max(minscore, 0), KQ);
+    f.twins = (flags & KBBQ_ROWS_TWINS) ? 1 : 0;
     f.out = reinterpret_cast<int8_t*>(d_pair_lut);
     hipLaunchKernelGGL(k3_fill_pair_lut, dim3((unsigned)(R * (33 + KQ))), dim3(256), 0, c->stream, f);
     HIPCHK(hipGetLastError());
@@ -1032,7 +1041,8 @@ int kbbq_apply_grouped_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_q
 // ---- layouts: rows as handed over -> what K1 / K2 run fastest on ------------
 static int layout_flags_ok(const char* who, int flags)
 {
-    if (flags & ~(KBBQ_ROWS_PAIRS | KBBQ_ROWS_NIBBLES)) return fail(KBBQ_E_ARG, "%s: unknown layout flags 0x%x", who, flags);
+    if (flags & ~(KBBQ_ROWS_PAIRS | KBBQ_ROWS_NIBBLES | KBBQ_ROWS_TWINS)) return fail(KBBQ_E_ARG, "%s: unknown layout flags 0x%x", who, flags);
+    if ((flags & KBBQ_ROWS_TWINS) && !(flags & KBBQ_ROWS_PAIRS)) return fail(KBBQ_E_ARG, "%s: KBBQ_ROWS_TWINS describes mate-pair rows (add KBBQ_ROWS_PAIRS)", who);
     return KBBQ_OK;
 }
 
@@ -1047,7 +1057,7 @@ int kbbq_accumulate_rows_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d
     if (pairs) { rc = check_pairs("kbbq_accumulate_rows_dev", nrows, S2); if (rc) return rc; }
     return accumulate_rows(c, "kbbq_accumulate_rows_dev", d_seq, d_cseq, d_qual, d_meta, nrows, pitch, pairs, R, S2, minscore,
                            dinuc_minscore, d_seg, d_tables, nullptr, pairs ? 0 : S_band, pairs ? 0 : S_min,
-                           (flags & KBBQ_ROWS_NIBBLES) ? 1 : 0);
+                           (flags & KBBQ_ROWS_NIBBLES) ? 1 : 0, (flags & KBBQ_ROWS_TWINS) ? 1 : 0);
 }
 
 int kbbq_apply_rows_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta, int64_t nrows,

@@ -49,6 +49,8 @@ struct K1v3Params {
     int dn_flush_iters;         // workgroup iterations between flushes of the (16-bit packed) context table
     int maxlen;                 // longest row the tables take: S, or 2S + 1 for mate-pair rows
     int gap;                    // mate-pair rows: 1 (the separator byte between the mates), else 0
+    int twins;                  // mate-pair rows holding two FIRST-in-pair reads (single-end input packed two to a row): the second
+                                // half counts into the forward columns [0, S) like the first, not into the mirrored ones
     int gS2;                    // columns of the GLOBAL cycle tables (2 x the longest read of the whole input); S may be
                                 // smaller -- the longest read of THIS batch -- because a second-in-pair column
                                 // 2*len-1-i does not depend on the S the LDS table is laid out for
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                         prow[x] = 0u;
                         const int k = x / KJ, j = x - k * KJ, at = 16 * j + k;       // byte offset within the mate-pair row
                         if (at == S || at > S2) continue;                           // separator / padding: never counted
-                        const int col = at < S ? at : (S2 - 1 - (at - S - 1));
+                        const int col = at < S ? at : (p.twins ? at - S - 1 : S2 - 1 - (at - S - 1));
                         atomicAdd(&pos_total[grow + col], (u64)(v & 0xFFFFu));
                         if (v >> 16) atomicAdd(&pos_errs[grow + col], (u64)(v >> 16));
                     }
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
                 if (v) {
                     prow[x] = 0u;
                     if (p.gap && x == S) continue;                            // the separator byte of a mate-pair row is never counted
-                    const int col = x < S ? x : (S2 - 1 - (x - S - p.gap));
+                    const int col = x < S ? x : (p.twins ? x - S - p.gap : S2 - 1 - (x - S - p.gap));
                     atomicAdd(&pos_total[grow + col], (u64)(v & 0xFFFFu));
                     if (v >> 16) atomicAdd(&pos_errs[grow + col], (u64)(v >> 16));
                 }
@@ -1161,6 +1163,7 @@ __host__ __device__ __forceinline__ int pair_lut_row_bytes(int S2)
 
 struct PairLutParams {
     const int16_t* lut16; int rs16; int R; int Qt; int S2; int minscore;
+    int twins;                       // rows of two first-in-pair reads: the second half looks up the forward columns too
     int8_t* out;
 };
 
@@ -1180,7 +1183,7 @@ __global__ __launch_bounds__(256) void k3_fill_pair_lut(PairLutParams p)
             if (x < cyc) v = qb == 0 ? -33 : qb - 33;                     // padding -> 0 ; uncounted -> unchanged
         } else {
             if (x < S) v = src[x];                                        // mate 1: column = position
-            else if (x > S && x <= p.S2) v = src[p.S2 - 1 - (x - S - 1)]; // mate 2, position i = x-S-1: column 2S-1-i
+            else if (x > S && x <= p.S2) v = src[p.twins ? x - S - 1 : p.S2 - 1 - (x - S - 1)]; // mate 2, position i = x-S-1: column 2S-1-i (twins: i)
             else if (x >= cyc && x < cyc + 25) v = src[p.S2 + (x - cyc)];
         }
         dst[x] = (int8_t)v;

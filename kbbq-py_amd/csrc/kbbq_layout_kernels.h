@@ -20,12 +20,14 @@
 //          mates in different read groups, a length different from read 0's (0 = the batch can use mate-pair rows,
 //          given an even, non-zero number of reads)
 // stats[4] empty reads
+// stats[5] violations of "uniform pairs of FIRST-in-pair reads" (single-end input, two reads to a mate-pair row): a read that
+//          is second in pair, neighbours 2p / 2p+1 in different read groups, a length different from read 0's, an odd count
 #define K7_NSTATS 8
 struct MetaStatsParams { const u32* meta; long long n; int* stats; };
 
 __global__ __launch_bounds__(256) void k7_meta_stats(MetaStatsParams p)
 {
-    int mn = 0x7FFFFFFF, mx = 0, rgmax = 0, viol = 0, empty = 0;
+    int mn = 0x7FFFFFFF, mx = 0, rgmax = 0, viol = 0, empty = 0, tviol = 0;
     const u32 len0 = p.n > 0 ? (p.meta[0] & 0xFFFFu) : 0u;
     const long long npairs = (p.n + 1) >> 1;
     for (long long pr = (long long)blockIdx.x * blockDim.x + threadIdx.x; pr < npairs; pr += (long long)gridDim.x * blockDim.x) {
@@ -37,11 +39,13 @@ __global__ __launch_bounds__(256) void k7_meta_stats(MetaStatsParams p)
             if (len) { mn = len < mn ? len : mn; } else ++empty;
             mx = len > mx ? len : mx;
             rgmax = rg > rgmax ? rg : rgmax;
-            if ((m[k] & 0xFFFFu) != len0) ++viol;
+            if ((m[k] & 0xFFFFu) != len0) { ++viol; ++tviol; }
+            if ((m[k] >> 31) != 0u) ++tviol;
         }
         if ((mm.x >> 31) != 0u) ++viol;
         if (has2 && ((mm.y >> 31) == 0u || ((mm.x ^ mm.y) & 0x7FFF0000u) != 0u)) ++viol;
-        if (!has2) ++viol;
+        if (!has2) { ++viol; ++tviol; }
+        if (has2 && ((mm.x ^ mm.y) & 0x7FFF0000u) != 0u) ++tviol;
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -51,11 +55,13 @@ __global__ __launch_bounds__(256) void k7_meta_stats(MetaStatsParams p)
         o = __shfl_xor(rgmax, off); rgmax = o > rgmax ? o : rgmax;
         viol += __shfl_xor(viol, off);
         empty += __shfl_xor(empty, off);
+        tviol += __shfl_xor(tviol, off);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicMin(&p.stats[0], mn); atomicMax(&p.stats[1], mx); atomicMax(&p.stats[2], rgmax);
         if (viol) atomicAdd(&p.stats[3], viol);
         if (empty) atomicAdd(&p.stats[4], empty);
+        if (tviol) atomicAdd(&p.stats[5], tviol);
     }
 }
 

@@ -248,6 +248,7 @@ class PairBatch:
     nib = False
     seg = None
     perm = None
+    twins = False        # both reads of a row are first in pair: single-end input packed two to a row (KBBQ_ROWS_TWINS)
 
     def __init__(self, npairs, S, with_corrected=True, device=None, nib=False):
         torch = _torch()
@@ -263,7 +264,7 @@ class PairBatch:
         self.read_pitch = None
 
     def describe(self):
-        return _describe(self, 'mate-pair rows, pitch %d per pair' % self.pitch)
+        return _describe(self, ('two single-end reads per row, pitch %d' if self.twins else 'mate-pair rows, pitch %d per pair') % self.pitch)
 
     def layout_key(self):
         return 'pairs_nib' if self.nib else 'pairs'
@@ -314,7 +315,8 @@ def meta_stats(batch):
     st = np.zeros(8, dtype=np.int32)
     N.check(N.load().kbbq_meta_stats_dev(ctx.handle, N.ptr(batch.meta), batch.n, N.ptr(st)))
     shortest = int(st[0]) if st[0] != 0x7FFFFFFF else 0
-    return {'shortest': shortest, 'longest': int(st[1]), 'max_rg': int(st[2]), 'pair_violations': int(st[3]), 'empty': int(st[4])}
+    return {'shortest': shortest, 'longest': int(st[1]), 'max_rg': int(st[2]), 'pair_violations': int(st[3]), 'empty': int(st[4]),
+            'twin_violations': int(st[5])}
 
 
 def _describe(batch, base):
@@ -370,10 +372,11 @@ def _lay_out_rows(batch, flags, S2, perm, seg):
     pairs, nib = bool(flags & N.ROWS_PAIRS), bool(flags & N.ROWS_NIBBLES)
     if pairs:
         laid = PairBatch(batch.n // 2, S2 // 2, with_corrected=batch.cseq is not None, device=batch.seq.device, nib=nib)
-        laid.read_pitch = batch.pitch
+        laid.read_pitch, laid.twins = batch.pitch, bool(flags & N.ROWS_TWINS)
     elif isinstance(batch, PairBatch):                # pair rows gathered as rows: still pair rows
         laid = PairBatch(batch.n, batch.S, with_corrected=batch.cseq is not None, device=batch.seq.device, nib=nib)
-        laid.read_pitch = batch.read_pitch
+        laid.read_pitch, laid.twins = batch.read_pitch, batch.twins
+        flags &= ~N.ROWS_TWINS
     else:
         laid = ReadBatch(batch.n, batch.pitch, with_corrected=batch.cseq is not None, device=batch.seq.device, nib=nib)
     ctx = context(batch.seq.device.index)
@@ -387,7 +390,8 @@ def _lay_out_rows(batch, flags, S2, perm, seg):
 def lay_out(batch, R, S=None, packed=True, pairs=None, stats=None):
     """The device layout K1 / K2 run fastest on for this input-order ReadBatch, written in ONE pass
     (k7_lay_out): mate-pair rows when the reads are uniform first / second pairs of one length and read group (and
-    pair rows are narrower than two rows), rows gathered by read-group segment when R > 1, 4-bit sequence planes when
+    pair rows are narrower than two rows) -- or single-end reads of one length whose neighbours share a read group: the
+    same rows with `twins` set, both halves counting into the forward cycle columns --, rows gathered by read-group segment when R > 1, 4-bit sequence planes when
     `packed` and every base of seq AND cseq is one of ACGTN (otherwise the pass is repeated with character planes).
     The result carries `perm` (apply(..., restore_order=True) stores straight back into input order) and `seg`.
     Returns `batch` itself when no layout applies."""
@@ -397,11 +401,18 @@ def lay_out(batch, R, S=None, packed=True, pairs=None, stats=None):
         return batch
     st = stats or meta_stats(batch)
     S_ = st['longest']
+    # two reads to a row: first / second mates, or -- single-end input -- two first-in-pair neighbours (`twins`)
+    fits = batch.n % 2 == 0 and S_ > 0
+    twins = False
     if pairs is None:
-        pairs = batch.n % 2 == 0 and st['pair_violations'] == 0 and S_ > 0 and PairBatch.worthwhile(S_, batch.pitch)
-    elif pairs and (batch.n % 2 or st['pair_violations'] or S_ == 0):
-        raise ValueError('reads are not uniform first/second pairs of one length and read group')
-    flags = (N.ROWS_PAIRS if pairs else 0) | (N.ROWS_NIBBLES if packed else 0)
+        pairs = fits and st['pair_violations'] == 0 and PairBatch.worthwhile(S_, batch.pitch)
+        if not pairs and fits and st['twin_violations'] == 0 and PairBatch.worthwhile(S_, batch.pitch):
+            pairs = twins = True
+    elif pairs and not (fits and st['pair_violations'] == 0):
+        if not (fits and st['twin_violations'] == 0):
+            raise ValueError('reads are not uniform first/second pairs (or single-end neighbours) of one length and read group')
+        twins = True
+    flags = (N.ROWS_PAIRS if pairs else 0) | (N.ROWS_NIBBLES if packed else 0) | (N.ROWS_TWINS if twins else 0)
     perm = seg = None
     if R > 1:
         perm, seg = _group_perm(batch.meta, batch.n // 2 if pairs else batch.n, pairs, R)
@@ -451,7 +462,8 @@ _pair_luts = {}
 
 
 def _row_flags(batch):
-    return (N.ROWS_PAIRS if isinstance(batch, PairBatch) else 0) | (N.ROWS_NIBBLES if batch.nib else 0)
+    pairs = isinstance(batch, PairBatch)
+    return (N.ROWS_PAIRS if pairs else 0) | (N.ROWS_NIBBLES if batch.nib else 0) | (N.ROWS_TWINS if pairs and batch.twins else 0)
 
 
 LONG_READS = 160         # beyond this a band's shortest read decides whether K1's LDS tables fit (kbbq_accumulate_band_dev)
@@ -531,7 +543,7 @@ def apply(batch, lut_dev, shape, out=None, minscore=MINSCORE, check=True, restor
             if plut is None:
                 plut = torch.empty(lib.kbbq_pair_lut_bytes(R, NQ, S2), dtype=torch.uint8, device=batch.seq.device)
                 _pair_luts[key] = plut
-            N.check(lib.kbbq_pair_lut_dev(ctx.handle, N.ptr(lut_dev), R, S2, minscore, N.ptr(plut)))
+            N.check(lib.kbbq_pair_lut_rows_dev(ctx.handle, N.ptr(lut_dev), R, S2, minscore, _row_flags(batch), N.ptr(plut)))
         perm = batch.perm if (restore_order and grouped) else None
         N.check(lib.kbbq_apply_rows_dev(ctx.handle, N.ptr(batch.seq), N.ptr(batch.qual), N.ptr(batch.meta), batch.n,
                                         batch.pitch, _row_flags(batch), R, S2, minscore, N.ptr(lut_dev), N.ptr(plut),

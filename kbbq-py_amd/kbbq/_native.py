@@ -23,7 +23,7 @@ KBBQ_E_NAME = -6
 KBBQ_E_LUT = -7
 KBBQ_E_MEANQ = -8
 APPLY_CHECKED, APPLY_FAST = 0, 1
-ROWS_PAIRS, ROWS_NIBBLES = 1, 2
+ROWS_PAIRS, ROWS_NIBBLES, ROWS_TWINS = 1, 2, 4
 
 NQ = 43
 NDINUC = 16
@@ -80,6 +80,7 @@ PROTOTYPES = {
     'kbbq_unpack_pairs_dev': (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     'kbbq_accumulate_pairs_dev': (_i, [_vp] * 5 + [_i64, _i, _i, _i, _i, _vp]),
     'kbbq_pair_lut_dev': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'kbbq_pair_lut_rows_dev': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'kbbq_apply_pairs_dev': (_i, [_vp] * 4 + [_i64, _i, _i, _i] + [_vp] * 3),
     'kbbq_accumulate_grouped_dev': (_i, [_vp] * 5 + [_i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'kbbq_apply_grouped_dev': (_i, [_vp] * 4 + [_i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -285,3 +285,34 @@ def test_apply_with_the_lut_narrowed_to_the_rows_pitch(dev, oracle, lo, hi, R, p
         assert np.array_equal(plain[:n], want), name
         assert np.array_equal(outs[name][:n], want), name
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('S,R,n,packed', [(150, 1, 6000, True), (150, 4, 8000, True), (100, 2, 4000, True), (70, 1, 2002, False),
+                                          (151, 3, 3000, True)])
+def test_single_end_reads_take_mate_pair_rows_two_to_a_row(dev, oracle, S, R, n, packed):
+    """Single-end input (no read is second in pair, compare_reads.py:304-306) of one length: lay_out packs two
+    neighbouring reads into a mate-pair row (KBBQ_ROWS_TWINS) and K1 / K2 treat both halves as first-in-pair reads --
+    the oracle's counts and qualities, which differ from what the same rows would give as first / second mates."""
+    import torch
+    b = dev.ReadBatch.synthetic(0, n, n, seed=91 + S + R, len_lo=S, len_hi=S, nrg=R)
+    assert dev.meta_stats(b)['twin_violations'] > 0 and dev.meta_stats(b)['pair_violations'] == 0
+    b.meta.bitwise_and_(0x7FFFFFFF)                                  # nobody is second in pair any more
+    st = dev.meta_stats(b)
+    assert st['twin_violations'] == 0 and st['pair_violations'] > 0
+    seq, cseq, qual, meta = _host(b, n)
+    want, ref = _oracle_run(oracle, seq, cseq, qual, meta, R, S)
+    laid = dev.lay_out(b, R, S, packed=packed)
+    assert isinstance(laid, dev.PairBatch) and laid.twins and laid.nib == packed and (laid.seg is not None) == (R > 1)
+    t = dev.Tables(R, 2 * S)
+    dev.accumulate(laid, t)
+    for got, w in zip(t.to_host(), want[5:9]):
+        assert np.array_equal(got, w)
+    assert int(t.to_host()[1][..., S:].sum()) == 0                    # nothing in the second-in-pair columns
+    lut, shape = dev.solve_lut(t)
+    out = laid.unpack(dev.apply(laid, lut, shape, restore_order=True), b.pitch)
+    assert np.array_equal(out[:n, :S].cpu().numpy().astype(np.int32) - 33, ref[:, :S])
+    # one read of another length, or an odd read out, and the batch keeps one read per row
+    odd = dev.ReadBatch.synthetic(0, n - 1, n - 1, seed=5, len_lo=S, len_hi=S, nrg=R)
+    odd.meta.bitwise_and_(0x7FFFFFFF)
+    assert not isinstance(dev.lay_out(odd, R, S, packed=packed), dev.PairBatch)
+    torch.cuda.synchronize()

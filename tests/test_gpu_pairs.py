@@ -180,6 +180,35 @@ def test_a_shorter_band_of_uniform_pairs_keeps_one_read_per_row(dev, oracle, sho
         assert np.array_equal(g, w)
 
 
+@pytest.mark.parametrize('nrg,infer', [(1, False), (3, True)])
+def test_single_end_files_go_two_reads_to_a_row(dev, oracle, nrg, infer, tmp_path, capfd):
+    """Single-end FASTQ files (no name ends in /2: every read is first in pair, compare_reads.py:304-306) of one length:
+    the file path lays two neighbouring reads into one mate-pair row (KBBQ_ROWS_TWINS) -- the whole command against the
+    oracle's text, with one read group and with read groups that change every second read."""
+    from kbbq import recalibrate, _device as D
+    n = 3000
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 7, 150, 150, nrg)
+    meta = meta & np.uint32(0x7FFFFFFF)
+    names = ['s%d' % i + ('_RG:Z:g%d' % ((i >> 1) % nrg) if infer else '') for i in range(n)]
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, names, cseq, qual, meta)
+    want, wantv, _ = oracle.recalibrate_fastq_text([fa, fb], infer)
+    seen = []
+    real = D.lay_out
+    D.lay_out = lambda *a, **k: seen.append(real(*a, **k)) or seen[-1]
+    try:
+        capfd.readouterr()
+        recalibrate.recalibrate_fastq([fa, fb], infer_rg=infer)
+        assert capfd.readouterr().out == want
+    finally:
+        D.lay_out = real
+    assert seen and all(isinstance(b, D.PairBatch) and b.twins for b in seen)
+    vec = recalibrate.fastq_to_covariate_arrays([fa, fb], infer_rg=infer)
+    for g, w in zip(vec, wantv):
+        assert np.array_equal(g, w)
+
+
 def _run_ranks(world, argv, timeout=300):
     import os, socket, subprocess, sys
     from conftest import ROOT
