@@ -29,6 +29,9 @@ while time.time() < t_end:
     qlo, qhi = int(rng.integers(0, 10)), int(rng.integers(20, 43))
     info = dict(S=S, lo=lo, nrg=nrg, minscore=minscore, n=n, q=(qlo, qhi), seed=cases)
     b = dev.ReadBatch.synthetic(0, n, n, seed=cases, len_lo=lo, len_hi=S, nrg=nrg, qlo=qlo, qhi=qhi)
+    if rng.random() < 0.25:                            # single-end input: no read is second in pair (lay_out: two reads to a row)
+        b.meta.bitwise_and_(0x7FFFFFFF)
+        info['single_end'] = True
     meta = b.meta[:n].cpu().numpy().view(np.uint32)
     lens = (meta & 0xFFFF).astype(np.int64)
     host = [x.cpu().numpy() for x in (b.seq[:n], b.cseq[:n], b.qual[:n])]
