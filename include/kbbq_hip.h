@@ -366,7 +366,8 @@ int    kbbq_apply_grouped_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t
  * length packed two reads to a mate-pair row (same planes, same sidecar, same 5 % fewer bytes); the second half of a row
  * then counts into / looks up the forward cycle columns [0, S) like the first half instead of the mirrored ones
  * (compare_reads.py:304-306: no "/2" in the name).  Precondition (kbbq_meta_stats_dev h_stats8[5] == 0): no read is second
- * in pair, reads 2p and 2p+1 share their read group, all reads have one length.  kbbq_accumulate_rows_dev and
+ * in pair, reads 2p and 2p+1 share their read group, all reads have one length (an odd count is fine: the last row's second
+ * half is padding, kbbq_lay_out_dev writes (nreads + 1) / 2 rows).  kbbq_accumulate_rows_dev and
  * kbbq_pair_lut_rows_dev take the flag (the apply kernel reads it out of the LUT); kbbq_lay_out_dev packs such rows as any
  * other pair rows.  */
 #define KBBQ_ROWS_TWINS    4

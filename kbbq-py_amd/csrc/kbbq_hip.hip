@@ -1134,9 +1134,9 @@ int kbbq_lay_out_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq, c
     if (!d_seq || !d_qual || !d_meta || !d_lseq || !d_lqual || !d_lmeta || (d_cseq && !d_lcseq)) return fail(KBBQ_E_ARG, "kbbq_lay_out_dev: NULL pointer");
     if (((uintptr_t)d_lseq | (uintptr_t)d_lcseq | (uintptr_t)d_lqual) & 15) return fail(KBBQ_E_ARG, "kbbq_lay_out_dev: planes must be 16-byte aligned");
     if (pairs) {
-        rc = check_pairs("kbbq_lay_out_dev", nreads / 2, S2);
+        rc = check_pairs("kbbq_lay_out_dev", (nreads + 1) / 2, S2);
         if (rc) return rc;
-        if (nreads & 1) return fail(KBBQ_E_ARG, "kbbq_lay_out_dev: mate-pair rows need an even number of reads");
+        if ((nreads & 1) && !(flags & KBBQ_ROWS_TWINS)) return fail(KBBQ_E_ARG, "kbbq_lay_out_dev: mate-pair rows need an even number of reads");
         if (pitch < S2 / 2) return fail(KBBQ_E_ARG, "kbbq_lay_out_dev: pitch %d < read length %d", pitch, S2 / 2);
     }
     if (nreads == 0) return KBBQ_OK;
@@ -1144,7 +1144,7 @@ int kbbq_lay_out_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq, c
     LayOutParams p;
     p.src[0] = d_seq; p.src[1] = d_cseq; p.src[2] = d_qual; p.dst[0] = d_lseq; p.dst[1] = d_lcseq; p.dst[2] = d_lqual;
     p.meta = d_meta; p.dmeta = d_lmeta; p.perm = reinterpret_cast<const long long*>(d_perm);
-    p.nrows = pairs ? nreads / 2 : nreads; p.pitch = pitch; p.dpitch = pairs ? pair_pitch(S2) : pitch; p.S = pairs ? S2 / 2 : 0;
+    p.nrows = pairs ? (nreads + 1) / 2 : nreads; p.nsrc = nreads; p.pitch = pitch; p.dpitch = pairs ? pair_pitch(S2) : pitch; p.S = pairs ? S2 / 2 : 0;
     p.pairs = pairs; p.nib = nib; p.status = c->d_status;
     const int rpb7 = (p.dpitch / 16) <= 256 ? 256 / (p.dpitch / 16) : 1;      // destination rows per workgroup iteration
     const int gx = bounded_grid((p.nrows + rpb7 - 1) / rpb7, c, 256, "KBBQ_K7_GRID");

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k7_meta_stats(MetaStatsParams p)
         }
         if ((mm.x >> 31) != 0u) ++viol;
         if (has2 && ((mm.y >> 31) == 0u || ((mm.x ^ mm.y) & 0x7FFF0000u) != 0u)) ++viol;
-        if (!has2) { ++viol; ++tviol; }
+        if (!has2) ++viol;                                            // (a lone last single-end read gets an empty partner: no twin violation)
         if (has2 && ((mm.x ^ mm.y) & 0x7FFF0000u) != 0u) ++tviol;
     }
 #pragma unroll
@@ -188,6 +188,7 @@ struct LayOutParams {
     const u32* meta; u32* dmeta;
     const long long* perm;
     long long nrows;                                  // destination rows
+    long long nsrc;                                   // source reads (pairs: 2 * nrows, or one less -- the last row's second half stays empty)
     int pitch, dpitch, S, pairs, nib;
     u64* status;
 };
@@ -229,8 +230,7 @@ __global__ __launch_bounds__(256) void k7_lay_out(LayOutParams p)
     const int slot = cpr <= 256 ? (int)threadIdx.x / cpr : 0;
     const int j0 = (int)threadIdx.x - slot * cpr;
     const bool idle = cpr <= 256 && slot >= rpb;
-    const long long src_rows = p.pairs ? 2 * p.nrows : p.nrows;
-    const long long limit = src_rows * (long long)p.pitch;              // bytes in a source plane (perm is a permutation)
+    const long long limit = p.nsrc * (long long)p.pitch;                // bytes in a source plane (perm is a permutation)
     for (long long rb = (long long)blockIdx.x * rpb; rb < p.nrows; rb += (long long)gridDim.x * rpb) {
         const long long d = rb + slot;
         if (idle || d >= p.nrows) continue;
@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) void k7_lay_out(LayOutParams p)
                 if (j == 0) p.dmeta[d] = (u32)(2 * S + 1) | (p.meta[2 * r] & 0x7FFF0000u);
                 // bytes [16j, 16j+16) of the pair row: mate 1 from its offset 16j, mate 2 from its offset 16j - S - 1
                 const long long at1 = (2 * r) * (long long)p.pitch + (16 * j < p.pitch ? 16 * j : p.pitch - 16);
-                const long long at2 = (2 * r + 1) * (long long)p.pitch + (16 * j - S - 1 < -15 ? 0 : 16 * j - S - 1);
+                const bool lone = 2 * r + 1 >= p.nsrc;                  // an odd number of single-end reads: the last row's second half is padding
+                const long long at2 = lone ? 0 : (2 * r + 1) * (long long)p.pitch + (16 * j - S - 1 < -15 ? 0 : 16 * j - S - 1);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
                     if (!p.src[pl]) continue;
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void k7_lay_out(LayOutParams p)
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
                         const u32 m1 = 16 * j < p.pitch ? byte_mask(S - 16 * j, w) : 0u;
-                        const u32 m2 = range_mask(S + 1 - 16 * j, 2 * S + 1 - 16 * j, w);
+                        const u32 m2 = lone ? 0u : range_mask(S + 1 - 16 * j, 2 * S + 1 - 16 * j, w);
                         o[pl][w] = (a[w] & m1) | (b[w] & m2) | (f4 & ~(m1 | m2));
                     }
                 }

@@ -371,7 +371,7 @@ def _lay_out_rows(batch, flags, S2, perm, seg):
     """kbbq_lay_out_dev: input-order rows -> the destination layout, one pass."""
     pairs, nib = bool(flags & N.ROWS_PAIRS), bool(flags & N.ROWS_NIBBLES)
     if pairs:
-        laid = PairBatch(batch.n // 2, S2 // 2, with_corrected=batch.cseq is not None, device=batch.seq.device, nib=nib)
+        laid = PairBatch((batch.n + 1) // 2, S2 // 2, with_corrected=batch.cseq is not None, device=batch.seq.device, nib=nib)
         laid.read_pitch, laid.twins = batch.pitch, bool(flags & N.ROWS_TWINS)
     elif isinstance(batch, PairBatch):                # pair rows gathered as rows: still pair rows
         laid = PairBatch(batch.n, batch.S, with_corrected=batch.cseq is not None, device=batch.seq.device, nib=nib)
@@ -402,20 +402,22 @@ def lay_out(batch, R, S=None, packed=True, pairs=None, stats=None):
     st = stats or meta_stats(batch)
     S_ = st['longest']
     # two reads to a row: first / second mates, or -- single-end input -- two first-in-pair neighbours (`twins`)
+    # (an odd number of single-end reads is fine: the last row's second half stays padding)
     fits = batch.n % 2 == 0 and S_ > 0
+    twin_fits = S_ > 0 and batch.n >= 2 and st['twin_violations'] == 0
     twins = False
     if pairs is None:
         pairs = fits and st['pair_violations'] == 0 and PairBatch.worthwhile(S_, batch.pitch)
-        if not pairs and fits and st['twin_violations'] == 0 and PairBatch.worthwhile(S_, batch.pitch):
+        if not pairs and twin_fits and PairBatch.worthwhile(S_, batch.pitch):
             pairs = twins = True
     elif pairs and not (fits and st['pair_violations'] == 0):
-        if not (fits and st['twin_violations'] == 0):
+        if not twin_fits:
             raise ValueError('reads are not uniform first/second pairs (or single-end neighbours) of one length and read group')
         twins = True
     flags = (N.ROWS_PAIRS if pairs else 0) | (N.ROWS_NIBBLES if packed else 0) | (N.ROWS_TWINS if twins else 0)
     perm = seg = None
     if R > 1:
-        perm, seg = _group_perm(batch.meta, batch.n // 2 if pairs else batch.n, pairs, R)
+        perm, seg = _group_perm(batch.meta, (batch.n + 1) // 2 if pairs else batch.n, pairs, R)
     if not flags and perm is None:
         return batch
     ctx = context(batch.seq.device.index)

@@ -311,8 +311,20 @@ def test_single_end_reads_take_mate_pair_rows_two_to_a_row(dev, oracle, S, R, n,
     lut, shape = dev.solve_lut(t)
     out = laid.unpack(dev.apply(laid, lut, shape, restore_order=True), b.pitch)
     assert np.array_equal(out[:n, :S].cpu().numpy().astype(np.int32) - 33, ref[:, :S])
-    # one read of another length, or an odd read out, and the batch keeps one read per row
+    # an odd number of reads: the last row's second half stays padding -- same counts and bytes as one read per row
     odd = dev.ReadBatch.synthetic(0, n - 1, n - 1, seed=5, len_lo=S, len_hi=S, nrg=R)
     odd.meta.bitwise_and_(0x7FFFFFFF)
+    lone = dev.lay_out(odd, R, S, packed=packed)
+    assert isinstance(lone, dev.PairBatch) and lone.twins and lone.n == n // 2
+    ta, tb = dev.Tables(R, 2 * S), dev.Tables(R, 2 * S)
+    dev.accumulate(odd, ta)
+    dev.accumulate(lone, tb)
+    assert torch.equal(ta.buf, tb.buf)
+    lut, shape = dev.solve_lut(ta)
+    plain = dev.apply(odd, lut, shape)
+    got = lone.unpack(dev.apply(lone, lut, shape, restore_order=True), odd.pitch)
+    assert got.shape[0] == n and torch.equal(got[:n - 1], plain[:n - 1]) and int(got[n - 1].sum()) == 0
+    # one read of another length and the batch keeps one read per row
+    odd.meta[3] = (odd.meta[3] & ~0xFFFF) | (S - 1)
     assert not isinstance(dev.lay_out(odd, R, S, packed=packed), dev.PairBatch)
     torch.cuda.synchronize()

@@ -26,10 +26,13 @@ while time.time() < t_end:
     nrg = int(rng.choice([1, 1, 2, 3, 8, int(rng.integers(1, 40))]))
     minscore = int(rng.choice([6, 6, 6, 0, 2, 3, 10, 20, 40]))
     n = int(rng.choice([2, 64, 130, int(rng.integers(2, 6000)), int(rng.integers(2, 60000))])) // 2 * 2
+    single_end = rng.random() < 0.25                   # no read is second in pair (lay_out: two reads to a row), any count
+    if single_end and rng.random() < 0.5:
+        n += 1
     qlo, qhi = int(rng.integers(0, 10)), int(rng.integers(20, 43))
     info = dict(S=S, lo=lo, nrg=nrg, minscore=minscore, n=n, q=(qlo, qhi), seed=cases)
     b = dev.ReadBatch.synthetic(0, n, n, seed=cases, len_lo=lo, len_hi=S, nrg=nrg, qlo=qlo, qhi=qhi)
-    if rng.random() < 0.25:                            # single-end input: no read is second in pair (lay_out: two reads to a row)
+    if single_end:
         b.meta.bitwise_and_(0x7FFFFFFF)
         info['single_end'] = True
     meta = b.meta[:n].cpu().numpy().view(np.uint32)
