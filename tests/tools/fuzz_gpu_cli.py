@@ -31,6 +31,9 @@ while time.time() < t_end:
         lo = S if rng.random() < 0.5 else int(rng.integers(max(1, S - 120), S + 1))
         nrg = int(rng.integers(1, 7)); infer = bool(rng.random() < 0.6)
         n = int(rng.choice([2, 66, int(rng.integers(2, 3000)), int(rng.integers(2, 40000))])) // 2 * 2
+        single_end = rng.random() < 0.25                              # no name ends in /2: every read is first in pair; any count
+        if single_end and rng.random() < 0.5:
+            n += 1
         seq, cseq, qual, meta = O.synth(0, n, n, cases, lo, S, nrg)
         order = np.argsort(meta & 0xFFFF, kind='stable')              # non-decreasing lengths: the only order the reference accepts
         seq, cseq, qual, meta = seq[order], cseq[order], qual[order], meta[order]
@@ -39,6 +42,8 @@ while time.time() < t_end:
             names = [nm.split('_')[0] + '_RG:Z:g%d' % ((m >> 16) & 0x7FFF) for nm, m in zip(names, meta.tolist())]
         else:
             meta = meta & 0x8000FFFF
+        if single_end:
+            names = ['s%d%s' % (i, nm[nm.index('_'):] if '_' in nm else '') for i, nm in enumerate(names)]
         second = np.array([nm.split('_')[0].endswith('/2') for nm in names])
         meta = (meta & 0x7FFFFFFF) | (second.astype(np.uint32) << 31)
         fa, fb = os.path.join(tmp, 'a.fq'), os.path.join(tmp, 'b.fq')
@@ -52,7 +57,7 @@ while time.time() < t_end:
             ga, gb = fa + '.gz', fb + '.gz'
         else:
             ga, gb = fa, fb
-        info = dict(case=cases, n=n, keep=keep, S=S, lo=lo, nrg=nrg, infer=infer, gz=ga != fa)
+        info = dict(case=cases, n=n, keep=keep, S=S, lo=lo, nrg=nrg, infer=infer, gz=ga != fa, single_end=single_end)
         try:
             want = O.recalibrate_fastq_text([fa, fb], infer)[0].encode('latin-1')
         except Exception as e:                                        # noqa: BLE001 -- the oracle refuses: not a case for this campaign
