@@ -234,6 +234,23 @@ def test_two_ranks_print_the_reference_output(dev, oracle, name, tmp_path):
     assert len(text) == info['output_len'] and oracle.sha256(text) == info['output_sha256']
 
 
+@pytest.mark.parametrize('n,world', [(4001, 2), (3000, 3)])
+def test_ranks_recalibrate_single_end_files(dev, oracle, n, world, tmp_path):
+    """Single-end FASTQ files under torch.distributed.run (gloo rehearsal on this GPU): every rank cuts its own byte
+    range (no name ends in /2, so any record start is a cut point), lays its reads two to a row -- an odd shard
+    included -- and the rank-ordered output is the oracle's text."""
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 11, 150, 150, 2)
+    meta = meta & np.uint32(0x7FFFFFFF)
+    names = ['s%d_RG:Z:g%d' % (i, (i >> 1) % 2) for i in range(n)]
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, names, cseq, qual, meta)
+    want = oracle.recalibrate_fastq_text([fa, fb], True)[0]
+    r = _run_ranks(world, ['recalibrate', '-f', fa, fb, '--infer-rg'])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout.decode() == want
+
+
 @pytest.mark.parametrize('name,world', [('c1_10k_1rg', 2), ('c3cut_2k_8rg', 3), ('c5cut_2k_mixed', 2)])
 def test_ranks_write_their_own_files(dev, oracle, name, world, tmp_path):
     """`kbbq recalibrate -o FILE` under torch.distributed.run: every rank cuts, indexes and scans its own byte range of
