@@ -781,3 +781,18 @@ def test_scan_refuses_more_read_groups_than_the_sidecar_holds(tmp_path):
     f = fastx.NativeFastq(str(path))
     with pytest.raises(ValueError, match='32767 read groups'):
         f.scan(f, True)
+
+
+def test_pmc_traffic_belongs_to_the_current_kernel_sources():
+    """profiles/pmc_traffic.json (the HBM bytes per base bench.py's roofline.traffic is computed from) was taken on the
+    kernel sources in the tree: after an edit of K1 / K2 re-run scripts/gpu_pmc_r2.sh and commit its pmc_traffic.json --
+    until then bench.py prints `traffic: null`, which this test turns into a visible failure instead of a silent one."""
+    import json
+    import bench
+    with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as fh:
+        pmc = json.load(fh)
+    assert pmc['kernel_source_sha'] == bench.kernel_source_sha()
+    for layout in ('pairs_nib', 'pairs', 'reads'):
+        for kernel in ('k1_accumulate', 'k2_apply'):
+            assert 1.5 < pmc[layout][kernel]['hbm_bytes_per_base'] < 3.6
+    assert bench.pmc_traffic('pairs_nib', 'k2_apply') == pmc['pairs_nib']['k2_apply']['hbm_bytes_per_base']
