@@ -155,7 +155,7 @@ def cpu_port_all_cores(sample_reads):
     cores = host_cores()
     per = sample_reads // cores // 2 * 2
     jobs = [(k * per, per, cores * per) for k in range(cores)]
-    with mp.get_context('fork').Pool(cores) as pool:
+    with mp.get_context('spawn').Pool(cores) as pool:       # fresh children: nothing of this process (a profiler's preloads, a HIP context) is inherited
         t0 = time.perf_counter()
         parts = pool.map(_port_worker, jobs)
         t1 = time.perf_counter()
@@ -271,7 +271,7 @@ def timed_steps(torch, dist, use_dist, dev, parallel, res, steps, warmup, rehear
             b.record()
             if timed:
                 ar_events.append((a, b))
-        lut, shape = dev.solve_lut(res.tables, check=False)
+        lut, shape = dev.solve_lut(res.tables, check=False, reuse=True)
         dev.apply(res.batch, lut, shape, out=res.out, check=False, restore_order=restore_order)
 
     def fence():
@@ -382,7 +382,7 @@ def extra_mixed_lengths(torch, dev, n, steps, warmup, lo=36, hi=300):
             part.buf.zero_()
             dev.accumulate(it['rows'], part, check=False, s_band=it['S'], s_min=it['Smin'])
             tables.add(part)
-        lut, shape = dev.solve_lut(tables, check=False)
+        lut, shape = dev.solve_lut(tables, check=False, reuse=True)
         for it in items:
             dev.apply(it['rows'], lut, shape, out=it['out'], check=False)
     for _ in range(warmup):
@@ -586,10 +586,22 @@ def run_rank(args):
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    # the CPU figures come FIRST: the all-core leg forks worker processes, which must not inherit a HIP context or the
+    # runtime's threads (nothing GPU-side has been imported or initialised yet)
+    cpu_base = None
+    if world == 1 and rank == 0 and args.cpu_sample > 0:
+        assert 'torch' not in sys.modules
+        cpu_base = cpu_port_one_core(args.cpu_sample)
+        if not args.no_extra:
+            try:
+                cpu_base['all_cores'] = cpu_port_all_cores(args.cpu_sample * 2)
+            except Exception as e:        # noqa: BLE001
+                cpu_base['all_cores'] = {'error': '%s: %s' % (type(e).__name__, e)}
+
+    import torch
+    import torch.distributed as dist
     local = int(os.environ.get('LOCAL_RANK', '0'))
     use_dist = 'RANK' in os.environ                 # launched by torch.distributed.run (any N, also 1)
     # fewer devices than ranks (a one-GPU box): every rank on the devices that exist, gloo instead of RCCL --
@@ -614,7 +626,11 @@ def run_rank(args):
     elapsed, k1_avg, k2_avg, k1_n, k2_n, ar_ms = timed_steps(torch, dist, use_dist, dev, parallel, res, args.steps,
                                                               args.warmup, rehearse)
     t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if rehearse or not use_dist else 'cuda')
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if use_dist:
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]      # stragglers show here
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ranks_seen = dist.get_world_size() if use_dist else 1
@@ -654,6 +670,7 @@ def run_rank(args):
                        'parallelism': 'reads sharded x%d, 1 allreduce of count tables' % world},
             'ranks_seen': ranks_seen, 'backend': backend,
             'allreduce_ms_per_step': ar_ms,
+            'per_rank_ms_per_step': {'min': min(per_rank_ms), 'max': max(per_rank_ms), 'ranks': per_rank_ms},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': domk['GB/s'], 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': domk['frac'],
                          'traffic': None if per_base is None else per_base * bases_per_rank,
@@ -663,8 +680,8 @@ def run_rank(args):
             'kernels': {'k1_accumulate': k1, 'k2_apply': k2,
                         'host_solve_and_sync_ms': step_ms - k1_avg - k2_avg},
         }
-        if world == 1 and args.cpu_sample > 0:
-            base = cpu_port_one_core(args.cpu_sample)
+        if cpu_base is not None:
+            base = cpu_base
             ref = reference_figure()
             if ref is not None:
                 base['reference_bases_per_s'] = ref.get('end_to_end_bases_per_s')
@@ -674,11 +691,7 @@ def run_rank(args):
                                           'the build container (%s host cores there) by oracle/gen_golden.py: tests/golden/c1_10k_1rg.json'
                                           % ref.get('host_cores', '8'))
             base['host_cores'] = host_cores()
-            if not args.no_extra:
-                try:
-                    base['all_cores'] = cpu_port_all_cores(args.cpu_sample * 2)
-                except Exception as e:        # noqa: BLE001
-                    base['all_cores'] = {'error': '%s: %s' % (type(e).__name__, e)}
+            base['measured'] = 'before the first GPU call of this process (the worker pool of the all-core leg is forked from a process without a HIP context)'
             res_line['cpu_baseline'] = base
         if world == 1 and not args.no_extra:
             res_line['extra'] = build_extra(torch, dev, parallel, args, args.layout)

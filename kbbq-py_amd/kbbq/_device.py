@@ -670,19 +670,20 @@ def _consts172():
 _consts172_ = None
 
 
-def solve_lut(tables, minscore=MINSCORE, check=True):
+def solve_lut(tables, minscore=MINSCORE, check=True, reuse=False):
     """(lut_dev, shape) for apply(): count tables -> apply LUT with NOTHING from the host inside the step when the
     device's gammaln has been proven equal to the host's (device_logtab): marginals, gammaln terms, meanq and the four
     levels of applybqsr.get_delta_qs are kernels on the launch stream, the buffers are kept per table shape.  A meanq the
     kernel cannot decide in double precision (within 1e-7 of a truncation boundary -- one quality value only is such a
     case) is reported by the status word: with check=True it is read here (one synchronisation) and the solve redone
-    with the host's longdouble meanq; with check=False the caller's context().status() raises MeanqNeedsHost."""
+    with the host's longdouble meanq; with check=False the caller's context().status() raises MeanqNeedsHost.
+    reuse: the LUT is the buffer kept per (device, R, S2) -- the next solve_lut of that shape overwrites it in place (a step
+    loop that solves and applies again and again wants exactly that); otherwise the caller gets a copy of its own."""
     torch = _torch()
     dev_ = tables.buf.device
     tab = device_logtab(dev_.index)
     if tab is None:
-        lut, shape, _, _ = solve(tables, minscore=minscore)
-        return lut, shape
+        return _host_fed_lut(tables, minscore, check)
     R, S2 = tables.R, tables.S2
     lib = N.load()
     key = (dev_.index, R, S2)
@@ -699,9 +700,27 @@ def solve_lut(tables, minscore=MINSCORE, check=True):
         try:
             ctx.status()
         except N.MeanqNeedsHost:
-            lut, shape, _, _ = solve(tables, minscore=minscore)
-            return lut, shape
-    return lut, (R, NQ, S2, N.APPLY_FAST)
+            return _host_fed_lut(tables, minscore, True)
+        except N.LutNeedsCheckedApply:
+            # k3_fill_full_lut found a value that does not fit int8 or a (cycle, context) sum that can leave 0..255: the
+            # canonical int16 part of the blob is complete, the table-driven part is not usable -- the checked kernel
+            # serves this LUT (apply() refuses the layouts that need the table-driven part and the caller falls back to
+            # one read per row, as with a host-built blob whose flags are set)
+            return (lut if reuse else lut.clone()), (R, NQ, S2, N.APPLY_CHECKED)
+    return (lut if reuse else lut.clone()), (R, NQ, S2, N.APPLY_FAST)
+
+
+def _host_fed_lut(tables, minscore, check):
+    """solve() for solve_lut's callers: (lut, shape), the shape's mode taken from the status word the LUT builder
+    (k3_fill_full_lut) sets when the table-driven part cannot serve the LUT -- read here when `check`, else left for the
+    caller's context().status() as in solve_lut."""
+    lut, shape, _, _ = solve(tables, minscore=minscore)
+    if check:
+        try:
+            context(tables.buf.device.index).status()
+        except N.LutNeedsCheckedApply:
+            shape = shape[:3] + (N.APPLY_CHECKED,)
+    return lut, shape
 
 
 def solve(tables, want_dq=False, minscore=MINSCORE):

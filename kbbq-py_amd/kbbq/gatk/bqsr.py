@@ -232,8 +232,12 @@ def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxsc
         # 4-bit sequence planes between K6 and K1 (one byte per base less to write and to read) unless a forward read
         # carries a letter outside ACGTN, the reads are longer than K1's packed form takes, or K1's tables for this
         # minscore do not fit beside it (both refusals come before anything is counted)
+        # (tallied into tables of its own and added on success only: a refusal that arrives after the launch must not
+        #  leave counts behind that the character-plane pass would add again)
         try:
-            dev.accumulate(canonical(S <= dev.PACKED_READS), tables, minscore, dinuc_minscore=6)
+            part = dev.Tables(max(R, 1), 2 * S)
+            dev.accumulate(canonical(S <= dev.PACKED_READS), part, minscore, dinuc_minscore=6)
+            tables.add(part)
         except N.LutNeedsCheckedApply:
             dev.accumulate(canonical(False), tables, minscore, dinuc_minscore=6)
     benchmark._on_all_ranks(shard if m else (lambda: None), lo)
