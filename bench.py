@@ -251,10 +251,40 @@ class Resident:
         self.out = torch.empty_like(batch.qual)
         self.tables = dev.Tables(R, 2 * S)
 
-    def free_rows(self):
+    def free_rows(self, check_reads=1_000_000):
+        """Drop the input-order rows, keeping the character rows behind the first rows of the resident batch: after the
+        timed region the output of those rows is checked against the persistent apply kernel on one read per row
+        (`verify`) -- the layout the headline is measured on, against the kernel and layout it does not use."""
+        torch, dev, b = self.torch, self.dev, self.batch
+        self.check = None
+        if b is not self.rows and check_reads:
+            two = isinstance(b, dev.PairBatch)
+            nrows = min(b.n, check_reads // 2 if two else check_reads)
+            src = b.perm[:nrows] if b.perm is not None else torch.arange(nrows, device=b.seq.device)
+            reads = torch.stack([2 * src, 2 * src + 1], 1).flatten() if two else src
+            reads = reads[reads < self.rows.n]
+            chk = dev.ReadBatch(int(reads.numel()), self.rows.pitch, with_corrected=False)
+            chk.seq.copy_(self.rows.seq[reads]); chk.qual.copy_(self.rows.qual[reads]); chk.meta.copy_(self.rows.meta[reads])
+            self.check = (chk, nrows, two)
         self.rows = None
-        self.torch.cuda.synchronize()
-        self.torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    def verify(self):
+        """True when the new qualities of the checked rows (self.out, as the last step left it) equal what the persistent
+        kernel makes of the same reads on character rows with the LUT of the same tables; None when nothing was kept."""
+        if self.check is None:
+            return None
+        torch, dev = self.torch, self.dev
+        chk, nrows, two = self.check
+        lut, shape = dev.solve_lut(self.tables)
+        want = dev.apply(chk, lut, shape)
+        got, S = self.out[:nrows], self.S
+        if two:
+            ok = torch.equal(got[:, :S], want[0::2, :S]) and torch.equal(got[:want.shape[0] // 2, S + 1:2 * S + 1], want[1::2, :S])
+        else:
+            ok = torch.equal(got[:, :S], want[:, :S])
+        return bool(ok) and bool((want[:, :S] != chk.qual[:, :S]).any().item())      # and the kernel did change qualities
 
 
 def timed_steps(torch, dist, use_dist, dev, parallel, res, steps, warmup, rehearse, restore_order=False):
@@ -313,6 +343,7 @@ def extra_config3(torch, dev, parallel, n, steps, warmup):
     res = Resident(dev, torch, 0, n, 1, 8, 'packed')
     res.free_rows()
     elapsed, k1, k2, n1, n2, _ = timed_steps(torch, None, False, dev, parallel, res, steps, warmup, False)
+    verified = res.verify()
     elapsed_r, k1r, k2r, _, n2r, _ = timed_steps(torch, None, False, dev, parallel, res, steps, 1, False, restore_order=True)
     bases = n * READ_LEN
     step_ms, step_r_ms = elapsed / steps * 1e3, elapsed_r / steps * 1e3
@@ -325,7 +356,7 @@ def extra_config3(torch, dev, parallel, n, steps, warmup):
         torch.cuda.synchronize()
         unpack_ms = a.elapsed_time(b)
         del rows
-    return {'workload': '%d synthetic 2x150 bp reads, 8 read groups (BASELINE config 3)' % n, 'layout': res.name,
+    return {'workload': '%d synthetic 2x150 bp reads, 8 read groups (BASELINE config 3)' % n, 'layout': res.name, 'verified': verified,
             'value': bases * steps / elapsed, 'unit': 'bases/s', 'ms_per_step': step_ms,
             'k1_accumulate': kernel_entry(k1, n1, bases), 'k2_apply': kernel_entry(k2, n2, bases),
             'host_solve_and_sync_ms': step_ms - k1 - k2,
@@ -342,7 +373,7 @@ def extra_layout(torch, dev, parallel, n, steps, warmup, layout, single_end=Fals
     elapsed, k1, k2, n1, n2, _ = timed_steps(torch, None, False, dev, parallel, res, steps, warmup, False)
     bases = n * READ_LEN
     return {'workload': ('%d synthetic single-end 150 bp reads, 1 read group' if single_end else '%d synthetic 2x150 bp reads, 1 read group') % n,
-            'layout': res.name,
+            'layout': res.name, 'verified': res.verify(),
             'value': bases * steps / elapsed, 'unit': 'bases/s', 'ms_per_step': elapsed / steps * 1e3,
             'k1_accumulate': kernel_entry(k1, n1, bases), 'k2_apply': kernel_entry(k2, n2, bases)}
 
@@ -350,7 +381,7 @@ def extra_layout(torch, dev, parallel, n, steps, warmup, layout, single_end=Fals
 def extra_mixed_lengths(torch, dev, n, steps, warmup, lo=36, hi=300):
     """BASELINE config 5, the recalibration half, device-resident: n reads of lo..hi bases in the length bands the file
     path cuts (kbbq/fastx.py BAND_CLASSES: every band at its own pitch), each band in the layout the product picks for
-    it (kbbq.recalibrate._lay_out: 4-bit planes, one read per row), count tables of 2 x hi columns.
+    it (kbbq.fastx._fill_bands: 4-bit planes, one read per row), count tables of 2 x hi columns.
     A step = K1 over every band (into a band's own tables, added to the file's: recalibrate._tally_local) -> solve ->
     K2 over every band."""
     from kbbq import fastx, recalibrate
@@ -367,12 +398,11 @@ def extra_mixed_lengths(torch, dev, n, steps, warmup, lo=36, hi=300):
     for k, (blo, bhi) in enumerate(bands):
         batch = dev.ReadBatch.synthetic(k * per, per, per * len(bands), seed=1, len_lo=blo, len_hi=bhi)
         st = dev.meta_stats(batch)
-        laid = recalibrate._lay_out(batch, 1, st['longest'], hi)
-        rows = laid if laid is not None else batch
+        rows = dev.lay_out(batch, 1, st['longest'], packed=st['longest'] <= dev.PACKED_READS, pairs=None if st['longest'] == hi else False, stats=st)
         bases += int(batch.lengths_host().sum())
         padded += rows.n * rows.pitch
         items.append({'rows': rows, 'S': st['longest'], 'Smin': st['shortest'], 'out': torch.empty_like(rows.qual)})
-        del batch, laid
+        del batch
     torch.cuda.empty_cache()
     ctx = dev.context()
 
@@ -547,9 +577,11 @@ def extra_file_path(torch, dev, n=8_000_000):
             if os.path.exists(p):
                 os.remove(p)
     bases = n * READ_LEN
+    bands = list(recalibrate.LAST_RUN.get('bands', []))
     return {'workload': '%d synthetic 2x150 bp reads as two FASTQ files (%.1f GB each) -> recalibrated FASTQ file (%.1f GB), '
                         'in-process, device warm' % (n, n * 318 / 1e9, size / 1e9),
-            'value': bases / wall, 'unit': 'bases/s', 'wall_s': wall, 'stages_s': stages,
+            'value': bases / wall, 'unit': 'bases/s', 'wall_s': wall, 'stages_s': stages, 'bands': bands,
+            'h2d_bytes_per_base': sum(b['h2d_bytes'] for b in bands) / bases if bands else None,
             'input_written_in_s': write_s}
 
 
@@ -573,6 +605,12 @@ def build_extra(torch, dev, parallel, args, headline_layout):
         extra[key]['took_s'] = round(time.perf_counter() - t0, 2)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+    src = extra.get('layout_reads')
+    if src and 'error' not in src:
+        extra['from_input_order_rows'] = dict(src, note='what kbbq.recalibrate does for rows as a caller holds them (one character row per read, '
+                                                        'input order, on the device): K1 and K2 run on those rows as they are, no layout pass, no '
+                                                        'unpack -- a device pass into the mate-pair / 4-bit layout costs more than it saves for ONE '
+                                                        'accumulate + apply; the file path never has such rows: its packer writes the layout of the headline')
     return extra
 
 
@@ -635,6 +673,7 @@ def run_rank(args):
     elapsed = float(t.item())
     ranks_seen = dist.get_world_size() if use_dist else 1
     backend = dist.get_backend() if use_dist else None
+    verified = res.verify()
     layout_name = res.name
     layout_pass_ms = res.layout_ms.get('lay_out')
     layout_key = res.batch.layout_key() if hasattr(res.batch, 'layout_key') else ('reads' if args.layout == 'reads' else 'pairs')
@@ -650,6 +689,9 @@ def run_rank(args):
         k1 = kernel_entry(k1_avg, k1_n, bases_per_rank)
         k2 = kernel_entry(k2_avg, k2_n, bases_per_rank)
         dom, domk = ('k1_accumulate', k1) if k1_avg >= k2_avg else ('k2_apply', k2)
+        # bytes the resident layout itself holds per base (4-bit planes: half a byte per sequence base; padding not counted)
+        nibs = 'nib' in layout_key
+        layout_bytes = {'k1_accumulate': 2.0 if nibs else 3.0, 'k2_apply': 2.5 if nibs else 3.0}
         per_base = pmc_traffic(layout_key, dom)
         for name, k in (('k1_accumulate', k1), ('k2_apply', k2)):
             pb = pmc_traffic(layout_key, name)
@@ -664,15 +706,26 @@ def run_rank(args):
             'config': {'workload': '%d synthetic 2x150 bp reads per GPU, %d read group(s), Q0-41, '
                                    'accumulate + solve + apply end-to-end, device-resident' % (n, R),
                        'reads_per_gpu': n, 'read_len': S, 'read_groups': R, 'layout': layout_name,
+                       'layout_written_by': 'in the product: the FASTQ packer itself (kbbq_fastq_fill_rows fills these rows into the '
+                                            'page-locked upload slabs, no device pass); here: synthetic reads generated on the device as '
+                                            'character rows and laid out before the timed region by the pass that writes the same bytes '
+                                            '(tests/test_gpu_layouts.py::test_the_packer_writes_the_rows_the_layout_pass_writes)',
                        'layout_pass_ms_before_the_timed_region': layout_pass_ms,
                        'layout_inclusive_bases_per_s': (None if layout_pass_ms is None else
                                                         bases_per_rank * world / ((step_ms + layout_pass_ms) * 1e-3)),
                        'parallelism': 'reads sharded x%d, 1 allreduce of count tables' % world},
+            'verified': verified,
+            'verified_how': 'after the timed region: the new qualities of the first 1 M reads of the resident batch (in the '
+                            "headline's layout, as the last step left them) == the persistent apply kernel on the same reads as "
+                            'character rows, one read per row',
             'ranks_seen': ranks_seen, 'backend': backend,
             'allreduce_ms_per_step': ar_ms,
             'per_rank_ms_per_step': {'min': min(per_rank_ms), 'max': max(per_rank_ms), 'ranks': per_rank_ms},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': domk['GB/s'], 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': domk['frac'],
+                         'bytes_per_base_algorithmic': 3,
+                         'bytes_per_base_of_the_layout': layout_bytes[dom], 'achieved_on_layout_bytes': gbs(layout_bytes[dom] * bases_per_rank, domk['avg_ms']),
+                         'frac_on_layout_bytes': gbs(layout_bytes[dom] * bases_per_rank, domk['avg_ms']) / HBM_PEAK_GBS,
                          'traffic': None if per_base is None else per_base * bases_per_rank,
                          'traffic_source': 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate '
                                            'passes, 20 M reads, scaled per base; null when taken on another kernel source)',

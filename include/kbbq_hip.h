@@ -482,6 +482,27 @@ int         kbbq_fastq_fill(const kbbq_fastq* a, const kbbq_fastq* b, int infer_
 /* the same for reads [first, first + n) -> rows [0, n): one rank's shard; read-group ids are those of the scan */
 int kbbq_fastq_fill_range(const kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t first, int64_t n, int pitch,
                           uint8_t* seq, uint8_t* cseq, uint8_t* qual, uint32_t* meta);
+/* ---- the packer writes the device layout itself (no kbbq_lay_out_dev pass, 2 B/base over PCIe instead of 3) ----
+ * Replaces, like kbbq_fastq_fill_range, the pysam iteration + per-read arrays of recalibrate.py:56-57,89-101,141-148, but
+ * hands the kernels the layout they are measured on: mate-pair rows / 4-bit sequence planes / rows gathered by
+ * read-group segment (KBBQ_ROWS_* above), byte for byte what kbbq_lay_out_dev would make of kbbq_fastq_fill_range's rows.
+ * kbbq_fastq_meta: the sidecar words of reads [first, first + n) (read-group ids of the scan) and the statistics of
+ * kbbq_meta_stats_dev over them (stats8, same slots) -- what decides which layout the reads qualify for.
+ * kbbq_group_rows_host: the stable counting sort of kbbq_group_rows_dev on the host (perm, seg).
+ * kbbq_fastq_fill_rows: destination rows [row_lo, row_lo + nrows) of that band into plane rows 0 .. nrows - 1 (seq / cseq:
+ * row stride pitch / 2 with KBBQ_ROWS_NIBBLES); KBBQ_ROWS_PAIRS: pitch = kbbq_pair_pitch(S2) (the argument is ignored) and
+ * every read has length S2 / 2; perm (may be NULL): destination row r holds source row perm[r].  *foreign is set to 1 when
+ * a seq / cseq letter outside ACGTN met the nibble packing: repeat the band without KBBQ_ROWS_NIBBLES (character planes
+ * carry the reference's TypeError rule, compare_reads.py:224,292).
+ * kbbq_fastq_format_rows: kbbq_fastq_format reading the new qualities out of the layout K2 wrote them in (mate-pair rows:
+ * read first + i at row i / 2, byte offset (i & 1) * (S2 / 2 + 1)) -- recalibrate.py:153-156 without an unpack pass.  */
+int         kbbq_fastq_meta(const kbbq_fastq* a, int infer_rg, int64_t first, int64_t n, uint32_t* meta, int32_t* stats8);
+int         kbbq_group_rows_host(const uint32_t* meta, int64_t nrows, int pairs, int R, int64_t* perm, int64_t* seg);
+int         kbbq_fastq_fill_rows(const kbbq_fastq* a, const kbbq_fastq* b, int64_t first, int64_t n, const uint32_t* meta,
+                                 int flags, int S2, int pitch, const int64_t* perm, int64_t row_lo, int64_t nrows,
+                                 uint8_t* seq, uint8_t* cseq, uint8_t* qual, uint32_t* dmeta, int* foreign);
+int64_t     kbbq_fastq_format_rows(const kbbq_fastq* a, int64_t first, int64_t n, int flags, int S2, int pitch,
+                                   const uint8_t* newqual, char* out, int64_t cap);
 /* benchmark.py:102-124: idx[i] = the alignment whose QNAME + "/1"|"/2" equals the name of FASTQ read i up to its
  * first '_' (the last such alignment), -1 if none.                                                   */
 int         kbbq_sam_match_fastq(const kbbq_sam* f, const kbbq_fastq* fq, int64_t* idx);

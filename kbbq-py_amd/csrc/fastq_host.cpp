@@ -30,6 +30,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 extern "C" const char* kbbq_last_error(void);
 int kbbq_set_error_(int code, const char* msg);      // defined in kbbq_hip.hip
@@ -307,6 +310,51 @@ const char* kbbq_fastq_rg_name(const kbbq_fastq* f, int i)
 
 } // extern "C"
 
+// 16 characters -> 8 bytes of code nibbles in the layout of KBBQ_ROWS_NIBBLES (word w of a chunk holds bases 8w..8w+3 in
+// the low nibbles of its bytes and 8w+4..8w+7 in the high nibbles; A0 T1 G2 C3, N 4: compare_reads.py:199).  Returns
+// non-zero when a character is none of ACGTN (such a batch keeps character planes: the reference's TypeError rule).
+static inline unsigned pack16_scalar(const uint8_t* c, uint8_t* out)
+{
+    static const uint8_t code_of[8] = {0, 3, 1, 2, 4, 4, 4, 4};              // index (ch >> 1) & 7: A C T G . . . N
+    static const uint8_t expect[8] = {'A', 'C', 'T', 'G', 0, 0, 0, 'N'};
+    uint8_t k[16]; unsigned bad = 0;
+    for (int i = 0; i < 16; ++i) { const unsigned h = (c[i] >> 1) & 7u; k[i] = code_of[h]; bad |= (unsigned)(expect[h] ^ c[i]); }
+    for (int w = 0; w < 2; ++w)
+        for (int b = 0; b < 4; ++b) out[4 * w + b] = (uint8_t)(k[8 * w + b] | (k[8 * w + 4 + b] << 4));
+    return bad;
+}
+
+#if defined(__x86_64__)
+__attribute__((target("ssse3"))) static inline unsigned pack16_ssse3(const uint8_t* c, uint8_t* out)
+{
+    const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(c));
+    const __m128i h = _mm_and_si128(_mm_srli_epi16(v, 1), _mm_set1_epi8(7));
+    const __m128i codes = _mm_setr_epi8(0, 3, 1, 2, 4, 4, 4, 4, 0, 3, 1, 2, 4, 4, 4, 4);
+    const __m128i expect = _mm_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 'N', 'A', 'C', 'T', 'G', 0, 0, 0, 'N');
+    const __m128i code = _mm_shuffle_epi8(codes, h);
+    const unsigned ok = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_shuffle_epi8(expect, h), v));
+    // dword d of `code` = the codes of bases 4d .. 4d+3: out word 0 = d0 | d1 << 4, out word 1 = d2 | d3 << 4
+    const __m128i o = _mm_or_si128(code, _mm_slli_epi16(_mm_srli_si128(code, 4), 4));      // codes <= 4: no carry between bytes
+    const uint32_t w0 = (uint32_t)_mm_cvtsi128_si32(o), w1 = (uint32_t)_mm_cvtsi128_si32(_mm_srli_si128(o, 8));
+    memcpy(out, &w0, 4); memcpy(out + 4, &w1, 4);
+    return ok ^ 0xFFFFu;
+}
+static const bool g_ssse3 = __builtin_cpu_supports("ssse3");
+#else
+static const bool g_ssse3 = false;
+#endif
+
+// a row of `pitch` characters (pitch a multiple of 16) -> pitch / 2 bytes of nibbles
+static inline unsigned pack_row(const uint8_t* chars, int pitch, uint8_t* out)
+{
+    unsigned bad = 0;
+#if defined(__x86_64__)
+    if (g_ssse3) { for (int j = 0; j < pitch; j += 16) bad |= pack16_ssse3(chars + j, out + (j >> 1)); return bad; }
+#endif
+    for (int j = 0; j < pitch; j += 16) bad |= pack16_scalar(chars + j, out + (j >> 1));
+    return bad;
+}
+
 // compare_reads.py:304-306: the first '_' field ends with "/2"
 static inline bool name_second(const char* s, int n)
 {
@@ -579,25 +627,219 @@ int kbbq_fastq_fill_range(const kbbq_fastq* a, const kbbq_fastq* b, int infer_rg
     return KBBQ_OK;
 }
 
+// ---- the packer writes the device layout itself --------------------------------------------
+// The kernels run fastest on mate-pair rows with 4-bit sequence planes, rows gathered by read-group segment
+// (include/kbbq_hip.h KBBQ_ROWS_*).  Rounds 1-2 uploaded one character row per read and converted on the device
+// (k7_lay_out before K1, an unpack pass after K2); here the host writes the destination rows straight from the FASTQ
+// text into the page-locked slabs -- same bytes as kbbq_lay_out_dev produces, 2 B/base over PCIe instead of 3, no pass.
+
+// Sidecar words (len | read group << 16 | second << 31; compare_reads.py:304-318) of reads [first, first + n) and the
+// statistics the layout decision needs -- the host twin of kbbq_meta_stats_dev: stats8[0] shortest non-empty read
+// (0x7FFFFFFF: none), [1] longest, [2] largest read-group id, [3] violations of "uniform first / second pairs of one
+// length and read group", [4] empty reads, [5] violations of the KBBQ_ROWS_TWINS preconditions.  Read-group ids are
+// those of the scan (kbbq_fastq_scan / kbbq_fastq_set_rg_names).
+int kbbq_fastq_meta(const kbbq_fastq* a, int infer_rg, int64_t first, int64_t n, uint32_t* meta, int32_t* stats8)
+{
+    if (!a || (n > 0 && !meta) || !stats8) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_meta: NULL argument");
+    if (first < 0 || n < 0 || first + n > (int64_t)a->h0.size()) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_meta: range out of bounds");
+    std::unordered_map<std::string, int> rgmap;
+    for (size_t i = 0; i < a->rg_names.size(); ++i) rgmap.emplace(a->rg_names[i], (int)i);
+    std::atomic<int> bad(0);
+    parallel_for(n, nthreads_for((size_t)n * 256), [&](int64_t lo, int64_t hi) {
+        const char* last = nullptr; int lastlen = -1; uint32_t lastid = 0;       // neighbours mostly share a read group
+        for (int64_t row = lo; row < hi; ++row) {
+            const int64_t i = first + row;
+            const char* nm = (const char*)a->buf + a->h0[i]; const int nl = (int)a->hlen[i];
+            uint32_t rgid = 0;
+            if (infer_rg) {
+                const char* rg; int rl;
+                if (name_rg(nm, nl, &rg, &rl)) { bad = 2; meta[row] = 0; continue; }
+                if (rl == lastlen && memcmp(rg, last, (size_t)rl) == 0) rgid = lastid;
+                else {
+                    auto it = rgmap.find(std::string(rg, (size_t)rl));
+                    if (it == rgmap.end()) { bad = 2; meta[row] = 0; continue; }
+                    rgid = (uint32_t)it->second; last = rg; lastlen = rl; lastid = rgid;
+                }
+            }
+            meta[row] = a->slen[i] | (rgid << 16) | ((uint32_t)name_second(nm, nl) << 31);
+        }
+    });
+    if (bad.load()) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_meta: input does not match the scan (call kbbq_fastq_scan first)");
+    // statistics (k7_meta_stats, kbbq_layout_kernels.h), pair by pair
+    int mn = 0x7FFFFFFF, mx = 0, rgmax = 0; int64_t viol = 0, empty = 0, tviol = 0;
+    const uint32_t len0 = n > 0 ? (meta[0] & 0xFFFFu) : 0u;
+    const int64_t npairs = (n + 1) >> 1;
+    for (int64_t pr = 0; pr < npairs; ++pr) {
+        const bool has2 = 2 * pr + 1 < n;
+        const uint32_t m[2] = {meta[2 * pr], has2 ? meta[2 * pr + 1] : 0xFFFFFFFFu};
+        for (int k = 0; k < (has2 ? 2 : 1); ++k) {
+            const int len = (int)(m[k] & 0xFFFFu), rg = (int)((m[k] >> 16) & 0x7FFFu);
+            if (len) mn = std::min(mn, len); else ++empty;
+            mx = std::max(mx, len); rgmax = std::max(rgmax, rg);
+            if ((m[k] & 0xFFFFu) != len0) { ++viol; ++tviol; }
+            if ((m[k] >> 31) != 0u) ++tviol;
+        }
+        if ((m[0] >> 31) != 0u) ++viol;
+        if (has2 && ((m[1] >> 31) == 0u || ((m[0] ^ m[1]) & 0x7FFF0000u) != 0u)) ++viol;
+        if (!has2) ++viol;
+        if (has2 && ((m[0] ^ m[1]) & 0x7FFF0000u) != 0u) ++tviol;
+    }
+    auto cap = [](int64_t v) { return (int32_t)std::min<int64_t>(v, 0x7FFFFFFF); };
+    stats8[0] = mn; stats8[1] = mx; stats8[2] = rgmax; stats8[3] = cap(viol); stats8[4] = cap(empty); stats8[5] = cap(tviol);
+    stats8[6] = stats8[7] = 0;
+    return KBBQ_OK;
+}
+
+// Stable counting sort of rows by read group on the host -- the twin of kbbq_group_rows_dev: perm[nrows] (row i of
+// the grouped order is row perm[i]) and seg[R + 1].  pairs != 0: a row is a PAIR of reads, its group the first
+// mate's sidecar's.  A sidecar with a read group >= R -> KBBQ_E_RANGE.
+int kbbq_group_rows_host(const uint32_t* meta, int64_t nrows, int pairs, int R, int64_t* perm, int64_t* seg)
+{
+    if (nrows < 0 || R <= 0 || R > 32767 || !seg || (nrows > 0 && (!meta || !perm))) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_group_rows_host: bad argument");
+    const unsigned nt = nthreads_for((size_t)nrows * 64);
+    const int64_t per = (nrows + nt - 1) / std::max(nt, 1u);
+    std::vector<std::vector<int64_t>> cnt(nt, std::vector<int64_t>((size_t)R, 0));
+    std::atomic<int> bad(0);
+    auto key = [&](int64_t i) { return (int)((meta[pairs ? 2 * i : i] >> 16) & 0x7FFFu); };
+    auto over = [&](auto body) {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) {
+            const int64_t lo = std::min<int64_t>(nrows, (int64_t)t * per), hi = std::min<int64_t>(nrows, lo + per);
+            if (nt == 1) body(t, lo, hi); else th.emplace_back([=]() { body(t, lo, hi); });
+        }
+        for (auto& t : th) t.join();
+    };
+    over([&](unsigned t, int64_t lo, int64_t hi) {
+        auto& c = cnt[t];
+        for (int64_t i = lo; i < hi; ++i) { const int k = key(i); if (k >= R) { bad = 1; continue; } ++c[(size_t)k]; }
+    });
+    if (bad.load()) return kbbq_set_error_(KBBQ_E_RANGE, "kbbq_group_rows_host: a row carries a read group >= R");
+    int64_t run = 0;
+    for (int g = 0; g < R; ++g) {
+        seg[g] = run;
+        for (unsigned t = 0; t < nt; ++t) { const int64_t c = cnt[t][(size_t)g]; cnt[t][(size_t)g] = run; run += c; }
+    }
+    seg[R] = nrows;
+    over([&](unsigned t, int64_t lo, int64_t hi) {
+        auto& c = cnt[t];
+        for (int64_t i = lo; i < hi; ++i) perm[c[(size_t)key(i)]++] = i;
+    });
+    return KBBQ_OK;
+}
+
+// Destination rows [row_lo, row_lo + nrows) of reads [first, first + n) in the layout `flags` describes, written into
+// plane rows 0 .. nrows - 1 (seq / cseq: row stride pitch / 2 with KBBQ_ROWS_NIBBLES; cseq and b may be NULL):
+//   KBBQ_ROWS_PAIRS  row r = reads 2s, 2s + 1 as [mate 1: S][separator][mate 2: S][padding], S = S2 / 2, pitch =
+//                    kbbq_pair_pitch(S2) (the `pitch` argument is ignored), sidecar (2S + 1) | read group << 16; every
+//                    read must have length S (the caller checked kbbq_fastq_meta's statistics); an odd n leaves the last
+//                    row's second half as padding (KBBQ_ROWS_TWINS input);
+//   otherwise        row r = read s at the caller's `pitch`, sidecar = the read's;
+//   s = perm[r] (rows gathered by read-group segment: kbbq_group_rows_host) or r when perm is NULL.
+// meta: the sidecars of kbbq_fastq_meta for the same [first, first + n).  *foreign is set to 1 (never cleared) when
+// nibble packing met a seq / cseq character outside ACGTN: the caller then repeats the band with character planes.
+int kbbq_fastq_fill_rows(const kbbq_fastq* a, const kbbq_fastq* b, int64_t first, int64_t n, const uint32_t* meta, int flags,
+                         int S2, int pitch, const int64_t* perm, int64_t row_lo, int64_t nrows,
+                         uint8_t* seq, uint8_t* cseq, uint8_t* qual, uint32_t* dmeta, int* foreign)
+{
+    if (!a || (nrows > 0 && (!seq || !qual || !dmeta || !meta || (b && !cseq)))) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_fill_rows: NULL argument");
+    if (first < 0 || n < 0 || first + n > (int64_t)a->h0.size() || (b && first + n > (int64_t)b->h0.size()))
+        return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_fill_rows: range out of bounds");
+    if (flags & ~(KBBQ_ROWS_PAIRS | KBBQ_ROWS_NIBBLES | KBBQ_ROWS_TWINS)) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_fill_rows: unknown layout flags");
+    const bool pairs = (flags & KBBQ_ROWS_PAIRS) != 0, nib = (flags & KBBQ_ROWS_NIBBLES) != 0;
+    const int S = S2 / 2;
+    if (pairs) {
+        if (S2 <= 0 || (S2 & 1) || S2 > 65534) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_fill_rows: S2 must be positive and even");
+        pitch = (S2 + 1 + 15) & ~15;
+    }
+    if (pitch <= 0 || (pitch & 15)) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_fill_rows: pitch must be a positive multiple of 16");
+    const int64_t total = pairs ? (n + 1) / 2 : n;
+    if (row_lo < 0 || nrows < 0 || row_lo + nrows > total) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_fill_rows: rows out of bounds");
+    const size_t sp = nib ? (size_t)pitch / 2 : (size_t)pitch;
+    std::atomic<int> bad(0); std::atomic<unsigned> odd(0);
+    parallel_for(nrows, nthreads_for((size_t)nrows * (size_t)pitch * 3), [&](int64_t lo, int64_t hi) {
+        std::vector<uint8_t> tmp(nib ? (size_t)pitch : 0);
+        unsigned foreign_here = 0;
+        for (int64_t row = lo; row < hi; ++row) {
+            const int64_t s = perm ? perm[row_lo + row] : row_lo + row;
+            if (s < 0 || s >= total) { bad = 3; continue; }
+            uint8_t* q = qual + (size_t)row * pitch;
+            uint8_t* planes[2] = {seq + (size_t)row * sp, b ? cseq + (size_t)row * sp : nullptr};
+            const kbbq_fastq* src[2] = {a, b};
+            if (pairs) {
+                const int64_t i1 = first + 2 * s; const bool lone = 2 * s + 1 >= n; const int64_t i2 = lone ? i1 : i1 + 1;
+                if ((int)a->slen[i1] != S || (int)a->slen[i2] != S || (b && ((int)b->slen[i1] != S || (int)b->slen[i2] != S))) { bad = 1; continue; }
+                memcpy(q, a->buf + a->q0[i1], (size_t)S);
+                if (lone) memset(q + S, 0, (size_t)(pitch - S));
+                else { q[S] = 0; memcpy(q + S + 1, a->buf + a->q0[i2], (size_t)S); memset(q + 2 * S + 1, 0, (size_t)(pitch - 2 * S - 1)); }
+                for (int pl = 0; pl < 2; ++pl) {
+                    if (!planes[pl]) continue;
+                    uint8_t* c = nib ? tmp.data() : planes[pl];
+                    memcpy(c, src[pl]->buf + src[pl]->s0[i1], (size_t)S);
+                    if (lone) memset(c + S, 'N', (size_t)(pitch - S));
+                    else { c[S] = 'N'; memcpy(c + S + 1, src[pl]->buf + src[pl]->s0[i2], (size_t)S); memset(c + 2 * S + 1, 'N', (size_t)(pitch - 2 * S - 1)); }
+                    if (nib) foreign_here |= pack_row(c, pitch, planes[pl]);
+                }
+                dmeta[row] = (uint32_t)(2 * S + 1) | (meta[2 * s] & 0x7FFF0000u);
+            } else {
+                const int64_t i = first + s;
+                const uint32_t L = a->slen[i];
+                if ((int)L > pitch || (b && b->slen[i] != L)) { bad = 1; continue; }
+                memcpy(q, a->buf + a->q0[i], L); memset(q + L, 0, (size_t)pitch - L);
+                for (int pl = 0; pl < 2; ++pl) {
+                    if (!planes[pl]) continue;
+                    uint8_t* c = nib ? tmp.data() : planes[pl];
+                    memcpy(c, src[pl]->buf + src[pl]->s0[i], L); memset(c + L, 'N', (size_t)pitch - L);
+                    if (nib) foreign_here |= pack_row(c, pitch, planes[pl]);
+                }
+                dmeta[row] = meta[s];
+            }
+        }
+        if (foreign_here) odd = 1;
+    });
+    if (bad.load()) return kbbq_set_error_(KBBQ_E_ARG, bad.load() == 3 ? "kbbq_fastq_fill_rows: perm holds a row out of range"
+                                                      : "kbbq_fastq_fill_rows: a read does not fit the layout (lengths differ from what the statistics said)");
+    if (odd.load() && foreign) *foreign = 1;
+    return KBBQ_OK;
+}
+
 // recalibrate.py:153-156 for reads [first, first + n): "@name\nsequence\n+\nquality\n" with the
 // quality characters taken from rows [0, n) of `newqual` (pitch bytes each).  Returns the number of
 // bytes written into out (capacity cap) or -needed when cap is too small.
 int64_t kbbq_fastq_format(const kbbq_fastq* a, int64_t first, int64_t n, int pitch, const uint8_t* newqual,
                           char* out, int64_t cap)
 {
+    return kbbq_fastq_format_rows(a, first, n, 0, 0, pitch, newqual, out, cap);
+}
+
+// The same with the new qualities still in the layout K2 wrote them in: flags & KBBQ_ROWS_PAIRS -> read first + i sits in
+// row i / 2 of `newqual` at byte offset (i & 1) * (S2 / 2 + 1), row stride kbbq_pair_pitch(S2) (`first` is the first
+// mate of newqual's row 0; `pitch` is ignored) -- the writer reads mate-pair rows as they are, no unpack pass.
+int64_t kbbq_fastq_format_rows(const kbbq_fastq* a, int64_t first, int64_t n, int flags, int S2, int pitch,
+                               const uint8_t* newqual, char* out, int64_t cap)
+{
     if (!a || first < 0 || n < 0 || first + n > (int64_t)a->h0.size()) { kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_format: bad range"); return 0; }
+    const bool pairs = (flags & KBBQ_ROWS_PAIRS) != 0;
+    const int S = S2 / 2;
+    if (pairs) {
+        if (S2 <= 0 || (S2 & 1)) { kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_format_rows: S2 must be positive and even"); return 0; }
+        pitch = (S2 + 1 + 15) & ~15;
+    }
     std::vector<int64_t> off((size_t)n + 1, 0);
     for (int64_t i = 0; i < n; ++i) off[(size_t)i + 1] = off[(size_t)i] + 1 + a->hlen[first + i] + 1 + a->slen[first + i] + 3 + a->slen[first + i] + 1;
     if (off[(size_t)n] > cap) return -off[(size_t)n];
+    std::atomic<int> bad(0);
     parallel_for(n, nthreads_for((size_t)off[(size_t)n]), [&](int64_t lo, int64_t hi) {
         for (int64_t i = lo; i < hi; ++i) {
             char* p = out + off[(size_t)i];
             const int64_t r = first + i; const uint32_t L = a->slen[r];
+            if (pairs && (int)L != S) { bad = 1; continue; }
+            const uint8_t* nq = pairs ? newqual + (size_t)(i >> 1) * pitch + (size_t)(i & 1) * (size_t)(S + 1) : newqual + (size_t)i * pitch;
             *p++ = '@'; memcpy(p, a->buf + a->h0[r], a->hlen[r]); p += a->hlen[r]; *p++ = '\n';
             memcpy(p, a->buf + a->s0[r], L); p += L; *p++ = '\n'; *p++ = '+'; *p++ = '\n';
-            memcpy(p, newqual + (size_t)i * pitch, L); p += L; *p++ = '\n';
+            memcpy(p, nq, L); p += L; *p++ = '\n';
         }
     });
+    if (bad.load()) { kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_format_rows: a read of a mate-pair row does not have length S2 / 2"); return 0; }
     return off[(size_t)n];
 }
 

@@ -37,11 +37,10 @@ def warm_up(device=0):
     import scipy.special                      # noqa: F401
     with torch.cuda.device(device):
         batch = ReadBatch.synthetic(0, 128, 128, seed=1)
-        pairs = PairBatch.from_reads(batch)
-        tables = Tables(1, 2 * pairs.S)
-        accumulate(pairs, tables)
+        tables = Tables(1, 2 * 150)
+        accumulate(batch, tables)
         lut, shape = solve_lut(tables)            # also proves (once per process) the device's gammaln against the host's
-        pairs.unpack(apply(pairs, lut, shape)).cpu()
+        apply(batch, lut, shape).cpu()
         torch.cuda.synchronize()
     _warm = True
 
@@ -219,6 +218,7 @@ class ReadBatch:
             for e in events.values():
                 e.synchronize()
         release_pinned('ingest')
+        b.h2d_bytes = n * (planes * pitch + 4)
         return b
 
     @classmethod
@@ -387,6 +387,27 @@ def _lay_out_rows(batch, flags, S2, perm, seg):
     return laid
 
 
+def layout_flags(st, n, pitch, packed=True, pairs=None):
+    """The KBBQ_ROWS_* bits of the layout `n` reads qualify for, from their sidecar statistics `st` (meta_stats on the
+    device, fastx.NativeFastq.meta on the host -- the same numbers): two reads to a row for uniform first / second mates
+    -- or single-end neighbours (`twins`; an odd number is fine: the last row's second half stays padding) -- of one
+    length and read group when such rows are narrower than two rows of `pitch`; 4-bit planes when `packed`.  pairs=True
+    insists on two reads to a row (ValueError if the reads do not qualify), pairs=False forbids it."""
+    S_ = st['longest']
+    fits = n % 2 == 0 and S_ > 0
+    twin_fits = S_ > 0 and n >= 2 and st['twin_violations'] == 0
+    twins = False
+    if pairs is None:
+        pairs = fits and st['pair_violations'] == 0 and PairBatch.worthwhile(S_, pitch)
+        if not pairs and twin_fits and PairBatch.worthwhile(S_, pitch):
+            pairs = twins = True
+    elif pairs and not (fits and st['pair_violations'] == 0):
+        if not twin_fits:
+            raise ValueError('reads are not uniform first/second pairs (or single-end neighbours) of one length and read group')
+        twins = True
+    return (N.ROWS_PAIRS if pairs else 0) | (N.ROWS_NIBBLES if packed else 0) | (N.ROWS_TWINS if twins else 0)
+
+
 def lay_out(batch, R, S=None, packed=True, pairs=None, stats=None):
     """The device layout K1 / K2 run fastest on for this input-order ReadBatch, written in ONE pass
     (k7_lay_out): mate-pair rows when the reads are uniform first / second pairs of one length and read group (and
@@ -401,20 +422,8 @@ def lay_out(batch, R, S=None, packed=True, pairs=None, stats=None):
         return batch
     st = stats or meta_stats(batch)
     S_ = st['longest']
-    # two reads to a row: first / second mates, or -- single-end input -- two first-in-pair neighbours (`twins`)
-    # (an odd number of single-end reads is fine: the last row's second half stays padding)
-    fits = batch.n % 2 == 0 and S_ > 0
-    twin_fits = S_ > 0 and batch.n >= 2 and st['twin_violations'] == 0
-    twins = False
-    if pairs is None:
-        pairs = fits and st['pair_violations'] == 0 and PairBatch.worthwhile(S_, batch.pitch)
-        if not pairs and twin_fits and PairBatch.worthwhile(S_, batch.pitch):
-            pairs = twins = True
-    elif pairs and not (fits and st['pair_violations'] == 0):
-        if not twin_fits:
-            raise ValueError('reads are not uniform first/second pairs (or single-end neighbours) of one length and read group')
-        twins = True
-    flags = (N.ROWS_PAIRS if pairs else 0) | (N.ROWS_NIBBLES if packed else 0) | (N.ROWS_TWINS if twins else 0)
+    flags = layout_flags(st, batch.n, batch.pitch, packed, pairs)
+    pairs = bool(flags & N.ROWS_PAIRS)
     perm = seg = None
     if R > 1:
         perm, seg = _group_perm(batch.meta, (batch.n + 1) // 2 if pairs else batch.n, pairs, R)
@@ -429,6 +438,85 @@ def lay_out(batch, R, S=None, packed=True, pairs=None, stats=None):
             if not (flags & ~N.ROWS_NIBBLES) and perm is None:
                 return batch
             laid = _lay_out_rows(batch, flags & ~N.ROWS_NIBBLES, 2 * S_, perm, seg)
+    return laid
+
+
+def laid_from_reader(text, other, infer_rg_flag, first, n, pitch, R, packed=True, pairs=None, slab=1 << 17, device=None):
+    """Reads [first, first + n) of a fastx.NativeFastq (and their corrections from `other`, or None) onto the device IN
+    THE LAYOUT lay_out() would give them -- written by the C++ packer itself (kbbq_fastq_fill_rows): mate-pair rows, 4-bit
+    sequence planes, rows gathered by read-group segment, decided from the sidecar statistics of the text (kbbq_fastq_meta)
+    before a byte is uploaded.  No character rows ever exist, on the host or on the device, and no layout pass runs:
+    2 B/base cross PCIe instead of 3.  Page-locked slabs are filled by all host threads while the copy engine uploads the
+    previous ones, as in ReadBatch.from_reader.  Returns None when no layout applies (plain rows: ReadBatch.from_reader);
+    a letter outside ACGTN repeats the fill with character planes (the reference's TypeError rule lives there)."""
+    torch = _torch()
+    if n == 0:
+        return None
+    meta, st = text.meta(infer_rg_flag, first, n)
+    S_ = st['longest']
+    flags = layout_flags(st, n, pitch, packed, pairs)
+    two = bool(flags & N.ROWS_PAIRS)
+    nrows = (n + 1) // 2 if two else n
+    perm = seg = None
+    if R > 1:
+        if st['max_rg'] >= R:
+            raise ValueError('a row carries read group %d but R = %d' % (st['max_rg'], R))
+        perm, seg = np.empty(nrows, dtype=np.int64), np.empty(R + 1, dtype=np.int64)
+        N.check(N.load().kbbq_group_rows_host(N.ptr(meta), nrows, 1 if two else 0, R, N.ptr(perm), N.ptr(seg)))
+    while True:
+        if not flags and perm is None:
+            return None
+        nib = bool(flags & N.ROWS_NIBBLES)
+        if two:
+            laid = PairBatch(nrows, S_, with_corrected=other is not None, device=device, nib=nib)
+            laid.read_pitch, laid.twins = pitch, bool(flags & N.ROWS_TWINS)
+        else:
+            laid = ReadBatch(n, pitch, with_corrected=other is not None, device=device, nib=nib)
+        dp = laid.pitch
+        sp = dp // 2 if nib else dp
+        nseq = 2 if other is not None else 1
+        step = max(slab // 2 if two else slab, 1)                 # destination rows per slab: the same bytes either way
+        row_bytes = nseq * sp + dp + 4
+        events, foreign = {}, False
+        with torch.cuda.device(laid.seq.device):
+            for k, lo in enumerate(range(0, nrows, step)):
+                m = min(step, nrows - lo)
+                slot = k % 3
+                if slot in events:
+                    events[slot].synchronize()                    # the slab's previous upload has left the buffer
+                buf = pinned('ingest', slot, step * row_bytes)
+                at = [0]
+
+                def view(width, rows=m, cap=step):
+                    v = buf[at[0]:at[0] + rows * width].view(rows, width)
+                    at[0] += cap * width
+                    return v
+                h_seq = view(sp)
+                h_cseq = view(sp) if other is not None else None
+                h_qual = view(dp)
+                h_meta = buf[at[0]:at[0] + 4 * m].view(torch.int32)
+                foreign |= text.fill_rows(other, first, n, meta, flags, 2 * S_, dp, perm, lo, m, h_seq.numpy(),
+                                          None if h_cseq is None else h_cseq.numpy(), h_qual.numpy(), h_meta.numpy().view(np.uint32))
+                if foreign:
+                    break
+                laid.seq[lo:lo + m].copy_(h_seq, non_blocking=True)
+                laid.qual[lo:lo + m].copy_(h_qual, non_blocking=True)
+                if other is not None:
+                    laid.cseq[lo:lo + m].copy_(h_cseq, non_blocking=True)
+                laid.meta[lo:lo + m].copy_(h_meta, non_blocking=True)
+                events[slot] = torch.cuda.Event()
+                events[slot].record()
+            for e in events.values():
+                e.synchronize()
+        release_pinned('ingest')
+        if not foreign:
+            break
+        flags &= ~N.ROWS_NIBBLES                                  # a base outside ACGTN: character planes keep the exact semantics
+    laid.h2d_bytes = nrows * row_bytes                            # what crossed PCIe for this band (the file path's trace reports it)
+    if perm is not None:
+        laid.perm = torch.from_numpy(perm).to(laid.seq.device)
+        laid.seg = torch.from_numpy(seg).to(laid.seq.device)
+        laid.h2d_bytes += perm.nbytes + seg.nbytes
     return laid
 
 

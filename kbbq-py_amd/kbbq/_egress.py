@@ -78,7 +78,8 @@ class Slots:
 
 
 def _slabs(bands, outs, step):
-    """(serial number, band, its device plane of new qualities, first row, rows) for slabs of `step` reads."""
+    """(serial number, band, its device plane of new qualities, first read, reads) for slabs of `step` reads (even, so
+    that a slab of mate-pair rows starts at a first mate)."""
     k = 0
     for band, out in zip(bands, outs):
         for first in range(0, band['n'], step):
@@ -86,18 +87,28 @@ def _slabs(bands, outs, step):
             k += 1
 
 
+def _rows_of(band, first, m):
+    """Rows [r0, r1) of a band's output plane that hold reads [first, first + m) (first even): the band's own layout --
+    two reads to a mate-pair row (recalibrate.apply_band's out_flags), else one read per row."""
+    if band.get('out_flags', 0) & 1:
+        return first // 2, (first + m + 1) // 2
+    return first, first + m
+
+
 def emit_records(text, base, bands, outs, slab=1 << 18, sink=None):
-    """Print the recalibrated records of this rank -- reads base + band['first'] + row of the fastx.NativeFastq `text`,
-    new quality characters in the device planes `outs` (one per band) -- to sys.stdout, rendered by the C++ writer in
-    slabs.  A binary stdout gets the bytes through the three-stage pipeline above (copy off the device into
-    page-locked buffers | rendering into re-used buffers | write(2)); a text-only stdout (StringIO) gets print(),
-    like the reference."""
+    """Print the recalibrated records of this rank -- reads base + band['first'] + i of the fastx.NativeFastq `text`,
+    new quality characters in the device planes `outs` (one per band, in the layout K2 wrote: mate-pair rows are read as
+    they are, kbbq_fastq_format_rows) -- to sys.stdout, rendered by the C++ writer in slabs.  A binary stdout gets the
+    bytes through the three-stage pipeline above (copy off the device into page-locked buffers | rendering into re-used
+    buffers | write(2)); a text-only stdout (StringIO) gets print(), like the reference."""
     sys.stdout.flush()
     raw = sink if sink is not None else getattr(sys.stdout, 'buffer', None)      # sink: a binary file of the caller's
     if raw is None:
         for _, band, out, first, m in _slabs(bands, outs, 1 << 20):
-            newq = out[first:first + m].cpu().numpy()
-            print(text.format_array(base + band['first'] + first, m, newq).tobytes().decode('latin-1'), end='')
+            r0, r1 = _rows_of(band, first, m)
+            newq = out[r0:r1].cpu().numpy()
+            print(text.format_rows_array(base + band['first'] + first, m, newq, band.get('out_flags', 0),
+                                         band.get('out_S2', 0)).tobytes().decode('latin-1'), end='')
         sys.stdout.flush()
         return
     import torch
@@ -113,16 +124,18 @@ def emit_records(text, base, bands, outs, slab=1 << 18, sink=None):
 
     def fetch(item):
         k, band, out, first, m = item
+        r0, r1 = _rows_of(band, first, m)
+        width = out.shape[1]
         with stage('D2H'), torch.cuda.device(out.device):           # a new thread starts on device 0
-            host = staging.get(k, m * band['pitch'])[:m * band['pitch']].view(m, band['pitch'])
-            host.copy_(out[first:first + m], non_blocking=True)
+            host = staging.get(k, (r1 - r0) * width)[:(r1 - r0) * width].view(r1 - r0, width)
+            host.copy_(out[r0:r1], non_blocking=True)
             torch.cuda.current_stream().synchronize()
-        return k, base + band['first'] + first, m, host.numpy()
+        return k, base + band['first'] + first, m, host.numpy(), band.get('out_flags', 0), band.get('out_S2', 0)
 
     def render(item):
-        k, first, m, newq = item
+        k, first, m, newq, flags, S2 = item
         with stage('format'):
-            return text.format_array(first, m, newq, out=lambda nbytes: rendered.get(k, nbytes))
+            return text.format_rows_array(first, m, newq, flags, S2, out=lambda nbytes: rendered.get(k, nbytes))
 
     def write(buf):
         with stage('write'):

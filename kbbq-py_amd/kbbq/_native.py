@@ -127,6 +127,10 @@ PROTOTYPES = {
     'kbbq_fastq_fill': (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     'kbbq_fastq_fill_range': (_i, [_vp, _vp, _i, _i64, _i64, _i, _vp, _vp, _vp, _vp]),
     'kbbq_fastq_format': (_i64, [_vp, _i64, _i64, _i, _vp, _vp, _i64]),
+    'kbbq_fastq_meta': (_i, [_vp, _i, _i64, _i64, _vp, _vp]),
+    'kbbq_group_rows_host': (_i, [_vp, _i64, _i, _i, _vp, _vp]),
+    'kbbq_fastq_fill_rows': (_i, [_vp, _vp, _i64, _i64, _vp, _i, _i, _i, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _c.POINTER(_i)]),
+    'kbbq_fastq_format_rows': (_i64, [_vp, _i64, _i64, _i, _i, _i, _vp, _vp, _i64]),
     'kbbq_synth_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _u64,
                             _i, _i, _i, _i, _i, _vp]),
     'kbbq_ctx_timing': (_i, [_vp, _i]),

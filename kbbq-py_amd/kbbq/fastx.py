@@ -345,6 +345,45 @@ class NativeFastq:
                                                  1 if infer_rg_flag else 0, first - self.first, n, pitch, _N.ptr(seq),
                                                  _N.ptr(cseq), _N.ptr(qual), _N.ptr(meta)))
 
+    def meta(self, infer_rg_flag, first=None, n=None):
+        """(sidecar words uint32 [n], statistics) of reads [first, first + n): kbbq_fastq_meta -- the host twin of
+        _device.meta_stats, computed from the text before anything is uploaded."""
+        first = self.first if first is None else first
+        n = self.first + self.n - first if n is None else n
+        meta = np.empty(max(n, 1), dtype=np.uint32)
+        st = np.zeros(8, dtype=np.int32)
+        _N.check(_N.load().kbbq_fastq_meta(self._h, 1 if infer_rg_flag else 0, first - self.first, n, _N.ptr(meta), _N.ptr(st)))
+        return meta[:n], {'shortest': int(st[0]) if st[0] != 0x7FFFFFFF else 0, 'longest': int(st[1]), 'max_rg': int(st[2]),
+                          'pair_violations': int(st[3]), 'empty': int(st[4]), 'twin_violations': int(st[5])}
+
+    def fill_rows(self, other, first, n, meta, flags, S2, pitch, perm, row_lo, nrows, seq, cseq, qual, dmeta):
+        """Destination rows [row_lo, row_lo + nrows) of reads [first, first + n) in the layout `flags` (the _native.ROWS_*
+        bits) straight from the text (kbbq_fastq_fill_rows).  Returns True when a letter outside ACGTN met the nibble
+        packing (the band then needs character planes)."""
+        if other is not None and other.first != self.first:
+            raise ValueError('the two readers of a pair must start at the same record')
+        foreign = _ct.c_int(0)
+        _N.check(_N.load().kbbq_fastq_fill_rows(self._h, other._h if other is not None else None, first - self.first, n,
+                                                 _N.ptr(meta), int(flags), int(S2), int(pitch), _N.ptr(perm), int(row_lo), int(nrows),
+                                                 _N.ptr(seq), _N.ptr(cseq), _N.ptr(qual), _N.ptr(dmeta), _ct.byref(foreign)))
+        return bool(foreign.value)
+
+    def format_rows_array(self, first, n, newqual, flags, S2, out=None):
+        """format_array with the new qualities still in the rows K2 wrote (mate-pair rows when flags has ROWS_PAIRS:
+        `first` is the first mate of newqual's row 0)."""
+        newqual = np.ascontiguousarray(newqual)
+        pitch = newqual.shape[1]
+        lib = _N.load()
+        local = first - self.first
+        need = int(-lib.kbbq_fastq_format_rows(self._h, local, n, int(flags), int(S2), pitch, _N.ptr(newqual), None, 0))
+        if need == 0 and n:
+            _N.check(_N.KBBQ_E_ARG)
+        buf = np.empty(max(need, 1), dtype=np.uint8) if out is None else out(max(need, 1))
+        got = lib.kbbq_fastq_format_rows(self._h, local, n, int(flags), int(S2), pitch, _N.ptr(newqual), _N.ptr(buf), need)
+        if got != need:
+            _N.check(_N.KBBQ_E_ARG)
+        return buf[:need]
+
     def format_array(self, first, n, newqual, out=None):
         """FASTQ text of reads [first, first+n) with qualities from rows of `newqual`, as a uint8 array
         (written once by the C++ writer: no zero fill, no copy).  out: callable nbytes -> uint8 array of at least
@@ -403,10 +442,14 @@ def length_bands(lens, max_bands=16):
     return out
 
 
-def _fill_bands(A, B, infer_rg_flag, lo, hi, to_device=False):
+def _fill_bands(A, B, infer_rg_flag, lo, hi, to_device=False, R=1, S=None):
     """Reads [lo, hi) packed band by band: [dict(first, n, S, Smin, pitch, seq, cseq, qual, meta)], `first` counted from
-    lo.  to_device: instead of host planes every band carries `batch`, a _device.ReadBatch filled slab by slab through
-    page-locked staging (ReadBatch.from_reader) -- the form the file path uses."""
+    lo.  to_device: instead of host planes every band carries `laid`, the band on the device in the layout the kernels
+    run fastest on, written by the packer itself slab by slab through page-locked staging (_device.laid_from_reader;
+    R = read groups, S = the input's longest read: mate-pair rows need count tables of exactly 2 x the band's length) --
+    or, when no layout applies, `batch`: one character row per read (_device.ReadBatch.from_reader).  `source` lets
+    band_rows() make those rows later for a band that has `laid` only (whatever a layout's kernels refuse is redone on
+    them: they carry the reference's exact error semantics)."""
     from ._trace import stage
     out = []
     with stage('bands'):
@@ -416,12 +459,28 @@ def _fill_bands(A, B, infer_rg_flag, lo, hi, to_device=False):
         band = dict(first=b_lo, n=b_hi - b_lo, S=longest, Smin=shortest, pitch=pitch)
         if to_device:
             from . import _device as dev
-            band['batch'] = dev.ReadBatch.from_reader(A, B, infer_rg_flag, lo + b_lo, b_hi - b_lo, pitch)
+            band['source'] = (A, B, infer_rg_flag, lo + b_lo)
+            band['batch'] = None
+            band['laid'] = dev.laid_from_reader(A, B, infer_rg_flag, lo + b_lo, b_hi - b_lo, pitch, max(R, 1),
+                                                packed=longest <= dev.PACKED_READS, pairs=None if S in (None, longest) else False)
+            if band['laid'] is None:
+                band_rows(band)
         else:
             seq, cseq, qual, meta = A.fill(B, infer_rg_flag, b_hi - b_lo, pitch, first=lo + b_lo)
             band.update(seq=seq, cseq=cseq, qual=qual, meta=meta)
         out.append(band)
     return out
+
+
+def band_rows(band):
+    """The band as one character row per read on the device (band['batch']), filled from the text on first use."""
+    if band.get('batch') is None:
+        from . import _device as dev
+        A, B, infer_rg_flag, first = band['source']
+        if B is not None and (getattr(B, '_closing', False) or B._h is None):
+            B = None                                              # the corrected file has been closed: pass 2 does not need it
+        band['batch'] = dev.ReadBatch.from_reader(A, B, infer_rg_flag, first, band['n'], band['pitch'])
+    return band['batch']
 
 
 def _shard(n, shard):
@@ -436,6 +495,7 @@ def close_later(reader):
     """Close a NativeFastq on a helper thread: unmapping GBs of file costs tens of milliseconds, which need not sit on
     the path to the first kernel (the C call runs without the interpreter lock)."""
     import threading
+    reader._closing = True                   # from here on nobody may start new work on it (band_rows)
     threading.Thread(target=reader.close, daemon=True).start()
 
 
@@ -643,14 +703,18 @@ def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None,
     common = dict(n=hi - lo, first=lo, total=total, pitch=pitch, S=S, R=R,
                   rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)},
                   text=A, pending_error=pending)
+    keep = False
     try:
         with stage('fill'):
             if bands:
-                return dict(common, bands=_fill_bands(A, B, infer_rg_flag, lo, hi, to_device))
+                keep = to_device             # a band the kernels refuse in its layout is re-filled as character rows: the
+                return dict(common, other=B if to_device else None,      # caller closes B after the tally (close_later)
+                            bands=_fill_bands(A, B, infer_rg_flag, lo, hi, to_device, R, S))
             seq, cseq, qual, meta = A.fill(B, infer_rg_flag, hi - lo, pitch, first=lo)
         return dict(common, seq=seq, cseq=cseq, qual=qual, meta=meta)
     finally:
-        close_later(B)                       # file B is not needed after the fill: unmap it off the critical path
+        if not keep:
+            close_later(B)                   # file B is not needed after the fill: unmap it off the critical path
 
 
 def pack_single(text, infer_rg_flag, shard=None, bands=False, to_device=False):
@@ -665,6 +729,6 @@ def pack_single(text, infer_rg_flag, shard=None, bands=False, to_device=False):
     common = dict(n=hi - lo, first=lo, total=total, pitch=pitch, S=S, R=R,
                   rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)})
     if bands:
-        return dict(common, bands=_fill_bands(text, None, infer_rg_flag, lo, hi, to_device))
+        return dict(common, bands=_fill_bands(text, None, infer_rg_flag, lo, hi, to_device, R, S))
     seq, _, qual, meta = text.fill(None, infer_rg_flag, hi - lo, pitch, first=lo)
     return dict(common, seq=seq, qual=qual, meta=meta)

@@ -46,21 +46,13 @@ def _vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore)
     return _solve.vectors_from_tables(pos_errs, pos_total, dinuc_errs, dinuc_total, maxscore)
 
 
-def _lay_out(batch, R, S, S_global=None):
-    """The device layout that moves the fewest bytes / keeps every lane busy for this batch, made
-    in one native pass (dev.lay_out): mate-pair rows for uniform first/second pairs, rows gathered by read-group segment
-    when there are several groups, 4-bit sequence planes when every base is one of ACGTN.  None: the batch stays as
-    it is.  Mate-pair rows need count tables of exactly 2S columns, so a band shorter than the input's longest read
-    keeps one read per row."""
-    pairs = None if S_global in (None, S) else False
-    laid = dev.lay_out(batch, R, S, packed=S <= dev.PACKED_READS, pairs=pairs)
-    return None if laid is batch else laid
+LAST_RUN = {}            # what the most recent recalibrate_fastq did per length band (layouts, bytes uploaded): bench.py, traces
 
 
 def _tally_local(packed, minscore, maxscore):
     """K1 over this rank's packed reads, length band by length band -> device Tables (zero tables when the rank has
-    no reads).  Each band is tallied in the layout _lay_out picks; whatever that path reports (bad input, a shape it
-    does not serve) is redone one read per row, which carries the reference's exact error semantics.  The read index
+    no reads).  Each band is tallied in the layout the packer wrote it in (fastx._fill_bands); whatever that path reports
+    (bad input, a shape it does not serve) is redone one read per row, which carries the reference's exact error semantics.  The read index
     of a kernel-reported error is made relative to the rank's first read."""
     if maxscore != 42:
         raise ValueError('the Q axis of the device tables is fixed at 43 (maxscore = 42)')
@@ -69,7 +61,7 @@ def _tally_local(packed, minscore, maxscore):
         return None
     tables = dev.Tables(R, 2 * S)
 
-    def tally_band(band, batch, laid):
+    def tally_band(band, laid):
         hints = dict(s_band=band['S'], s_min=band.get('Smin', 0))
         if laid is not None:
             part = dev.Tables(R, 2 * S)
@@ -79,20 +71,20 @@ def _tally_local(packed, minscore, maxscore):
                 band['laid'] = laid
                 return
             except (IndexError, TypeError, ValueError, dev.N.LutNeedsCheckedApply):
-                pass                         # bad input or an unsupported shape: the row-per-read kernel decides
-        dev.accumulate(batch, tables, minscore, **hints)
+                band['laid'] = None          # bad input or an unsupported shape: the row-per-read kernel decides
+        dev.accumulate(fastx.band_rows(band), tables, minscore, **hints)
 
     for band in packed['bands']:
-        batch = band.get('batch')                      # filled straight onto the device by the packer (to_device)
-        if batch is None:
-            with stage('H2D', sync=True):
-                batch = dev.ReadBatch.from_host(band['seq'], band['qual'], band['meta'], cseq=band['cseq'])
-        band['batch'], band['laid'] = batch, None      # still resident: pass 2 re-uses them when it covers file A
-        with stage('layout', sync=True):
-            laid = _lay_out(batch, R, band['S'], S)
+        if 'source' in band:
+            laid = band.get('laid')                    # written by the packer in its layout (fastx._fill_bands): nothing to convert
+        else:                                          # host planes of a caller's own: tallied and applied as they are -- a
+            with stage('H2D', sync=True):              # device pass into another layout costs more than it saves for ONE
+                band['batch'] = dev.ReadBatch.from_host(band['seq'], band['qual'], band['meta'], cseq=band['cseq'])   # accumulate + apply
+            laid = None
+        band['laid'] = None                            # still resident: pass 2 re-uses them when it covers file A
         try:
             with stage('K1', sync=True):
-                tally_band(band, batch, laid)
+                tally_band(band, laid)
         except (IndexError, TypeError) as e:
             if hasattr(e, 'read_index'):
                 e.read_index = band['first'] + max(e.read_index, 0)
@@ -144,9 +136,17 @@ def _pack_and_tally(fastq, infer_rg, minscore, maxscore):
         # the reference fails at the FIRST offending read: let the kernel look at the reads
         # before it (and at it, when its own checks come first) before raising the host error
         idx, exc, inclusive = err
-        _tally(packed, minscore, maxscore)
+        try:
+            _tally(packed, minscore, maxscore)
+        finally:
+            if packed.get('other') is not None:
+                fastx.close_later(packed.pop('other'))
         raise exc
-    tables = _tally(packed, minscore, maxscore)
+    try:
+        tables = _tally(packed, minscore, maxscore)
+    finally:
+        if packed.get('other') is not None:
+            fastx.close_later(packed.pop('other'))     # the corrected file is not needed past the tally: unmap it off the critical path
     if tables is not None and packed.get('total', packed['n']) == 0:
         tables = None
     return packed, tables
@@ -248,20 +248,23 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None, output=None):
             if text.n != text.total:
                 text = fastx.NativeFastq(fastq[0])                 # a shard's reader: pass 2 needs all of file A
             single = fastx.pack_single(text, infer_rg, shard, bands=True, to_device=True)
-        for band in single['bands']:
-            band['laid'] = _lay_out(band['batch'], R, band['S'], single['S'])
 
     def apply_band(band):
+        """New qualities of a band: in the band's own layout (mate-pair rows stay mate-pair rows, stored in input order
+        -- the writer reads them as they are) or, when the layout's kernel cannot serve the LUT or the rows, one read
+        per row from the checked kernel."""
         laid, out = band.get('laid'), None
+        band['out_flags'], band['out_S2'] = 0, 0
         if laid is not None:
             try:
                 out = dev.apply(laid, lut, shape, restore_order=True)      # grouped rows: stored straight back in input order
                 if isinstance(laid, dev.PairBatch):
-                    out = laid.unpack(out)
+                    band['out_flags'], band['out_S2'] = dev.N.ROWS_PAIRS, 2 * laid.S
             except dev.N.LutNeedsCheckedApply:
                 out = None                   # a LUT the fast kernel cannot serve: the checked row-per-read kernel
         if out is None:
-            out = dev.apply(band['batch'], lut, shape)
+            band['out_flags'], band['out_S2'] = 0, 0
+            out = dev.apply(fastx.band_rows(band), lut, shape)
         return out
 
     def apply_shard():
@@ -276,6 +279,14 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None, output=None):
         return outs
     with stage('apply', sync=True):
         outs = _collective(apply_shard, single['first'])
+    LAST_RUN.clear()
+    LAST_RUN['bands'] = [dict(reads=b['n'], longest=b['S'],
+                              layout=(b['laid'] if b.get('laid') is not None else b['batch']).describe(),
+                              written_by='the FASTQ packer (kbbq_fastq_fill_rows)' if b.get('laid') is not None and 'source' in b else
+                                         'the row-per-read packer (kbbq_fastq_fill_range)',
+                              h2d_bytes=sum(getattr(x, 'h2d_bytes', 0) for x in (b.get('laid'), b.get('batch')) if x is not None),
+                              output_rows='mate-pair rows, read by the writer as they are' if b.get('out_flags') else 'one read per row')
+                         for b in single['bands']]
 
     # recalibrate.py:153-156: '@' + name, sequence, '+', qualities
     from . import _egress

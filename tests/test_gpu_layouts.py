@@ -328,3 +328,43 @@ def test_single_end_reads_take_mate_pair_rows_two_to_a_row(dev, oracle, S, R, n,
     odd.meta[3] = (odd.meta[3] & ~0xFFFF) | (S - 1)
     assert not isinstance(dev.lay_out(odd, R, S, packed=packed), dev.PairBatch)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('n,S,nrg,single_end,foreign', [(6000, 150, 1, False, False), (6000, 150, 4, False, False), (5001, 150, 1, True, False),
+                                                        (4000, 100, 3, True, False), (3000, 40, 1, False, True), (2000, 150, 2, False, True),
+                                                        (2, 150, 1, False, False), (1, 20, 1, True, False)])
+def test_the_packer_writes_the_rows_the_layout_pass_writes(dev, tmp_path, n, S, nrg, single_end, foreign):
+    """_device.laid_from_reader (the C++ packer fills mate-pair / 4-bit / read-group-gathered rows straight into the
+    page-locked slabs: kbbq_fastq_fill_rows) against dev.lay_out of the character rows the row-per-read packer uploads
+    (k7_lay_out): every plane, the sidecars, perm and seg byte for byte; slab sizes that do and do not divide the band;
+    a letter outside ACGTN sends both to character planes."""
+    from kbbq import fastx
+    from test_packer_layouts import _pair_files
+    rng = np.random.default_rng(n + S)
+    fa, fb = _pair_files(tmp_path, rng, n, S, nrg, single_end, foreign=foreign)
+    infer = nrg > 1
+    A, B, info = fastx.PairScan(fa, fb, infer).result()
+    R = info[2]
+    pitch = fastx.pitch_for(S)
+    for other in (B, None):
+        rows = dev.ReadBatch.from_reader(A, other, infer, 0, n, pitch)
+        want = dev.lay_out(rows, R, S, packed=True)
+        for slab in (1 << 17, 998):
+            got = dev.laid_from_reader(A, other, infer, 0, n, pitch, R, packed=True, slab=slab)
+            if want is rows:
+                assert got is None
+                continue
+            assert type(got) is type(want) and got.n == want.n and got.pitch == want.pitch and got.nib == want.nib
+            assert got.nib == (not foreign)
+            if isinstance(want, dev.PairBatch):
+                assert got.S == want.S and got.twins == want.twins == single_end
+            m = want.n
+            for name in ('seq', 'cseq', 'qual', 'meta'):
+                g, w = getattr(got, name), getattr(want, name)
+                assert (g is None) == (w is None), name
+                if g is not None:
+                    assert np.array_equal(g[:m].cpu().numpy(), w[:m].cpu().numpy()), (name, slab)
+            assert (got.perm is None) == (want.perm is None) == (R == 1)
+            if R > 1:
+                assert np.array_equal(got.perm.cpu().numpy(), want.perm.cpu().numpy()) and np.array_equal(got.seg.cpu().numpy(), want.seg.cpu().numpy())
+    assert not [k for k in dev._pinned if k[0] == 'ingest']

@@ -604,6 +604,44 @@ def test_full_size_properties(dev):
     assert torch.equal(out_pairs[:n], out[:n])
 
 
+@pytest.mark.parametrize('R', [1, 8])
+def test_the_headline_layout_at_full_size(dev, R):
+    """BASELINE configs 2 and 3 in full (50 M x 2x150 bp, 1 and 8 read groups) in the layout bench.py's headline is measured
+    on and the FASTQ packer writes -- mate-pair rows, 4-bit sequence planes, rows gathered by read-group segment: its
+    count tables equal those of K1 on one character row per read, and the short-lived apply kernel's output on it (in
+    grouped order, and stored through the permutation) equals the persistent kernel's on the character rows."""
+    import torch
+    n, S = 50_000_000, 150
+    b = dev.ReadBatch.synthetic(0, n, n, seed=1, nrg=R)
+    t = dev.Tables(R, 2 * S)
+    dev.accumulate(b, t)
+    laid = dev.lay_out(b, R, S, packed=True)
+    assert laid.nib and isinstance(laid, dev.PairBatch) and (laid.seg is not None) == (R > 1) and laid.n == n // 2
+    t2 = dev.Tables(R, 2 * S)
+    dev.accumulate(laid, t2)
+    assert torch.equal(t.buf, t2.buf) and int(t.buf.sum()) > 0
+    lut, shape = dev.solve_lut(t)
+    assert shape[3] == 1
+    want = dev.apply(b, lut, shape)                       # one read per row, character planes: the persistent kernels
+    del b
+    torch.cuda.empty_cache()
+    got = laid.unpack(dev.apply(laid, lut, shape))        # k2t_apply, rows in the layout's (grouped) order
+    pitch = want.shape[1]
+    if R == 1:
+        assert torch.equal(got[:n, :S], want[:n, :S])
+    else:
+        pairs = want[:n].view(n // 2, 2 * pitch)
+        step = 5_000_000
+        for lo in range(0, n // 2, step):                 # row i of the layout is pair perm[i] of the input
+            hi = min(n // 2, lo + step)
+            assert torch.equal(got[2 * lo:2 * hi].view(hi - lo, 2 * pitch), pairs[laid.perm[lo:hi]]), lo
+    del got
+    torch.cuda.empty_cache()
+    back = laid.unpack(dev.apply(laid, lut, shape, restore_order=True))      # stored through the permutation: input order
+    assert torch.equal(back[:n, :S], want[:n, :S])
+    assert not bool(back[:n, S:].any())
+
+
 def test_bench_prints_one_json_line_with_the_contract_fields(dev):
     """bench.py's contract with the driver: exactly one JSON line on stdout, the metric / config of BASELINE.json, the
     roofline and cpu_baseline objects; a small run (the default sizes are the driver's business)."""
@@ -628,6 +666,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields(dev):
     # the figures next to it: the reference's own measured rate, the port on all host cores
     assert cpu['reference_bases_per_s'] > 1e5 and cpu['reference_cores'] == 1 and cpu['all_cores']['cores'] == cpu['host_cores']
     assert d['ranks_seen'] == 1 and d['kernels']['host_solve_and_sync_ms'] < 5
+    assert d['verified'] is True and cpu['measured'].startswith('before the first GPU call')
+    assert d['per_rank_ms_per_step']['min'] == d['per_rank_ms_per_step']['max'] == d['ms_per_step']
     # the other configurations and the rows next to the path, measured in the same process
     extra = d['extra']
     for key in ('config3_8rg', 'layout_pairs', 'layout_reads', 'aligned_read_kernels', 'file_path'):
@@ -635,6 +675,11 @@ def test_bench_prints_one_json_line_with_the_contract_fields(dev):
     assert extra['config3_8rg']['layout_inclusive']['value'] < extra['config3_8rg']['value']
     assert all(extra['aligned_read_kernels'][k]['GB/s'] > 0 for k in ('k4_find_errors', 'k5_count_q', 'k6_canonical_reads'))
     assert extra['file_path']['value'] > 1e6 and extra['file_path']['stages_s']
+    # the file path uploads the layout of the headline, written by the packer: 2 B/base, no layout pass, no unpack
+    assert 'layout' not in extra['file_path']['stages_s'] and 2.0 <= extra['file_path']['h2d_bytes_per_base'] < 2.1
+    assert all('mate-pair rows' in b['layout'] and '4-bit' in b['layout'] and 'kbbq_fastq_fill_rows' in b['written_by'] for b in extra['file_path']['bands'])
+    assert extra['config3_8rg']['verified'] is True and extra['single_end_150']['verified'] is True
+    assert extra['from_input_order_rows']['ms_per_step'] == extra['layout_reads']['ms_per_step']
 
 
 def test_bench_launches_its_own_two_rank_job(dev):
