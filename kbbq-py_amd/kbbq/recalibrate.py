@@ -249,6 +249,12 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None, output=None):
                 text = fastx.NativeFastq(fastq[0])                 # a shard's reader: pass 2 needs all of file A
             single = fastx.pack_single(text, infer_rg, shard, bands=True, to_device=True)
 
+    if single['R'] != R:
+        # pass 2 met read groups the model does not have (recalibrate.py:143-151: an IndexError at the first such read) or
+        # fewer than it has: rows gathered by THEIR read-group segments do not fit the model's -- one read per row decides
+        for band in single['bands']:
+            band['laid'] = None
+
     def apply_band(band):
         """New qualities of a band: in the band's own layout (mate-pair rows stay mate-pair rows, stored in input order
         -- the writer reads them as they are) or, when the layout's kernel cannot serve the LUT or the rows, one read

@@ -194,14 +194,14 @@ def test_single_end_files_go_two_reads_to_a_row(dev, oracle, nrg, infer, n, tmp_
     oracle.write_fastq(fb, names, cseq, qual, meta)
     want, wantv, _ = oracle.recalibrate_fastq_text([fa, fb], infer)
     seen = []
-    real = D.lay_out
-    D.lay_out = lambda *a, **k: seen.append(real(*a, **k)) or seen[-1]
+    real = D.laid_from_reader                     # the packer writes the layout itself: no device layout pass to look at
+    D.laid_from_reader = lambda *a, **k: seen.append(real(*a, **k)) or seen[-1]
     try:
         capfd.readouterr()
         recalibrate.recalibrate_fastq([fa, fb], infer_rg=infer)
         assert capfd.readouterr().out == want
     finally:
-        D.lay_out = real
+        D.laid_from_reader = real
     assert seen and all(isinstance(b, D.PairBatch) and b.twins for b in seen)
     vec = recalibrate.fastq_to_covariate_arrays([fa, fb], infer_rg=infer)
     for g, w in zip(vec, wantv):
@@ -545,3 +545,38 @@ def test_two_ranks_when_pass_2_covers_more_than_pass_1(dev, oracle, tmp_path):
         assert one.returncode == 0 and two.returncode == 0, (one.stderr.decode()[-1500:], two.stderr.decode()[-1500:])
         assert len(one.stdout) > 1000 and two.stdout == one.stdout, argv
     assert os.path.getsize(model) > 1000
+
+
+@pytest.mark.parametrize('nrg', [1, 3])
+def test_a_lut_the_table_driven_kernels_cannot_serve_takes_checked_rows(dev, oracle, nrg, tmp_path, monkeypatch):
+    """The file path with a model whose apply LUT is not range-safe for the table-driven kernels (a row whose smallest cycle
+    entry + smallest context entry would leave 0..255: the blob's flags say so, shape mode APPLY_CHECKED): the layout the
+    packer wrote cannot be applied, the band is filled again as one character row per read from the text and the checked
+    kernel serves it -- same bytes as the oracle's apply with those tables.  (A solved model is always range-safe -- the
+    prior forbids a posterior further than 18 from its prior at every level -- so the model is put in place of the solve.)"""
+    from kbbq import recalibrate
+    n, S = 3000, 150
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 23, S, S, nrg, 10, 41)
+    names = oracle.synth_names(0, n, nrg, with_rg=nrg > 1)
+    fa, fb, fo = (str(tmp_path / x) for x in ('a.fq', 'b.fq', 'out.fq'))
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, names, cseq, qual, meta)
+    rng = np.random.default_rng(3)
+    meanq = rng.integers(15, 25, nrg); rgdq = rng.integers(-2, 3, nrg); qdq = rng.integers(-3, 4, (nrg, 43))
+    posdq = rng.integers(-6, 7, (nrg, 43, 2 * S)); ddq = rng.integers(-6, 7, (nrg, 43, 17)); ddq[..., 16] = 0
+    posdq[:, 7, :] = -70                                       # a quality no read carries (10..41): only the row's range check sees it
+    lut, shp = dev.build_lut(meanq, rgdq, qdq, posdq, ddq)
+    assert shp[3] == dev.N.APPLY_CHECKED
+    d_lut = dev.lut_to_device(lut)
+    monkeypatch.setattr(dev, 'solve_lut', lambda tables, **k: (d_lut, shp))
+    recalibrate.recalibrate_fastq([fa, fb], infer_rg=nrg > 1, output=fo)
+    ref = oracle.apply(seq, qual, meta, meanq, rgdq, qdq, posdq, ddq)
+    want = ''.join('@%s\n%s\n+\n%s\n' % (names[i], bytes(seq[i, :S]).decode(), bytes((ref[i, :S] + 33).astype(np.uint8)).decode()) for i in range(n))
+    assert open(fo).read() == want
+    bands = recalibrate.LAST_RUN['bands']
+    assert all(b['output_rows'] == 'one read per row' for b in bands)
+    # and with the model the path solves itself the same command writes mate-pair rows
+    monkeypatch.undo()
+    recalibrate.recalibrate_fastq([fa, fb], infer_rg=nrg > 1, output=fo)
+    assert open(fo).read() == oracle.recalibrate_fastq_text([fa, fb], nrg > 1)[0]
+    assert all('mate-pair rows' in b['output_rows'] and 'kbbq_fastq_fill_rows' in b['written_by'] for b in recalibrate.LAST_RUN['bands'])
