@@ -406,7 +406,10 @@ def extra_mixed_lengths(torch, dev, n, steps, warmup, lo=36, hi=300):
     torch.cuda.empty_cache()
     ctx = dev.context()
 
-    def step():
+    triples = [(it['rows'], it['S'], it['Smin']) for it in items]
+    outs = [it['out'] for it in items]
+
+    def step_per_band():
         tables.buf.zero_()
         for it in items:
             part.buf.zero_()
@@ -415,6 +418,32 @@ def extra_mixed_lengths(torch, dev, n, steps, warmup, lo=36, hi=300):
         lut, shape = dev.solve_lut(tables, check=False, reuse=True)
         for it in items:
             dev.apply(it['rows'], lut, shape, out=it['out'], check=False)
+
+    def step():                             # what the file path does: one K1 launch and one K2 launch over all bands
+        tables.buf.zero_()
+        part.buf.zero_()
+        dev.accumulate_bands(triples, part, check=False)
+        tables.add(part)
+        lut, shape = dev.solve_lut(tables, check=False, reuse=True)
+        dev.apply_bands(triples, lut, shape, outs=outs, check=False)
+    # the launch-per-band form first: its tables and new qualities are what the merged launches must reproduce
+    step_per_band()
+    ctx.status()
+    want_tables = tables.buf.clone()
+    want_outs = [o.clone() for o in outs]
+    ctx.kernel_ms(0, reset=True); ctx.kernel_ms(1, reset=True)
+    ctx.timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_per_band()
+    torch.cuda.synchronize()
+    per_band_s = time.perf_counter() - t0
+    ctx.timing(False)
+    pb1, pb1n = ctx.kernel_ms(0, reset=True)
+    pb2, pb2n = ctx.kernel_ms(1, reset=True)
+    for o in outs:
+        o.zero_()
     for _ in range(warmup):
         step()
     ctx.status()
@@ -430,8 +459,15 @@ def extra_mixed_lengths(torch, dev, n, steps, warmup, lo=36, hi=300):
     ctx.status()
     k1_ms, k1_n = ctx.kernel_ms(0)
     k2_ms, k2_n = ctx.kernel_ms(1)
+    same = bool(torch.equal(tables.buf, want_tables)) and all(bool(torch.equal(a, b)) for a, b in zip(outs, want_outs))
     return {'workload': '%d synthetic reads of %d-%d bases in %d length bands of %d reads (BASELINE config 5, recalibration half), '
                         '1 read group, tables of %d cycle columns' % (per * len(bands), lo, hi, len(bands), per, 2 * hi),
+            'launches': 'ONE K1 launch and ONE K2 launch over all bands (kbbq_accumulate_bands_dev / kbbq_apply_bands_dev: every band on '
+                        'its share of the workgroups, its own pitch, LDS geometry and pitch-narrowed LUT)',
+            'verified': same, 'verified_how': 'count tables and every new quality byte == the launch-per-band form on the same bands',
+            'launch_per_band': {'value': bases * steps / per_band_s, 'ms_per_step': per_band_s / steps * 1e3,
+                                'k1_accumulate_all_bands': kernel_entry(pb1 / steps, pb1n, bases),
+                                'k2_apply_all_bands': kernel_entry(pb2 / steps, pb2n, bases)},
             'layout': '; '.join('%d-%d: %s' % (b[0], b[1], it['rows'].describe()) for b, it in zip(bands, items)),
             'bases_per_step': bases, 'padded_row_bytes_per_plane': padded,
             'value': bases * steps / elapsed, 'unit': 'bases/s', 'ms_per_step': elapsed / steps * 1e3,

@@ -88,6 +88,17 @@ int kbbq_dev_free(kbbq_ctx* ctx, void* dptr);
 int kbbq_dev_zero(kbbq_ctx* ctx, void* dptr, size_t bytes);                       /* async */
 int kbbq_dev_upload(kbbq_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);   /* sync */
 int kbbq_dev_download(kbbq_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* sync */
+/* the rest of what the file path needs to run WITHOUT torch (kbbq/_hipmem.py: the single-GPU command line never imports
+ * it): page-locked host buffers for the ingest / egress slabs, copies enqueued on the context's stream (kind 1 host to
+ * device, 2 device to host, 3 device to device; no synchronisation), events on that stream (when has a slab's upload
+ * left its buffer). */
+int kbbq_host_alloc(size_t bytes, void** hptr);
+int kbbq_host_free(void* hptr);
+int kbbq_dev_copy_async(kbbq_ctx* ctx, void* dst, const void* src, size_t bytes, int kind);
+int kbbq_event_create(kbbq_ctx* ctx, void** event);
+int kbbq_event_record(kbbq_ctx* ctx, void* event);
+int kbbq_event_sync(void* event);
+int kbbq_event_destroy(void* event);
 
 /* ---- geometry ---------------------------------------------------------- */
 size_t kbbq_tables_count(int R, int S2);          /* int64 elements in a count-table buffer */
@@ -205,6 +216,11 @@ int    kbbq_combiln_host(const int64_t* errs, const int64_t* total, int64_t ncel
  * and aux = the gammaln term of every cell in kbbq_solve_dev's order [rg R | q R*43 | pos R*43*S2 | dinuc R*43*16]. */
 int kbbq_solve_prep_host(const int64_t* tables, int R, int S2, double* aux, int64_t* marg, int threads);
 int    kbbq_gammaln_host(const double* x, int64_t n, double* out);
+/* the solve's two log tables without importing SciPy: logp[i] = xlogy(1, p[i]) = log(p[i]) and log1mp[i] = xlog1py(1, -p[i])
+ * = log1p(-p[i]), both with the C library's routines, which is what SciPy 1.15 evaluates for real arguments (compared bit
+ * for bit in tests/test_solve_core_host.py); the reference reaches both through scipy.stats.binom.logpmf
+ * (compare_reads.py:254). */
+int    kbbq_xlogy_tables_host(const double* p, int n, double* logp, double* log1mp);
 /* The solve without the host (csrc/lgam_core.h): kbbq_libm_log_data reads the constants of the host libm's own log()
  * (ln 2 split in two, 5 coefficients, 128 x {1/c, log c}: 263 doubles) out of the mapped library, so that a kernel can
  * evaluate the same gammaln bit for bit; KBBQ_E_HIP when they are not found (then kbbq_solve_dev's host-fed form stays
@@ -378,6 +394,27 @@ int    kbbq_apply_rows_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d
                            int pitch, int flags, int R, int S2, int minscore, const void* d_lut_blob, const void* d_pair_lut,
                            const int64_t* d_seg, const int64_t* d_perm, uint8_t* d_out);
 int    kbbq_meta_stats_dev(kbbq_ctx* ctx, const uint32_t* d_meta, int64_t nreads, int32_t* h_stats8);
+/* ---- all length bands of a mixed-length input in one launch per kernel (BASELINE config 5) --------------------
+ * The reference grows its count arrays as the reads get longer (recalibrate.py:81-101) and tallies / applies read by read;
+ * the file path cuts a (length-sorted: SURVEY H2) input into bands of one row width each and used to launch K1 and K2 once
+ * per band -- pipeline fill, table zeroing and flush paid per band.  kbbq_accumulate_bands_dev / kbbq_apply_bands_dev take
+ * the whole list: bands the merged kernels serve (K1: every shape the table-driven kernel fits except the
+ * chunk-position-major form of 2 x 150 bp mate-pair rows; K2: one-read-per-row 4-bit planes, one read group, the shapes the
+ * short-lived kernel takes) run as ONE launch, every band on its share of the workgroups with its own pitch, LDS table
+ * geometry (S_band, S_min as in kbbq_accumulate_band_dev) and pitch-narrowed LUT; the others are launched as
+ * kbbq_accumulate_rows_dev / kbbq_apply_rows_dev (or kbbq_accumulate_band_dev / kbbq_apply_dev for flags == 0 without d_seg)
+ * would launch them.  Results are those of the per-band calls (counts ADD into d_tables; every band's d_out gets its new
+ * qualities); d_cseq is not read by apply, d_perm / d_out / d_pair_lut not by accumulate. */
+typedef struct kbbq_band {
+    const uint8_t* d_seq; const uint8_t* d_cseq; const uint8_t* d_qual; const uint32_t* d_meta;
+    int64_t nrows; int32_t pitch; int32_t flags;           /* KBBQ_ROWS_* */
+    int32_t S_band; int32_t S_min;                         /* longest / shortest read of the band (0: as kbbq_accumulate_band_dev) */
+    const int64_t* d_seg; const int64_t* d_perm;           /* rows grouped by read group (may be NULL) */
+    uint8_t* d_out; const void* d_pair_lut;                /* apply: output plane; mate-pair rows: kbbq_pair_lut_rows_dev's LUT */
+} kbbq_band;
+int    kbbq_accumulate_bands_dev(kbbq_ctx* ctx, const kbbq_band* bands, int nbands, int R, int S2, int minscore,
+                                 int dinuc_minscore, int64_t* d_tables);
+int    kbbq_apply_bands_dev(kbbq_ctx* ctx, const kbbq_band* bands, int nbands, int R, int S2, int minscore, const void* d_lut_blob);
 size_t kbbq_group_rows_work_bytes(int64_t nrows, int R);
 int    kbbq_group_rows_dev(kbbq_ctx* ctx, const uint32_t* d_meta, int64_t nrows, int pairs, int R, void* d_work,
                            int64_t* d_perm, int64_t* d_seg);

@@ -115,6 +115,11 @@ int kbbq_ctx_create(int device, kbbq_ctx** out)
     (void)hipFuncSetAttribute((const void*)(k2v3_apply<false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k2v3_apply<true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2t_apply, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)k2t_bands, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_bands<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_bands<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_bands<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_bands<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2_apply<int16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2_apply<int8_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipGetLastError();
@@ -248,6 +253,59 @@ int kbbq_dev_download(kbbq_ctx* c, void* dst, const void* src, size_t bytes)
     return KBBQ_OK;
 }
 
+int kbbq_host_alloc(size_t bytes, void** hptr)
+{
+    if (!hptr) return fail(KBBQ_E_ARG, "kbbq_host_alloc: NULL argument");
+    HIPCHK(hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return KBBQ_OK;
+}
+
+int kbbq_host_free(void* hptr)
+{
+    if (hptr) HIPCHK(hipHostFree(hptr));
+    return KBBQ_OK;
+}
+
+int kbbq_dev_copy_async(kbbq_ctx* c, void* dst, const void* src, size_t bytes, int kind)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (kind < 1 || kind > 3) return fail(KBBQ_E_ARG, "kbbq_dev_copy_async: kind must be 1 (host to device), 2 (device to host) or 3 (device to device)");
+    HIPCHK(hipSetDevice(c->device));
+    if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
+    return KBBQ_OK;
+}
+
+int kbbq_event_create(kbbq_ctx* c, void** ev)
+{
+    if (!c || !ev) return fail(KBBQ_E_ARG, "kbbq_event_create: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    hipEvent_t e;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *ev = (void*)e;
+    return KBBQ_OK;
+}
+
+int kbbq_event_record(kbbq_ctx* c, void* ev)
+{
+    if (!c || !ev) return fail(KBBQ_E_ARG, "kbbq_event_record: NULL argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord((hipEvent_t)ev, c->stream));
+    return KBBQ_OK;
+}
+
+int kbbq_event_sync(void* ev)
+{
+    if (!ev) return fail(KBBQ_E_ARG, "kbbq_event_sync: NULL event");
+    HIPCHK(hipEventSynchronize((hipEvent_t)ev));
+    return KBBQ_OK;
+}
+
+int kbbq_event_destroy(void* ev)
+{
+    if (ev) HIPCHK(hipEventDestroy((hipEvent_t)ev));
+    return KBBQ_OK;
+}
+
 size_t kbbq_tables_count(int R, int S2)
 {
     return 2 * (size_t)R * KQ * (size_t)S2 + 2 * (size_t)R * KQ * KND;
@@ -331,10 +389,13 @@ int kbbq_accumulate_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq
                                   minscore, minscore, d_tables);
 }
 
+// what accumulate_rows would launch (kernel parameters, LDS bytes, template variant): kbbq_accumulate_bands_dev collects
+// these for all length bands and launches them as ONE kernel
+struct K1Setup { K1v3Params q; int dn = 0; bool km = false; bool split = false; size_t lds = 0; int64_t iters = 0; int threads = K1V3_THREADS; };
 static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                            const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
                            int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band = 0, int S_min = 0, int nib = 0,
-                           int twins = 0);
+                           int twins = 0, K1Setup* setup_only = nullptr);
 
 int kbbq_accumulate_ex_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq,
                            const uint8_t* d_qual, const uint32_t* d_meta,
@@ -791,7 +852,8 @@ int kbbq_unpack_pairs_dev(kbbq_ctx* c, const uint8_t* d_pplane, int64_t npairs, 
 // K1 (table-driven kernel) on one-read-per-row or mate-pair rows, optionally grouped by read group
 static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                            const uint32_t* d_meta, int64_t nrows, int pitch, int pairs, int R, int S2, int minscore,
-                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band, int S_min, int nib, int twins)
+                           int dinuc_minscore, const int64_t* d_seg, int64_t* d_tables, bool* fits, int S_band, int S_min, int nib, int twins,
+                           K1Setup* setup_only)
 {
     if (fits) *fits = true;
     if (S_band < 0 || S_band > S2 / 2 || (pairs && S_band)) return fail(KBBQ_E_ARG, "%s: S_band out of range (%d)", who, S_band);
@@ -831,6 +893,23 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
         lds3 = (size_t)q.nrows * 128 * K1V3_DNREP + (size_t)q.nrows * q.row_bytes;
         if (lds3 <= (size_t)c->lds_bytes) dn = K1V3_DNREP;
     }
+    // An experiment kept behind KBBQ_K1_TWO=1 (round 3; measured, not adopted): narrow rows (the short bands of a mixed-length
+    // input) run K1 at half the rate of wide ones -- a 64-row block is a few steps of work behind two dependent loads -- and
+    // their tables are small: with 8 copies of the context table TWO workgroups of 12 waves fit a CU's LDS and registers (24
+    // waves per CU instead of 16; two 16-wave workgroups never fitted: 72 registers allow 7 waves per SIMD).  Config 5's K1:
+    // 1.80-1.85 ms against 1.74-1.75 merged, 1.97 against 1.90 a launch per band -- the halved copies cost more than the waves bring.
+    int threads = K1V3_THREADS, per_cu = 1;
+    {
+        const char* two_env = getenv("KBBQ_K1_TWO");
+        const int cut = trim, words = (3 * S - cut) | 1;
+        const size_t lds_two = (size_t)q.nrows * 128 * 8 + (size_t)q.nrows * words * 4 + (size_t)(S + 32) * 4;
+        if (!km && !pairs && two_env && !strcmp(two_env, "1") && 2 * (lds_two + 1024) <= (size_t)c->lds_bytes
+            && (768 / 8) * 16 * q.cpr <= 65535) {
+            q.row_bytes = (u32)words * 4u; q.minlen = cut; q.slack_bytes = (u32)(S + 32) * 4u;
+            q.dn_flush_iters = std::max(1, 65535 / ((768 / 8) * 16 * q.cpr));
+            lds3 = lds_two; dn = 8; threads = 768; per_cu = 2;
+        }
+    }
     for (int attempt = 0; attempt < (trim ? 3 : 1) && !dn; ++attempt) {
         const int copies = attempt == 2 ? 8 : K1V3_DNREP, cut = attempt ? trim : 0;
         const int words = (3 * S - cut) | 1;
@@ -848,9 +927,14 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     }
     const bool split = dinuc_minscore > minscore;
     const int64_t nblocks = (nrows + 63) / 64;
-    const int64_t iters = (nblocks + (K1V3_THREADS / 64) - 1) / (K1V3_THREADS / 64);
-    int gx = (int)std::min<int64_t>(iters, std::max(1, c->cus / R));
-    dim3 grid((unsigned)gx, (unsigned)R, 1), block(K1V3_THREADS, 1, 1);
+    const int64_t iters = (nblocks + (threads / 64) - 1) / (threads / 64);
+    if (setup_only) {
+        setup_only->q = q; setup_only->dn = dn; setup_only->km = km && dn == K1V3_DNREP; setup_only->split = split;
+        setup_only->lds = lds3; setup_only->iters = iters; setup_only->threads = threads;
+        return KBBQ_OK;
+    }
+    int gx = (int)std::min<int64_t>(iters, std::max(1, c->cus * per_cu / R));
+    dim3 grid((unsigned)gx, (unsigned)R, 1), block((unsigned)threads, 1, 1);
     {
         Timed t(c, 0);
         if (km && dn == K1V3_DNREP) {
@@ -1071,6 +1155,208 @@ int kbbq_apply_rows_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual
     if (pairs) { rc = check_pairs("kbbq_apply_rows_dev", nrows, S2); if (rc) return rc; }
     return apply_rows(c, "kbbq_apply_rows_dev", d_seq, d_qual, d_meta, nrows, pitch, pairs, R, S2, minscore, d_lut_blob,
                       d_pair_lut, d_seg, d_out, (flags & KBBQ_ROWS_NIBBLES) ? 1 : 0, d_perm);
+}
+
+// ---- all length bands of a mixed-length input in ONE launch per kernel -------------------------------------------
+static int band_accumulate_alone(kbbq_ctx* c, const kbbq_band& b, int R, int S2, int minscore, int dinuc_minscore, int64_t* d_tables)
+{
+    if (b.flags || b.d_seg)
+        return kbbq_accumulate_rows_dev(c, b.d_seq, b.d_cseq, b.d_qual, b.d_meta, b.nrows, b.pitch, b.flags, R, S2, b.S_band, b.S_min,
+                                        minscore, dinuc_minscore, b.d_seg, d_tables);
+    return kbbq_accumulate_band_dev(c, b.d_seq, b.d_cseq, b.d_qual, b.d_meta, b.nrows, b.pitch, R, S2, b.S_band, b.S_min, minscore,
+                                    dinuc_minscore, d_tables);
+}
+
+// workgroups for every band of a merged launch: one each, the rest of `total` by largest remainder of weight / sum(weight),
+// never more than a band can use (`cap`)
+static void share_workgroups(const std::vector<double>& weight, const std::vector<int64_t>& cap, int total, std::vector<int>& out)
+{
+    const size_t n = weight.size();
+    out.assign(n, 1);
+    int left = total - (int)n;
+    double sum = 0; for (double w : weight) sum += w;
+    for (int round = 0; round < 4 && left > 0 && sum > 0; ++round) {            // a capped band's surplus goes round again
+        std::vector<std::pair<double, size_t>> frac;
+        int given = 0; double open_sum = 0;
+        for (size_t i = 0; i < n; ++i) if (out[i] < cap[i]) open_sum += weight[i];
+        if (open_sum <= 0) break;
+        const int pool = left;
+        for (size_t i = 0; i < n; ++i) {
+            if (out[i] >= cap[i]) continue;
+            const double want = pool * weight[i] / open_sum;
+            int add = (int)std::min<int64_t>((int64_t)want, cap[i] - out[i]);
+            out[i] += add; given += add;
+            if (out[i] < cap[i]) frac.push_back({want - (int64_t)want, i});
+        }
+        left -= given;
+        std::sort(frac.begin(), frac.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+        for (auto& f : frac) { if (left <= 0) break; if (out[f.second] < cap[f.second]) { ++out[f.second]; --left; } }
+    }
+}
+
+int kbbq_accumulate_bands_dev(kbbq_ctx* c, const kbbq_band* bands, int nbands, int R, int S2, int minscore, int dinuc_minscore,
+                              int64_t* d_tables)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (nbands < 0 || (nbands > 0 && !bands)) return fail(KBBQ_E_ARG, "kbbq_accumulate_bands_dev: bad band list");
+    // which bands the merged kernel (k1v3_bands) takes: the table-driven K1 fits their LDS geometry, position-major cycle
+    // table (not the chunk-position-major form of 2 x 150 bp mate-pair rows), all on 4-bit planes or all on character planes
+    std::vector<K1Setup> setups; std::vector<int> merged, alone;
+    const char* off = getenv("KBBQ_K1_BANDS");                       // "0": a launch per band (A/B timing)
+    int nib_of_merge = -1;
+    for (int i = 0; i < nbands; ++i) {
+        const kbbq_band& b = bands[i];
+        if (b.nrows == 0) continue;
+        int rc = layout_flags_ok("kbbq_accumulate_bands_dev", b.flags);
+        if (rc) return rc;
+        const int pairs = (b.flags & KBBQ_ROWS_PAIRS) ? 1 : 0, nib = (b.flags & KBBQ_ROWS_NIBBLES) ? 1 : 0;
+        K1Setup su; bool fits = false;
+        bool can = !(off && !strcmp(off, "0")) && (int)merged.size() < K1V3_MAX_BANDS;
+        if (can) {
+            if (pairs) { rc = check_pairs("kbbq_accumulate_bands_dev", b.nrows, S2); if (rc) return rc; }
+            rc = accumulate_rows(c, "kbbq_accumulate_bands_dev", b.d_seq, b.d_cseq, b.d_qual, b.d_meta, b.nrows, b.pitch, pairs, R, S2, minscore,
+                                 dinuc_minscore, b.d_seg, d_tables, &fits, pairs ? 0 : b.S_band, pairs ? 0 : b.S_min, nib,
+                                 (b.flags & KBBQ_ROWS_TWINS) ? 1 : 0, &su);
+            if (rc) return rc;
+            can = fits && !su.km && (nib_of_merge < 0 || nib_of_merge == nib);
+        }
+        if (can) { nib_of_merge = nib; merged.push_back(i); setups.push_back(su); }
+        else alone.push_back(i);
+    }
+    // two kinds of bands: narrow rows whose tables let two 12-wave workgroups share a CU (accumulate_rows), and the rest
+    // (one 16-wave workgroup per CU); each kind with at least two bands is ONE launch, anything else goes alone
+    std::vector<std::vector<size_t>> groups(2);
+    for (size_t k = 0; k < merged.size(); ++k) groups[setups[k].threads == K1V3_THREADS ? 0 : 1].push_back(k);
+    for (auto& grp : groups) {
+        const int G = grp.empty() ? 1 : std::max(1, c->cus * (setups[grp[0]].threads == K1V3_THREADS ? 1 : 2) / std::max(R, 1));
+        if (grp.size() < 2 || (int)grp.size() > G) { for (size_t k : grp) alone.push_back(merged[k]); grp.clear(); }
+    }
+    for (int i : alone) {
+        int rc = band_accumulate_alone(c, bands[i], R, S2, minscore, dinuc_minscore, d_tables);
+        if (rc) return rc;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const char* rc_env = getenv("KBBQ_K1_BAND_ROWCOST");
+    const double row_cost = rc_env ? atof(rc_env) : 3.0;
+    for (auto& grp : groups) {
+        if (grp.empty()) continue;
+        const int threads = setups[grp[0]].threads;
+        const int G = std::max(1, c->cus * (threads == K1V3_THREADS ? 1 : 2) / std::max(R, 1));
+        K1BandsParams t;
+        memset(&t, 0, sizeof t);
+        t.nbands = (int)grp.size();
+        // a band's share of the workgroups follows its work: chunks to bin plus a per-row term (a 64-row block pays the sidecar
+        // -> row address -> first chunk latency whatever its width: narrow rows run at half the rate of wide ones)
+        std::vector<double> weight; std::vector<int64_t> cap; std::vector<int> share;
+        size_t lds = 0;
+        for (size_t k : grp) {
+            const K1Setup& su = setups[k];
+            weight.push_back((double)su.q.nreads * (su.q.cpr + row_cost));
+            cap.push_back(std::max<int64_t>(1, su.iters));
+            lds = std::max(lds, su.lds);
+        }
+        share_workgroups(weight, cap, G, share);
+        int run = 0;
+        for (size_t j = 0; j < grp.size(); ++j) {
+            t.wg_start[j] = run; run += share[j];
+            t.dn[j] = setups[grp[j]].dn; t.band[j] = setups[grp[j]].q;
+        }
+        t.wg_start[grp.size()] = run;
+        const bool split = setups[grp[0]].split;
+        dim3 grid((unsigned)run, (unsigned)R, 1), block((unsigned)threads, 1, 1);
+        {
+            Timed tm(c, 0);
+            if (nib_of_merge) {
+                if (split) hipLaunchKernelGGL((k1v3_bands<true, true>), grid, block, lds, c->stream, t);
+                else hipLaunchKernelGGL((k1v3_bands<false, true>), grid, block, lds, c->stream, t);
+            } else {
+                if (split) hipLaunchKernelGGL((k1v3_bands<true, false>), grid, block, lds, c->stream, t);
+                else hipLaunchKernelGGL((k1v3_bands<false, false>), grid, block, lds, c->stream, t);
+            }
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return KBBQ_OK;
+}
+
+static int band_apply_alone(kbbq_ctx* c, const kbbq_band& b, int R, int S2, int minscore, const void* d_lut_blob)
+{
+    if (b.flags || b.d_seg)
+        return kbbq_apply_rows_dev(c, b.d_seq, b.d_qual, b.d_meta, b.nrows, b.pitch, b.flags, R, S2, minscore, d_lut_blob, b.d_pair_lut,
+                                   b.d_seg, b.d_perm, b.d_out);
+    return kbbq_apply_dev(c, b.d_seq, b.d_qual, b.d_meta, b.nrows, b.pitch, R, KQ, S2, minscore, d_lut_blob, KBBQ_APPLY_FAST, b.d_out);
+}
+
+int kbbq_apply_bands_dev(kbbq_ctx* c, const kbbq_band* bands, int nbands, int R, int S2, int minscore, const void* d_lut_blob)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (nbands < 0 || (nbands > 0 && !bands) || !d_lut_blob) return fail(KBBQ_E_ARG, "kbbq_apply_bands_dev: bad argument");
+    if (R <= 0 || R > 32767 || S2 <= 0 || (S2 & 1) || S2 > 65534 || minscore < 0 || minscore > 222) return fail(KBBQ_E_ARG, "kbbq_apply_bands_dev: bad shape");
+    // the merged kernel (k2t_bands) takes what the short-lived kernel takes of one-read-per-row 4-bit planes with one read
+    // group: rows of 2..4096 chunks whose pitch-narrowed LUT is small (apply_rows' own test); the rest goes band by band
+    const char* off = getenv("KBBQ_K2_BANDS");
+    const char* tile = getenv("KBBQ_K2_TILE");
+    const size_t lut_cap = (size_t)(getenv("KBBQ_K2_TILE_LUT_KB") ? atoi(getenv("KBBQ_K2_TILE_LUT_KB")) : 52) << 10;
+    std::vector<int> merged, alone;
+    for (int i = 0; i < nbands; ++i) {
+        const kbbq_band& b = bands[i];
+        if (b.nrows == 0) continue;
+        int rc = layout_flags_ok("kbbq_apply_bands_dev", b.flags);
+        if (rc) return rc;
+        const int cpr = b.pitch / 16;
+        const int Sb = std::min(b.pitch, S2);
+        const bool can = !(off && !strcmp(off, "0")) && !(tile && !strcmp(tile, "0")) && (int)merged.size() < K2T_MAX_BANDS && R == 1
+                         && b.flags == KBBQ_ROWS_NIBBLES && !b.d_seg && !b.d_perm && b.pitch > 0 && !(b.pitch & 15) && cpr >= 2 && cpr <= 4096
+                         && (size_t)(33 + KQ) * full_lut_row_bytes(Sb) <= lut_cap
+                         && !(((uintptr_t)b.d_seq | (uintptr_t)b.d_qual | (uintptr_t)b.d_out) & 15) && b.d_seq && b.d_qual && b.d_meta && b.d_out;
+        (can ? merged : alone).push_back(i);
+    }
+    if (merged.size() < 2) { for (int i : merged) alone.push_back(i); merged.clear(); }
+    for (int i : alone) {
+        int rc = band_apply_alone(c, bands[i], R, S2, minscore, d_lut_blob);
+        if (rc) return rc;
+    }
+    if (merged.empty()) return KBBQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    // every band's LUT, narrowed to the columns rows of its pitch can reach, side by side in the context's scratch
+    std::vector<size_t> lut_off; size_t need = 0;
+    for (int i : merged) { lut_off.push_back(need); need += ((size_t)R * (33 + KQ) * full_lut_row_bytes(std::min(bands[i].pitch, S2)) + 255) & ~(size_t)255; }
+    if (c->rowlut_bytes < need) {
+        if (c->d_rowlut) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_rowlut); c->d_rowlut = nullptr; c->rowlut_bytes = 0; }
+        HIPCHK(hipMalloc(&c->d_rowlut, need));
+        c->rowlut_bytes = need;
+    }
+    K2tBandsParams t;
+    memset(&t, 0, sizeof t);
+    t.nbands = (int)merged.size();
+    const int64_t per_wg = (int64_t)(K2T_THREADS / 64) * 64 * K2T_STEPS;
+    int64_t run = 0; size_t lds = 0;
+    for (size_t k = 0; k < merged.size(); ++k) {
+        const kbbq_band& b = bands[merged[k]];
+        const int Sb = std::min(b.pitch, S2);
+        RowLutParams f;
+        f.lut16 = reinterpret_cast<const int16_t*>(d_lut_blob); f.rs16 = lut_row_stride(S2); f.R = R; f.Qt = KQ; f.S2 = S2; f.Sb = Sb;
+        f.minscore = std::min(std::max(minscore, 0), KQ);
+        f.out = reinterpret_cast<int8_t*>(c->d_rowlut) + lut_off[k];
+        hipLaunchKernelGGL(k3_fill_row_lut, dim3((unsigned)(R * (33 + KQ))), dim3(256), 0, c->stream, f);
+        K2tParams& q = t.band[k];
+        q.seq = b.d_seq; q.qual = b.d_qual; q.meta = b.d_meta; q.cpr = b.pitch / 16; q.cpr_magic = magic_for(q.cpr);
+        q.nchunks = b.nrows * q.cpr; q.Qt = KQ; q.S2 = S2; q.maxlen = Sb;
+        q.rb = (u32)full_lut_row_bytes(Sb); q.W = (u32)full_lut_width(Sb); q.ctx_off = 2u * q.W;
+        q.lut = f.out; q.lut_bytes = (int)((((size_t)(33 + KQ) * q.rb) + 15) & ~(size_t)15);
+        q.seg = nullptr; q.wg_start = nullptr; q.order = nullptr; q.R = R; q.perm = nullptr; q.pitch = b.pitch; q.out = b.d_out; q.status = c->d_status;
+        lds = std::max(lds, (size_t)q.lut_bytes);
+        t.wg_start[k] = (int)run;
+        run += (q.nchunks + per_wg - 1) / per_wg;
+        if (run > 0x7FFFFFFF) return fail(KBBQ_E_ARG, "kbbq_apply_bands_dev: too many workgroups");
+    }
+    t.wg_start[merged.size()] = (int)run;
+    {
+        Timed tm(c, 1);
+        hipLaunchKernelGGL(k2t_bands, dim3((unsigned)run), dim3(K2T_THREADS), lds, c->stream, t);
+    }
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
 }
 
 int kbbq_meta_stats_dev(kbbq_ctx* c, const uint32_t* d_meta, int64_t nreads, int32_t* h_stats8)

@@ -77,25 +77,26 @@ __global__ __launch_bounds__(256) void k2t_order(K2tOrderParams p)
     p.order[rank] = make_int2(g, i);
 }
 
-__global__ __launch_bounds__(K2T_THREADS) void k2t_apply(K2tParams p)
+// the kernel's body for workgroup `bx` of the batch `p` describes (k2t_apply: blockIdx.x; k2t_bands: the workgroup's
+// number within its length band)
+__device__ __forceinline__ void k2t_body(const K2tParams& p, u32* lds, const int bx)
 {
-    extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = K2T_THREADS / 64;
     // this workgroup's read group and chunk range (grouped rows), or everything
     int g = 0;
-    long long chunk_lo = 0, chunk_hi = p.nchunks, wg = blockIdx.x;
+    long long chunk_lo = 0, chunk_hi = p.nchunks, wg = bx;
     if (p.seg) {
-        if ((int)blockIdx.x >= p.wg_start[p.R]) return;
+        if (bx >= p.wg_start[p.R]) return;
         if (p.order) {
-            const int2 o = p.order[blockIdx.x];
+            const int2 o = p.order[bx];
             g = o.x; wg = o.y;
         } else {
-            int lo = 0, hi = p.R;                                   // largest g with wg_start[g] <= blockIdx.x
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.wg_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+            int lo = 0, hi = p.R;                                   // largest g with wg_start[g] <= bx
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.wg_start[mid] <= bx) lo = mid; else hi = mid; }
             g = lo;
-            wg = (long long)blockIdx.x - p.wg_start[g];
+            wg = (long long)bx - p.wg_start[g];
         }
         chunk_lo = p.seg[g] * p.cpr; chunk_hi = p.seg[g + 1] * p.cpr;
     }
@@ -190,4 +191,28 @@ __global__ __launch_bounds__(K2T_THREADS) void k2t_apply(K2tParams p)
             *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
         }
     }
+}
+
+__global__ __launch_bounds__(K2T_THREADS) void k2t_apply(K2tParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    k2t_body(p, lds, (int)blockIdx.x);
+}
+
+// ONE launch over all length bands of a mixed-length input (k1v3_bands' counterpart): workgroup blockIdx.x belongs to the
+// band whose run of workgroups holds it and stages THAT band's LUT (narrowed to the band's row pitch); the launch's LDS
+// size is the largest band's.  Rows not grouped by read group (one read group); anything else keeps a launch per band.
+#define K2T_MAX_BANDS 16
+struct K2tBandsParams {
+    int nbands;
+    int wg_start[K2T_MAX_BANDS + 1];
+    K2tParams band[K2T_MAX_BANDS];
+};
+
+__global__ __launch_bounds__(K2T_THREADS) void k2t_bands(K2tBandsParams t)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    int lo = 0, hi = t.nbands;                                      // largest b with wg_start[b] <= blockIdx.x
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (t.wg_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+    k2t_body(t.band[lo], lds, (int)blockIdx.x - t.wg_start[lo]);
 }

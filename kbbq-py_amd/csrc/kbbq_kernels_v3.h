@@ -129,10 +129,11 @@ struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int k; int j; int nb; };
 // position-major layout lets the random quality row pick the bank (a 32-lane half-wave on 32 banks: ~3.5 cycles).
 // Measured (profiles/r02_k1_lds.md): the cycle-table atomics were the larger half of K1's LDS time once the 4-bit
 // sequence planes had made K1 LDS-bound.  The per-base offset 4 * k * KJ is an instruction immediate.
-template <bool SPLIT, int DN = K1V3_DNREP, bool NIB = false, int KJ = 0>
-__global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
+// The kernel's body: workgroup `bx` of the `gx` that share this batch (k1v3_accumulate: the whole grid; k1v3_bands: the
+// workgroups one length band was given), read-group slice `g`.
+template <bool SPLIT, int DN, bool NIB, int KJ>
+__device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const int bx, const int gx, const int g)
 {
-    extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const int dn_words = p.nrows * 32 * DN;
     const int pos_words = p.nrows * (int)(p.row_bytes >> 2) + (int)(p.slack_bytes >> 2);
     u32* dnt = lds;
@@ -140,7 +141,6 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
     for (int i = threadIdx.x; i < dn_words + pos_words; i += blockDim.x) lds[i] = 0u;
     __syncthreads();
 
-    const int g = blockIdx.y;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: block bases live in SGPRs
     const int nwaves = blockDim.x >> 6;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
         }
     };
 
-    for (long long it = blockIdx.x; it < iters; it += gridDim.x) {
+    for (long long it = bx; it < iters; it += gx) {
         const long long blk = it * nwaves + wave;
         if (blk < nblocks) {
             const long long read0 = seg_lo + (blk << 6);
@@ -402,6 +402,39 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
     }
     __syncthreads();
     flush_dn(); flush_pos();
+}
+
+template <bool SPLIT, int DN = K1V3_DNREP, bool NIB = false, int KJ = 0>
+__global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    k1v3_body<SPLIT, DN, NIB, KJ>(p, lds, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
+}
+
+// ONE launch over all length bands of a mixed-length input (BASELINE config 5; recalibrate.py:81-101 grows its arrays as the
+// reads get longer, the file path cuts the reads into bands of one row width each: kbbq/fastx.py BAND_CLASSES).  A launch
+// per band is 9-10 iterations per workgroup for the narrow bands -- pipeline fill, table zeroing and the final flush of a
+// 100 KB table paid eight times per step; here every band gets its share of the CUs' workgroups (wg_start, by the host:
+// proportional to the band's chunks plus a per-row term) and they all run at once, each workgroup with ITS band's
+// parameters -- row pitch, LDS table geometry for the band's longest / shortest read, copies of the context table.
+#define K1V3_MAX_BANDS 16
+struct K1BandsParams {
+    int nbands;
+    int wg_start[K1V3_MAX_BANDS + 1];     // band b owns workgroups [wg_start[b], wg_start[b + 1]) of blockIdx.x
+    int dn[K1V3_MAX_BANDS];               // copies of the context table: K1V3_DNREP or 8
+    K1v3Params band[K1V3_MAX_BANDS];
+};
+
+template <bool SPLIT, bool NIB>
+__global__ __launch_bounds__(K1V3_THREADS) void k1v3_bands(K1BandsParams t)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    int b = 0;
+    while (b + 1 < t.nbands && (int)blockIdx.x >= t.wg_start[b + 1]) ++b;
+    const K1v3Params& p = t.band[b];
+    const int bx = (int)blockIdx.x - t.wg_start[b], gx = t.wg_start[b + 1] - t.wg_start[b];
+    if (t.dn[b] == K1V3_DNREP) k1v3_body<SPLIT, K1V3_DNREP, NIB, 0>(p, lds, bx, gx, (int)blockIdx.y);
+    else k1v3_body<SPLIT, 8, NIB, 0>(p, lds, bx, gx, (int)blockIdx.y);
 }
 
 // ---------------------------------------------------------------- K2 (table-driven)

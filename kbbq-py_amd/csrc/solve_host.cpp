@@ -280,3 +280,20 @@ int kbbq_combiln_host(const int64_t* errs, const int64_t* total, int64_t n, doub
 }
 
 }  // extern "C"
+
+// The two 43-entry log tables of the solve without importing SciPy (its import was 0.25 s of the command line's warm-up):
+// scipy.stats.binom.logpmf forms xlogy(k, p) + xlog1py(n - k, -p) (compare_reads.py:254 -> scipy/stats/_discrete_distns.py
+// binom_gen._logpmf); for real arguments SciPy 1.15 evaluates xlogy(x, y) = x * log(y) and xlog1py(x, y) = x * log1p(y) with
+// the C library's log / log1p (measured: bit-equal to libm's on 400 000 arguments; NOT the cephes log1p its xsf headers also
+// carry).  logp[i] = xlogy(1, p[i]), log1mp[i] = xlog1py(1, -p[i]); tests/test_solve_core_host.py compares both with
+// SciPy's own calls, bit for bit, wherever the tests run.
+extern "C" int kbbq_xlogy_tables_host(const double* p, int n, double* logp, double* log1mp)
+{
+    if (n < 0 || (n > 0 && (!p || !logp || !log1mp))) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_xlogy_tables_host: bad argument");
+    for (int i = 0; i < n; ++i) {
+        logp[i] = 1.0 * log(p[i]);
+        log1mp[i] = 1.0 * log1p(-p[i]);
+    }
+    return KBBQ_OK;
+}
+

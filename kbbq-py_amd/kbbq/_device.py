@@ -18,23 +18,48 @@ NQ = MAXSCORE + 1
 _contexts = {}
 
 
+_backend = None          # the module that provides device memory, streams and events: torch, or kbbq._hipmem (use_native_memory)
+
+
+def use_native_memory():
+    """Device memory, page-locked buffers, copies and events from libkbbq_hip's own C ABI (kbbq/_hipmem.py) instead of
+    PyTorch, for the rest of the process: the single-GPU command line calls this before it touches the device and never
+    imports torch (its import, HIP context and kernels' code objects were ~1 s of a 2.4 s command).  Refused once torch
+    tensors are in use (the two kinds of buffers do not mix); multi-GPU runs keep torch for the RCCL process group."""
+    global _backend
+    from . import _hipmem
+    if _backend is not None and _backend is not _hipmem:
+        raise RuntimeError('use_native_memory(): this process already uses torch for device memory')
+    if not _hipmem.cuda.is_available():
+        raise N.KbbqHipError('no HIP device available: kbbq needs an MI355X (gfx950); there is no CPU fallback')
+    _backend = _hipmem
+    return _hipmem
+
+
 def _torch():
-    import torch
-    if not torch.cuda.is_available():
-        raise N.KbbqHipError('torch sees no GPU: kbbq needs an MI355X (gfx950); there is no CPU fallback')
-    return torch
+    global _backend
+    if _backend is None:
+        import torch
+        if not torch.cuda.is_available():
+            raise N.KbbqHipError('torch sees no GPU: kbbq needs an MI355X (gfx950); there is no CPU fallback')
+        _backend = torch
+    return _backend
+
+
+def synchronize():
+    """Wait for everything enqueued on the current device (stage timing)."""
+    if _backend is not None:
+        _backend.cuda.synchronize()
 
 
 def warm_up(device=0):
-    """Everything the first call of a process pays once -- importing torch (and SciPy, which the solve's model
-    constants need), creating the HIP context, loading the code objects of libkbbq_hip and of the torch kernels the
+    """Everything the first call of a process pays once -- importing torch (unless kbbq._hipmem stands in), creating the HIP context, loading the code objects of libkbbq_hip and of the torch kernels the
     path uses -- as a miniature run (64 synthetic pairs: tally, solve, apply), so that a caller can pay it while the
     host reads its input files.  Does nothing the second time."""
     global _warm
     if _warm:
         return
     torch = _torch()
-    import scipy.special                      # noqa: F401
     with torch.cuda.device(device):
         batch = ReadBatch.synthetic(0, 128, 128, seed=1)
         tables = Tables(1, 2 * 150)
@@ -57,7 +82,8 @@ def context(device=None):
     if ctx is None:
         ctx = N.Context(device)
         _contexts[device] = ctx
-    ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+    if torch.__name__ == 'torch':            # without torch the context keeps its own stream (kbbq/_hipmem.py enqueues there too)
+        ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
     return ctx
 
 
@@ -587,6 +613,79 @@ def accumulate(batch, tables, minscore=MINSCORE, check=True, dinuc_minscore=None
                                                   N.ptr(tables.buf)))
     if check:
         ctx.status()
+
+
+def _addr(x):
+    return None if x is None else x.data_ptr()
+
+
+def _band_array(items, outs=None, pluts=None, restore_order=False):
+    """ctypes array of kbbq_band for `items` = [(batch, s_band, s_min)]."""
+    arr = (N.Band * max(len(items), 1))()
+    for k, (batch, s_band, s_min) in enumerate(items):
+        pairs = isinstance(batch, PairBatch)
+        b = arr[k]
+        b.d_seq, b.d_cseq, b.d_qual, b.d_meta = _addr(batch.seq), _addr(batch.cseq), _addr(batch.qual), _addr(batch.meta)
+        b.nrows, b.pitch, b.flags = batch.n, batch.pitch, _row_flags(batch)
+        b.S_band, b.S_min = (0, 0) if pairs else (int(s_band), int(s_min))
+        b.d_seg = _addr(batch.seg)
+        b.d_perm = _addr(batch.perm) if (restore_order and batch.seg is not None) else None
+        b.d_out = None if outs is None else _addr(outs[k])
+        b.d_pair_lut = None if pluts is None else _addr(pluts[k])
+    return arr
+
+
+def accumulate_bands(items, tables, minscore=MINSCORE, check=True, dinuc_minscore=None):
+    """K1 over ALL length bands of a mixed-length input in one launch (kbbq_accumulate_bands_dev: every band on its share of
+    the workgroups, with its own pitch and LDS geometry), adding into `tables`.  items: [(batch, s_band, s_min)] as
+    accumulate() takes them one by one -- same counts; bands the merged kernel does not serve are launched alone."""
+    if not items:
+        return
+    dev_ = items[0][0].seq.device
+    ctx = context(dev_.index)
+    for batch, _, _ in items:
+        if isinstance(batch, PairBatch) and tables.S2 != 2 * batch.S:
+            raise ValueError('mate-pair rows of %d-base reads need tables with 2S = %d columns' % (batch.S, 2 * batch.S))
+    dm = minscore if dinuc_minscore is None else dinuc_minscore
+    arr = _band_array(items)
+    N.check(N.load().kbbq_accumulate_bands_dev(ctx.handle, arr, len(items), tables.R, tables.S2, minscore, dm, N.ptr(tables.buf)))
+    if check:
+        ctx.status()
+
+
+def apply_bands(items, lut_dev, shape, outs=None, minscore=MINSCORE, check=True, restore_order=False):
+    """K2 over all length bands in one launch (kbbq_apply_bands_dev); returns the list of output planes (outs, or fresh
+    ones).  The table-driven LUT only (a shape the fast kernels cannot serve raises LutNeedsCheckedApply before anything
+    is launched: apply() band by band has the checked kernel)."""
+    torch = _torch()
+    R, Qt, S2, mode = shape
+    if not items:
+        return []
+    if Qt != NQ or mode != N.APPLY_FAST:
+        raise N.LutNeedsCheckedApply('the merged apply needs the fast LUT of a 43-row model')
+    dev_ = items[0][0].seq.device
+    ctx = context(dev_.index)
+    lib = N.load()
+    if outs is None:
+        outs = [torch.empty_like(b.qual) for b, _, _ in items]
+    pluts = []
+    for batch, _, _ in items:
+        plut = None
+        if isinstance(batch, PairBatch):
+            if S2 != 2 * batch.S:
+                raise N.LutNeedsCheckedApply('this layout needs the fast LUT of a %d-column model' % S2)
+            key = (dev_.index, R, S2)
+            plut = _pair_luts.get(key)
+            if plut is None:
+                plut = torch.empty(lib.kbbq_pair_lut_bytes(R, NQ, S2), dtype=torch.uint8, device=dev_)
+                _pair_luts[key] = plut
+            N.check(lib.kbbq_pair_lut_rows_dev(ctx.handle, N.ptr(lut_dev), R, S2, minscore, _row_flags(batch), N.ptr(plut)))
+        pluts.append(plut)
+    arr = _band_array(items, outs, pluts, restore_order)
+    N.check(lib.kbbq_apply_bands_dev(ctx.handle, arr, len(items), R, S2, minscore, N.ptr(lut_dev)))
+    if check:
+        ctx.status()
+    return outs
 
 
 def build_lut(meanq, rgdq, qdq, posdq, dinucdq, minscore=MINSCORE):

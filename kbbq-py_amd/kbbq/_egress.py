@@ -111,8 +111,8 @@ def emit_records(text, base, bands, outs, slab=1 << 18, sink=None):
                                          band.get('out_S2', 0)).tobytes().decode('latin-1'), end='')
         sys.stdout.flush()
         return
-    import torch
     from . import _device as dev
+    torch = dev._torch()
     widest = max([band['pitch'] for band in bands] + [16])
     made = [0]
 

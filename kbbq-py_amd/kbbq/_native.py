@@ -47,6 +47,13 @@ PROTOTYPES = {
     'kbbq_dev_zero': (_i, [_vp, _vp, _sz]),
     'kbbq_dev_upload': (_i, [_vp, _vp, _vp, _sz]),
     'kbbq_dev_download': (_i, [_vp, _vp, _vp, _sz]),
+    'kbbq_host_alloc': (_i, [_sz, _c.POINTER(_vp)]),
+    'kbbq_host_free': (_i, [_vp]),
+    'kbbq_dev_copy_async': (_i, [_vp, _vp, _vp, _sz, _i]),
+    'kbbq_event_create': (_i, [_vp, _c.POINTER(_vp)]),
+    'kbbq_event_record': (_i, [_vp, _vp]),
+    'kbbq_event_sync': (_i, [_vp]),
+    'kbbq_event_destroy': (_i, [_vp]),
     'kbbq_tables_count': (_sz, [_i, _i]),
     'kbbq_lut_count': (_sz, [_i, _i, _i]),
     'kbbq_accumulate_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
@@ -64,6 +71,7 @@ PROTOTYPES = {
     'kbbq_combiln_host': (_i, [_vp, _vp, _i64, _vp, _i]),
     'kbbq_solve_prep_host': (_i, [_vp, _i, _i, _vp, _vp, _i]),
     'kbbq_gammaln_host': (_i, [_vp, _i64, _vp]),
+    'kbbq_xlogy_tables_host': (_i, [_vp, _i, _vp, _vp]),
     'kbbq_libm_log_data': (_i, [_vp, _i]),
     'kbbq_gammaln_restated_host': (_i, [_vp, _i64, _vp, _vp]),
     'kbbq_gammaln_dev': (_i, [_vp, _vp, _i64, _vp, _vp]),
@@ -136,6 +144,18 @@ PROTOTYPES = {
     'kbbq_ctx_timing': (_i, [_vp, _i]),
     'kbbq_ctx_kernel_ms': (_i, [_vp, _i, _c.POINTER(_c.c_double), _c.POINTER(_i64), _i]),
 }
+
+
+
+class Band(ctypes.Structure):
+    """kbbq_band (include/kbbq_hip.h): one length band of a mixed-length input for kbbq_accumulate_bands_dev / kbbq_apply_bands_dev."""
+    _fields_ = [('d_seq', _vp), ('d_cseq', _vp), ('d_qual', _vp), ('d_meta', _vp), ('nrows', _i64), ('pitch', _c.c_int32),
+                ('flags', _c.c_int32), ('S_band', _c.c_int32), ('S_min', _c.c_int32), ('d_seg', _vp), ('d_perm', _vp),
+                ('d_out', _vp), ('d_pair_lut', _vp)]
+
+
+PROTOTYPES['kbbq_accumulate_bands_dev'] = (_i, [_vp, _c.POINTER(Band), _i, _i, _i, _i, _i, _vp])
+PROTOTYPES['kbbq_apply_bands_dev'] = (_i, [_vp, _c.POINTER(Band), _i, _i, _i, _i, _vp])
 
 _lib = None
 

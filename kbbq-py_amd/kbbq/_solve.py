@@ -29,7 +29,21 @@ def model_consts():
     prior = utils.RescaledNormal.prior_dist.astype(np.float64)
     assert np.all((prior.astype(np.longdouble) == utils.RescaledNormal.prior_dist)
                   | ~np.isfinite(prior))
-    import scipy.special                      # lazily: 0.15 s of the command line's start-up otherwise
+    # xlogy(1, p) and xlog1py(1, -p) as SciPy evaluates them, by the library's restatement (csrc/solve_host.cpp: the C
+    # library's log and log1p) -- importing scipy.special here was 0.25 s of the command line's warm-up;
+    # tests/test_solve_core_host.py compares the tables with SciPy's bit for bit
+    from . import _native as N
+    p = np.ascontiguousarray(p)
+    logp, log1mp = np.empty(NQ), np.empty(NQ)
+    N.check(N.load().kbbq_xlogy_tables_host(N.ptr(p), NQ, N.ptr(logp), N.ptr(log1mp)))
+    return np.ascontiguousarray(np.concatenate([prior, logp, log1mp]))
+
+
+def model_consts_scipy():
+    """The same three tables with SciPy's own xlogy / xlog1py calls: the definition model_consts() is tested against."""
+    import scipy.special
+    p = utils.q_to_p(np.arange(NQ, dtype=np.int_)).astype(np.float64)
+    prior = utils.RescaledNormal.prior_dist.astype(np.float64)
     with np.errstate(divide='ignore'):
         logp = scipy.special.xlogy(1.0, p)
         log1mp = scipy.special.xlog1py(1.0, -p)

@@ -34,9 +34,8 @@ def stage(name, sync=False):
         yield
     finally:
         if sync:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
+            from . import _device
+            _device.synchronize()
         with _lock:                       # several threads may close the same stage (the positioned writers)
             s, k = _acc.get(name, (0.0, 0))
             _acc[name] = (s + time.perf_counter() - t0, k + 1)

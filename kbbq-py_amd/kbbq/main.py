@@ -10,8 +10,14 @@ from . import recalibrate as _recal
 
 
 def recalibrate(args):
+    import os
     from . import parallel
-    parallel.init_from_env()          # one process per GPU under torch.distributed.run; no-op otherwise
+    world, _ = parallel.init_from_env()          # one process per GPU under torch.distributed.run; no-op otherwise
+    if world == 1 and 'torch' not in __import__('sys').modules and not os.environ.get('KBBQ_USE_TORCH'):
+        # one GPU: nothing of PyTorch is needed -- device memory, page-locked slabs, copies and events come from the library's
+        # own C ABI (kbbq/_hipmem.py) and `import torch` (~1 s with its HIP context) never happens
+        from . import _device
+        _device.use_native_memory()
     _recal.recalibrate(bam=args.bam, fastq=args.fastq, infer_rg=args.infer_rg,
                        use_oq=args.use_oq, set_oq=args.set_oq, gatkreport=args.gatkreport, output=args.output)
 

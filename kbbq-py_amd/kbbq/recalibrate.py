@@ -74,7 +74,23 @@ def _tally_local(packed, minscore, maxscore):
                 band['laid'] = None          # bad input or an unsupported shape: the row-per-read kernel decides
         dev.accumulate(fastx.band_rows(band), tables, minscore, **hints)
 
+    # several length bands (a mixed-length input, BASELINE config 5): ONE launch over all of them, each band on its share of
+    # the workgroups (kbbq_accumulate_bands_dev); whatever any band's kernel reports sends them all band by band below, where
+    # each has its own fallback and the first offending read is found
+    done = set()
+    several = [b for b in packed['bands'] if 'source' in b and b.get('laid') is not None]
+    if len(several) >= 2:
+        part = dev.Tables(R, 2 * S)
+        try:
+            with stage('K1', sync=True):
+                dev.accumulate_bands([(b['laid'], b['S'], b.get('Smin', 0)) for b in several], part, minscore)
+            tables.add(part)
+            done = {id(b) for b in several}
+        except (IndexError, TypeError, ValueError, dev.N.LutNeedsCheckedApply):
+            pass
     for band in packed['bands']:
+        if id(band) in done:
+            continue
         if 'source' in band:
             laid = band.get('laid')                    # written by the packer in its layout (fastx._fill_bands): nothing to convert
         else:                                          # host planes of a caller's own: tallied and applied as they are -- a
@@ -109,7 +125,7 @@ def _tally(packed, minscore, maxscore):
 def _warm_up():
     """The process's one-time device costs (dev.warm_up), paid while the C++ reader works on the input files."""
     import sys
-    torch = sys.modules.get('torch')         # the device this process selected (parallel.init_from_env), else 0
+    torch = dev._backend or sys.modules.get('torch')         # the device this process selected (parallel.init_from_env), else 0
     device = torch.cuda.current_device() if torch is not None and torch.cuda.is_available() else 0
     with stage('warm-up'):
         dev.warm_up(device)
@@ -274,8 +290,22 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None, output=None):
         return out
 
     def apply_shard():
+        merged = {}
+        several = [b for b in single['bands'] if b.get('laid') is not None]
+        if len(several) >= 2:                 # all length bands in one launch (kbbq_apply_bands_dev); any trouble: band by band
+            try:
+                res = dev.apply_bands([(b['laid'], b['S'], b.get('Smin', 0)) for b in several], lut, shape, restore_order=True)
+                for b, o in zip(several, res):
+                    merged[id(b)] = o
+                    two = isinstance(b['laid'], dev.PairBatch)
+                    b['out_flags'], b['out_S2'] = (dev.N.ROWS_PAIRS, 2 * b['laid'].S) if two else (0, 0)
+            except (IndexError, TypeError, ValueError, dev.N.LutNeedsCheckedApply):
+                merged = {}
         outs = []
         for band in single['bands']:
+            if id(band) in merged:
+                outs.append(merged[id(band)])
+                continue
             try:
                 outs.append(apply_band(band))
             except (IndexError, TypeError, ValueError) as e:

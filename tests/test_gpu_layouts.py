@@ -368,3 +368,63 @@ def test_the_packer_writes_the_rows_the_layout_pass_writes(dev, tmp_path, n, S, 
             if R > 1:
                 assert np.array_equal(got.perm.cpu().numpy(), want.perm.cpu().numpy()) and np.array_equal(got.seg.cpu().numpy(), want.seg.cpu().numpy())
     assert not [k for k in dev._pinned if k[0] == 'ingest']
+
+
+@pytest.mark.parametrize('R,n,S', [(1, 40000, 290), (3, 24000, 290), (1, 600, 290), (1, 30000, 150), (2, 9000, 150)])
+def test_all_length_bands_in_one_launch(dev, R, n, S, monkeypatch):
+    """kbbq_accumulate_bands_dev / kbbq_apply_bands_dev (one K1 and one K2 launch over the length bands of a mixed-length
+    input, every band on its share of the workgroups) against a launch per band on the same bands: identical count
+    tables, identical new qualities -- bands of 4-bit rows at every pitch the file path cuts (merged), a band of character
+    planes and a band of mate-pair rows at the tables' full width (each launched alone by the same call), with one read
+    group and with rows gathered by read-group segment (K1 merged over grid.y, K2 band by band)."""
+    import torch
+    spans = [(36, 48), (49, 64), (65, 96), (97, 128), (129, 160), (161, 208), (209, 256), (257, 290)]
+    if S == 150:                                           # ... and a top band of uniform 2 x 150 pairs: mate-pair rows
+        spans = [(20, 32), (36, 48), (49, 64), (65, 96), (97, 128), (129, 149)]
+    items, first = [], 0
+    for k, (lo, hi) in enumerate(spans):
+        b = dev.ReadBatch.synthetic(first, n, 10 * n, seed=31 + k, len_lo=lo, len_hi=hi, nrg=R)
+        first += n
+        st = dev.meta_stats(b)
+        packed = k != 4                                   # one band keeps character planes
+        laid = dev.lay_out(b, R, st['longest'], packed=packed, pairs=False, stats=st)
+        if laid is b:
+            assert not packed and R == 1
+        items.append((laid, st['longest'], st['shortest']))
+    alone = 1                                              # the character band
+    if S == 150:
+        top = dev.ReadBatch.synthetic(first, n, 10 * n, seed=77, len_lo=S, len_hi=S, nrg=R)     # uniform pairs of the longest length
+        laid = dev.lay_out(top, R, S, packed=True)
+        assert isinstance(laid, dev.PairBatch) and laid.nib
+        items.append((laid, S, S))
+        alone += 1                                         # 19 chunks per row: the chunk-position-major K1, launched alone
+    want_t = dev.Tables(R, 2 * S)
+    for b, smax, smin in items:
+        dev.accumulate(b, want_t, s_band=smax, s_min=smin)
+    got_t = dev.Tables(R, 2 * S)
+    ctx = dev.context()
+    ctx.kernel_ms(0, reset=True); ctx.timing(True)
+    dev.accumulate_bands(items, got_t)
+    ctx.timing(False)
+    assert 1 + alone <= ctx.kernel_ms(0)[1] <= 2 + alone   # one merged launch per workgroup shape (narrow rows: two workgroups per CU) + the bands it does not take
+    assert torch.equal(got_t.buf, want_t.buf) and int(got_t.buf.sum()) > 0
+    monkeypatch.setenv('KBBQ_K1_BANDS', '0')              # the A/B switch: a launch per band through the same entry point
+    again = dev.Tables(R, 2 * S)
+    dev.accumulate_bands(items, again)
+    assert torch.equal(again.buf, want_t.buf)
+    lut, shape = dev.solve_lut(want_t)
+    for restore in (False, True):
+        want_o = [dev.apply(b, lut, shape, restore_order=restore) for b, _, _ in items]
+        ctx.kernel_ms(1, reset=True); ctx.timing(True)
+        got_o = dev.apply_bands(items, lut, shape, restore_order=restore)
+        ctx.timing(False)
+        assert ctx.kernel_ms(1)[1] == (1 + alone if R == 1 else len(items))
+        for g, w, (b, _, _) in zip(got_o, want_o, items):
+            assert torch.equal(g[:b.n], w[:b.n]), b.describe()
+    # bad input in one band is reported by the merged launch as by its own
+    bad = items[2][0]
+    bad.qual[5, 3] = 33 + 43
+    with pytest.raises((IndexError, dev.N.LutNeedsCheckedApply)):
+        dev.accumulate_bands(items, dev.Tables(R, 2 * S))
+    with pytest.raises(dev.N.LutNeedsCheckedApply):
+        dev.apply_bands(items, lut, shape)

@@ -367,6 +367,45 @@ def test_dropin_api_matches_reference_goldens(dev, oracle, name, tmp_path, capfd
     assert text.startswith(info['first_records']) and text.endswith(info['last_records'])
 
 
+@pytest.mark.parametrize('case', GOLDEN_CASES)
+def test_the_command_line_runs_without_torch(dev, oracle, case, tmp_path):
+    """`python -m kbbq.main recalibrate -f A B` on one GPU never imports PyTorch (kbbq/_hipmem.py: device memory, page-locked
+    slabs, copies and events through the library's own C ABI) and prints the reference's bytes: the five golden cases,
+    to stdout and with -o, with the model saved (-g) and loaded back; KBBQ_USE_TORCH=1 gives the same bytes through torch."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    info, _ = load_golden(case)
+    fa, fb = _files(oracle, info, tmp_path)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, 'kbbq-py_amd'))
+    env.pop('KBBQ_USE_TORCH', None)
+    base = [sys.executable, '-X', 'importtime', '-m', 'kbbq.main', 'recalibrate', '-f', fa, fb] + (['--infer-rg'] if info['case']['infer_rg'] else [])
+
+    def imported(stderr):
+        return {ln.split('|')[-1].strip() for ln in stderr.decode().split('\n') if ln.startswith('import time:')}
+    r = subprocess.run(base, env=env, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    mods = imported(r.stderr)
+    assert 'kbbq._hipmem' in mods and not any(m == 'torch' or m.startswith('torch.') for m in mods)
+    assert len(r.stdout) == info['output_len'] and oracle.sha256(r.stdout) == info['output_sha256']
+    out, model = str(tmp_path / 'out.fq'), str(tmp_path / 'model.txt')
+    for extra in (['-o', out], ['-o', out, '-g', model], ['-o', out, '-g', model]):          # save the model, then load it
+        r = subprocess.run(base + extra, env=env, capture_output=True, timeout=300)
+        assert r.returncode == 0 and not r.stdout, r.stderr.decode()[-2000:]
+        assert not any(m == 'torch' for m in imported(r.stderr))
+        assert oracle.sha256(open(out, 'rb').read()) == info['output_sha256'], extra
+    assert os.path.getsize(model) > 500
+    if case == GOLDEN_CASES[0]:
+        r = subprocess.run(base, env=dict(env, KBBQ_USE_TORCH='1'), capture_output=True, timeout=300)
+        assert r.returncode == 0 and 'torch' in imported(r.stderr) and oracle.sha256(r.stdout) == info['output_sha256']
+        # bad input still ends the command with the reference's exception
+        lines = open(fa).read().split('\n')
+        lines[4 * 77 + 3] = lines[4 * 77 + 3][:10] + 'L' + lines[4 * 77 + 3][11:]                  # q = 43
+        bad = str(tmp_path / 'bad.fq')
+        open(bad, 'w').write('\n'.join(lines))
+        r = subprocess.run([sys.executable, '-m', 'kbbq.main', 'recalibrate', '-f', bad, fb], env=env, capture_output=True, timeout=300)
+        assert r.returncode != 0 and b'IndexError' in r.stderr
+
+
 def _write(tmp_path, name, recs):
     p = tmp_path / name
     p.write_text(''.join('@%s\n%s\n+\n%s\n' % r for r in recs))

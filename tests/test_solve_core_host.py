@@ -151,3 +151,19 @@ def test_fused_solve_prep_matches_the_numpy_route():
                 assert np.array_equal(got, w)
             assert np.array_equal(_solve.meanq_from_q_total(q_t), want[0])
     _solve.COMBILN_THREADS = None
+
+
+def test_log_tables_without_scipy_equal_scipys():
+    """_solve.model_consts() (xlogy / xlog1py by the C library's log / log1p, without importing SciPy) against
+    the SciPy calls themselves -- the 129 model constants, and the two functions on a wider sample of probabilities."""
+    from kbbq import _native as N, _solve
+    import scipy.special
+    got, want = _solve.model_consts(), _solve.model_consts_scipy()
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    rng = np.random.default_rng(11)
+    p = np.concatenate([10.0 ** -rng.uniform(0, 12, 200000), rng.uniform(0, 1, 200000), [0.0, 1.0, 0.5, 1 - 2.0 ** -53, 0.2928932188134524, 0.29289321881345254]])
+    logp, log1mp = np.empty_like(p), np.empty_like(p)
+    N.check(N.load().kbbq_xlogy_tables_host(N.ptr(p), p.size, N.ptr(logp), N.ptr(log1mp)))
+    with np.errstate(divide='ignore'):
+        assert np.array_equal(logp.view(np.uint64), scipy.special.xlogy(1.0, p).view(np.uint64))
+        assert np.array_equal(log1mp.view(np.uint64), scipy.special.xlog1py(1.0, -p).view(np.uint64))
