@@ -539,6 +539,10 @@ def extra_aligned(torch, dev, n=4_000_000, L=150, G=200_000_000, ins=0.05, reps=
     def k1(of=packed):
         dev.accumulate(of, tables, 6, check=False, dinuc_minscore=6)
 
+    def k61():                              # K6 fused into K1: the tally straight from the reads as aligned
+        N.check(lib.kbbq_accumulate_aligned_dev(ctx.handle, N.ptr(seq), N.ptr(oq), N.ptr(err), N.ptr(clip), N.ptr(trim), N.ptr(flags), n, pitch, L,
+                                                1, 6, 6, N.ptr(tables.buf)))
+
     out = {'workload': '%d aligned reads x %d bp, %d Mb random genome, %.0f %% of the reads with a 2-base insertion, half '
                        'reverse-strand; HIP events on the launch stream, %d launches each' % (n, L, G // 1000000, ins * 100, reps),
            'bytes_per_base': 'algorithmic, by the arrays of the reference: K4 3 read (read, reference, site mask) + 2 written (errors, '
@@ -550,7 +554,7 @@ def extra_aligned(torch, dev, n=4_000_000, L=150, G=200_000_000, ins=0.05, reps=
     bases = n * L
     for name, fn, bpb in (('k4_find_errors', lambda: k4(flip), 5), ('k5_count_q', k5, 3),
                           ('k4_find_errors_tally', lambda: k4(noflip), 5), ('k6_canonical_reads', k6, 7),
-                          ('k1_on_canonical_reads', k1, 3),
+                          ('k1_on_canonical_reads', k1, 3), ('k61_fused_tally', k61, 3),
                           ('k6_canonical_reads_character_planes', lambda: k6(False, batch), 7),
                           ('k1_on_canonical_reads_character_planes', lambda: k1(batch), 3),
                           ('k4_find_errors_two_planes', lambda: k4(flip, True), 5), ('k5_count_q_two_planes', lambda: k5(True), 3),
@@ -566,6 +570,15 @@ def extra_aligned(torch, dev, n=4_000_000, L=150, G=200_000_000, ins=0.05, reps=
         ms = sum(a.elapsed_time(b) for a, b in evs) / reps
         out[name] = kernel_entry(ms, reps, bases, bpb)
     ctx.status()
+    # the fused kernel counts what K6 -> K1 counts (same K4 flags, same reads): checked here on the bench's own data
+    k4(noflip); tables.buf.zero_(); k6(); k1(); want = tables.buf.clone()
+    tables.buf.zero_(); k61()
+    ctx.status()
+    out['k61_fused_tally']['verified'] = bool(torch.equal(tables.buf, want)) and int(want.sum()) > 0
+    out['whole_tally_ms'] = {'k4_k6_k1': out['k4_find_errors_tally']['avg_ms'] + out['k6_canonical_reads']['avg_ms'] + out['k1_on_canonical_reads']['avg_ms'],
+                             'k4_fused': out['k4_find_errors_tally']['avg_ms'] + out['k61_fused_tally']['avg_ms'],
+                             'note': 'gatk.bqsr.bam_to_bqsr_covariates on the device: K4 (flags) then K6 -> K1 (canonical reads written and read back: 3 + 2 + 2 '
+                                     'B/base) or the fused kernel (kbbq_accumulate_aligned_dev: 3 B/base read, nothing written)'}
     return out
 
 

@@ -304,6 +304,17 @@ int kbbq_canonical_reads_rows_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uin
                                   const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads, int pitch, int S,
                                   int minscore, int dinuc_minscore, int layout, uint8_t* d_out_seq,
                                   uint8_t* d_out_cseq, uint8_t* d_out_qual, uint32_t* d_out_meta);
+/* kbbq_accumulate_aligned_dev: kbbq_canonical_reads_rows_dev + kbbq_accumulate_rows_dev in ONE kernel (K6 fused into K1): the
+ * tally of gatk.bqsr.bam_to_bqsr_covariates (gatk/bqsr.py:52-123) straight from the reads as aligned -- d_seq, d_oq (OQ
+ * characters) and d_flagplane (kbbq_find_errors_dev's one plane of flags: bit 0 error, bit 1 skip) are [nreads, pitch]
+ * planes of reads of the common length S (pitch = S rounded up to 16); d_clip / d_trim / d_flags per read as for
+ * kbbq_canonical_reads_dev.  Counts ADD into d_tables (R, S2 = 2 S).  3 B/base read instead of 3 + 2 written + 2 read
+ * again.  A forward-strand read with a letter outside ACGTN makes kbbq_ctx_status return KBBQ_E_LUT: tally through
+ * kbbq_canonical_reads_rows_dev(layout 0), where the reference's TypeError is decided; a shape whose tables do not fit the
+ * LDS returns KBBQ_E_LUT at once. */
+int kbbq_accumulate_aligned_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_oq, const uint8_t* d_flagplane,
+                                const uint32_t* d_clip, const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads,
+                                int pitch, int S, int R, int minscore, int dinuc_minscore, int64_t* d_tables);
 int kbbq_count_q_dev(kbbq_ctx* ctx, const uint8_t* d_qual, const uint8_t* d_err, const uint8_t* d_skip,
                      const uint32_t* d_len, int64_t nreads, int pitch, int qoffset, int64_t* d_counts512);
 

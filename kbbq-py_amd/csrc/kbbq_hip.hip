@@ -116,6 +116,10 @@ int kbbq_ctx_create(int device, kbbq_ctx** out)
     (void)hipFuncSetAttribute((const void*)(k2v3_apply<true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2t_apply, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2t_bands, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_aligned<false, K1V3_DNREP>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_aligned<true, K1V3_DNREP>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_aligned<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_aligned<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k1v3_bands<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k1v3_bands<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k1v3_bands<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
@@ -869,6 +873,7 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     HIPCHK(hipSetDevice(c->device));
     const int S = S_band ? S_band : S2 / 2;          // the LDS tables are laid out for the longest read of THIS batch
     K1v3Params q;
+    q.aflags = nullptr; q.aclip = nullptr; q.atrim = nullptr;
     q.seq = d_seq; q.cseq = d_cseq; q.qual = d_qual; q.meta = d_meta;
     q.nreads = nrows; q.pitch = pitch; q.cpr = pitch / 16; q.cpr_magic = magic_for(q.cpr);
     q.R = R; q.S = S; q.gS2 = S2; q.minscore = minscore; q.type_minscore = dinuc_minscore;
@@ -1549,6 +1554,64 @@ int kbbq_canonical_reads_rows_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8
     const int gx = bounded_grid((nreads + rpb6 - 1) / rpb6, c, 64, "KBBQ_K6_GRID");
     if (layout & KBBQ_ROWS_NIBBLES) hipLaunchKernelGGL(k6_canonical_reads<true>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     else hipLaunchKernelGGL(k6_canonical_reads<false>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
+// K6 fused into K1 (k1v3_aligned): the BAM-sourced tally straight from the reads as aligned -- 3 B/base read (sequence, OQ,
+// K4's plane of flags), nothing written but the count tables; kbbq_canonical_reads_rows_dev + kbbq_accumulate_rows_dev moved
+// 3 + 2 + 2 B/base for the same tables.
+int kbbq_accumulate_aligned_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_oq, const uint8_t* d_flagplane,
+                                const uint32_t* d_clip, const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads,
+                                int pitch, int S, int R, int minscore, int dinuc_minscore, int64_t* d_tables)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    int rc = check_planes("kbbq_accumulate_aligned_dev", nreads, pitch, d_seq, d_oq, d_flagplane);
+    if (rc) return rc;
+    if (S <= 0 || S > pitch || S > 32767 || pitch != ((S + 15) & ~15)) return fail(KBBQ_E_ARG, "kbbq_accumulate_aligned_dev: rows of S = %d bases have pitch %d (got %d)", S, (S + 15) & ~15, pitch);
+    if (R <= 0 || R > 32767) return fail(KBBQ_E_ARG, "kbbq_accumulate_aligned_dev: R out of range (%d)", R);
+    if (minscore < 0 || minscore > KQ - 1 || dinuc_minscore < 0 || dinuc_minscore > 94) return fail(KBBQ_E_ARG, "kbbq_accumulate_aligned_dev: minscore out of range");
+    if (nreads == 0) return KBBQ_OK;
+    if (!d_seq || !d_oq || !d_flagplane || !d_clip || !d_trim || !d_flags || !d_tables) return fail(KBBQ_E_ARG, "kbbq_accumulate_aligned_dev: NULL pointer");
+    HIPCHK(hipSetDevice(c->device));
+    K1v3Params q;
+    memset(&q, 0, sizeof q);
+    q.seq = d_seq; q.cseq = d_flagplane; q.qual = d_oq; q.meta = nullptr;
+    q.aflags = d_flags; q.aclip = d_clip; q.atrim = d_trim;
+    q.nreads = nreads; q.pitch = pitch; q.cpr = pitch / 16; q.cpr_magic = magic_for(q.cpr);
+    q.R = R; q.S = S; q.gS2 = 2 * S; q.minscore = minscore; q.type_minscore = dinuc_minscore;
+    q.qlo_m1 = 32u + (u32)minscore; q.dlo = 33u + (u32)dinuc_minscore;
+    q.nrows = KQ + 1 - minscore;
+    q.maxlen = S; q.gap = 0; q.twins = 0; q.seg = nullptr;
+    q.tables = reinterpret_cast<u64*>(d_tables); q.status = c->d_status;
+    // LDS geometry as accumulate_rows: 3S words per cycle row (every read has length S: [0, S) read 1, [S, 2S) read 2 mirrored);
+    // 16 copies of the context table, or 8 when that does not fit
+    int dn = 0; size_t lds3 = 0;
+    for (int copies : {K1V3_DNREP, 8}) {
+        const int words = (3 * S) | 1;
+        // minlen = S: the flush walks columns [0, 2S) only -- the words behind them take the uncounted bytes in front of a read's
+        // first aligned base (kernel comment) and are never read
+        q.row_bytes = (u32)words * 4u; q.minlen = S; q.slack_bytes = (u32)(S + 32) * 4u;
+        q.dn_flush_iters = std::max(1, 65535 / ((K1V3_THREADS / copies) * 16 * q.cpr));
+        lds3 = (size_t)q.nrows * 128 * copies + (size_t)q.nrows * q.row_bytes + q.slack_bytes;
+        if (lds3 <= (size_t)c->lds_bytes && (K1V3_THREADS / copies) * 16 * q.cpr <= 65535) { dn = copies; break; }
+    }
+    if (!dn) return fail(KBBQ_E_LUT, "kbbq_accumulate_aligned_dev: %d-base reads with minscore %d do not fit the LDS tables; tally through kbbq_canonical_reads_rows_dev", S, minscore);
+    const bool split = dinuc_minscore > minscore;
+    const int64_t nblocks = (nreads + 63) / 64;
+    const int64_t iters = (nblocks + (K1V3_THREADS / 64) - 1) / (K1V3_THREADS / 64);
+    const int gx = (int)std::min<int64_t>(iters, std::max(1, c->cus / R));
+    dim3 grid((unsigned)gx, (unsigned)R, 1), block(K1V3_THREADS, 1, 1);
+    {
+        Timed t(c, 0);
+        if (dn == K1V3_DNREP) {
+            if (split) hipLaunchKernelGGL((k1v3_aligned<true, K1V3_DNREP>), grid, block, lds3, c->stream, q);
+            else hipLaunchKernelGGL((k1v3_aligned<false, K1V3_DNREP>), grid, block, lds3, c->stream, q);
+        } else {
+            if (split) hipLaunchKernelGGL((k1v3_aligned<true, 8>), grid, block, lds3, c->stream, q);
+            else hipLaunchKernelGGL((k1v3_aligned<false, 8>), grid, block, lds3, c->stream, q);
+        }
+    }
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
 }

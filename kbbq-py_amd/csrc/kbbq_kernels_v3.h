@@ -56,6 +56,11 @@ struct K1v3Params {
                                 // 2*len-1-i does not depend on the S the LDS table is laid out for
     const long long* seg;       // rows grouped by read group: slice g owns rows [seg[g], seg[g + 1]); NULL: every slice scans all rows
     u64* tables; u64* status;
+    // ALN form (aligned reads tallied in place, K6 fused into K1: see k1v3_body): seq = the reads as aligned, cseq = K4's plane of
+    // flags (bit 0 error, bit 1 skip), qual = the OQ characters; per read, instead of `meta`:
+    const u32* aflags;          // bit 0 reverse strand, bit 1 read 2, bits 16.. read group
+    const u32* aclip;           // query_alignment_start | query_alignment_end << 16
+    const u32* atrim;           // skipped range lo | hi << 16 (adaptor; lo == hi: none)
 };
 
 // nucleotide decode of 4 bases: code (A0 T1 G2 C3, N/other 4), 5*code, and the character each
@@ -107,9 +112,22 @@ __device__ __forceinline__ u32 chars_to_codes(u32 w, u32& bad)
 // 4 codes as bytes -> their characters
 __device__ __forceinline__ u32 codes_to_chars(u32 c) { return __builtin_amdgcn_perm(0x4E4E4E4Eu, 0x43475441u, c & 0x07070707u); }
 
+// 0x01 in every byte of x that is non-zero
+__device__ __forceinline__ u32 nonzero_bytes(u32 x)
+{
+    return ((x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u;
+}
+
+__device__ __forceinline__ void reverse16(u32 v[4])                      // byte i <- byte 15 - i
+{
+    const u32 a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+    v[0] = __builtin_amdgcn_perm(0u, a3, 0x00010203u); v[1] = __builtin_amdgcn_perm(0u, a2, 0x00010203u);
+    v[2] = __builtin_amdgcn_perm(0u, a1, 0x00010203u); v[3] = __builtin_amdgcn_perm(0u, a0, 0x00010203u);
+}
+
 typedef __attribute__((address_space(3))) u32 lds_u32;
 
-struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int k; int j; int nb; };
+struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int k; int j; int nb; u32 fl, clip, trim; int jj; };
 
 // LDS: dn [nrows][32][16] u32 context counts (errs << 16 | total), 16 copies (copy = lane & 15:
 //          the table is tiny and hot -- measured 15 LDS cycles per wave-atomic unreplicated --
@@ -131,9 +149,19 @@ struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int k; int j; int nb; };
 // sequence planes had made K1 LDS-bound.  The per-base offset 4 * k * KJ is an instruction immediate.
 // The kernel's body: workgroup `bx` of the `gx` that share this batch (k1v3_accumulate: the whole grid; k1v3_bands: the
 // workgroups one length band was given), read-group slice `g`.
-template <bool SPLIT, int DN, bool NIB, int KJ>
+// ALN (K6 fused into K1, gatk/bqsr.py:52-123 in one pass over the aligned reads instead of K6 writing canonical reads for K1 to
+// read back): the lane's chunk is 16 bytes of the read AS ALIGNED -- for a reverse-strand read the chunks are taken last to
+// first and byte-reversed in registers, bases complemented on their codes (A0 T1 G2 C3: code ^ 1), so that lane order and
+// byte order are sequencing order for either strand and everything below the prologue is the FASTQ kernel's: canonical
+// position c = i - qs (forward) or qe - 1 - i (reverse) is the cycle, read 2 takes the mirrored columns, the previous base
+// in sequencing order gives the context.  A base is uncounted (quality byte 0 -> trash row) outside the aligned part
+// [qs, qe), inside the trimmed range, where K4 set the skip flag or where it is N (bqsr.py:86-88); bases outside the
+// aligned part are no context either (code 4).  The error flag is K4's bit 0.  A forward read with a letter outside ACGTN
+// is reported (ST_LUT): the caller repeats the tally through K6's character planes, where the reference's TypeError is decided.
+template <bool SPLIT, int DN, bool NIB, int KJ, bool ALN = false>
 __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const int bx, const int gx, const int g)
 {
+    static_assert(!ALN || (!NIB && KJ == 0), "the aligned-read form reads character planes");
     const int dn_words = p.nrows * 32 * DN;
     const int pos_words = p.nrows * (int)(p.row_bytes >> 2) + (int)(p.slack_bytes >> 2);
     u32* dnt = lds;
@@ -225,7 +253,15 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
         if (blk < nblocks) {
             const long long read0 = seg_lo + (blk << 6);
             const long long myread = read0 + lane;
-            const u32 m = myread < seg_hi ? p.meta[myread] : 0u;
+            u32 m, afl = 0u, aclip = 0u, atrim = 0u;
+            if constexpr (ALN) {
+                afl = myread < seg_hi ? p.aflags[myread] : 0u;
+                aclip = myread < seg_hi ? p.aclip[myread] : 0u;
+                atrim = myread < seg_hi ? p.atrim[myread] : 0u;
+                m = myread < seg_hi ? ((u32)p.S | ((afl >> 16) << 16) | ((afl & 2u) << 30)) : 0u;     // every read has the common length S
+            } else {
+                m = myread < seg_hi ? p.meta[myread] : 0u;
+            }
             const bool match = myread < seg_hi && (int)((m >> 16) & 0x7FFFu) == g && (m & 0xFFFFu) != 0u;
             const u64 mask = __ballot(match);
             const int n = __popcll(mask);
@@ -235,6 +271,11 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                 const int dst = match ? rank : 63;
                 cm = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)(match ? m : 0u));
                 coff = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)(match ? (u32)lane : 0u));
+                if constexpr (ALN) {
+                    afl = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)(match ? afl : 0u));
+                    aclip = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)(match ? aclip : 0u));
+                    atrim = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)(match ? atrim : 0u));
+                }
             }
             const uint8_t* bseq = p.seq + (size_t)read0 * (NIB ? p.pitch >> 1 : p.pitch);
             const uint8_t* bcseq = p.cseq + (size_t)read0 * (NIB ? p.pitch >> 1 : p.pitch);
@@ -257,9 +298,14 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                 ch.mk = bperm(cm, k);
                 ch.off = n == 64 ? (u32)k : bperm(coff, k);
                 ch.nb = act0 ? ((int)(ch.mk & 0xFFFFu) - 16 * ch.j) : 0;
+                ch.jj = ch.j;
+                if constexpr (ALN) {
+                    ch.fl = bperm(afl, k); ch.clip = bperm(aclip, k); ch.trim = bperm(atrim, k);
+                    if (ch.fl & 1u) ch.jj = p.cpr - 1 - ch.j;          // a reverse-strand read: its chunks last to first
+                }
                 // lanes without work re-read the block's first chunk (valid memory, result unused)
 #ifndef KBBQ_ABL_NOLOAD
-                const u32 rowoff = ch.nb > 0 ? __umul24(ch.off, (u32)p.pitch) + (u32)(16 * ch.j) : 0u;
+                const u32 rowoff = ch.nb > 0 ? __umul24(ch.off, (u32)p.pitch) + (u32)(16 * ch.jj) : 0u;
 #else
                 const u32 rowoff = (u32)lane * 16u;      // timing only: every step re-reads the same cached KiB
 #endif
@@ -285,7 +331,49 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                 // byte-parallel decode; alphabet and q-range screening (no byte masks: bytes past
                 // the read are 'N' in seq/cseq and 0 in qual by the layout contract; anything else
                 // only costs a visit to the exact checker)
-                u32 code[4], code5[4], xw[4], badbits = 0u, hiq = 0u;
+                u32 code[4], code5[4], xw[4], qv[4], badbits = 0u, hiq = 0u;
+                int c0 = pos0;                       // canonical position (= cycle) of the chunk's byte 0
+                if constexpr (ALN) {
+                    // the prologue of the aligned-read form (see above): from 16 bytes of the read as aligned to codes, error
+                    // flags and qualities in sequencing order
+                    const bool rev = (ch.fl & 1u) != 0u;
+                    const int qs = (int)(ch.clip & 0xFFFFu), qe = (int)(ch.clip >> 16);
+                    const int tlo = (int)(ch.trim & 0xFFFFu), thi = (int)(ch.trim >> 16);
+                    const int i0 = 16 * ch.jj;                                       // position in the read of the loaded byte 0
+                    auto bits = [](int lo, int hi) -> u32 {                          // bit b set for lo <= b < hi, 0 <= b < 16
+                        lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo); hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
+                        return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+                    };
+                    u32 aligned = bits(qs - i0, qe - i0);                            // inside the aligned part
+                    u32 counted = aligned & ~bits(tlo - i0, thi - i0);               // ... and not trimmed away (adaptor)
+                    u32 sv[4] = {ch.s[0], ch.s[1], ch.s[2], ch.s[3]}, fv[4] = {ch.c[0], ch.c[1], ch.c[2], ch.c[3]};
+                    u32 ov[4] = {ch.q[0], ch.q[1], ch.q[2], ch.q[3]};
+                    if (rev) {
+                        reverse16(sv); reverse16(fv); reverse16(ov);
+                        aligned = __brev(aligned) >> 16; counted = __brev(counted) >> 16;
+                    }
+                    c0 = rev ? qe - i0 - 16 : i0 - qs;
+                    const u32 rev1 = rev ? 0x01010101u : 0u;
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) {
+                        const u32 am = (((aligned >> (4 * wd)) & 0xFu) * 0x00204081u & 0x01010101u) * 0xFFu;    // 4 bits -> 4 byte masks
+                        const u32 cm_ = (((counted >> (4 * wd)) & 0xFu) * 0x00204081u & 0x01010101u) * 0xFFu;
+                        u32 cd, cd5, expect;
+                        decode4x(sv[wd], cd, cd5, expect);
+                        const u32 odd = nonzero_bytes(expect ^ sv[wd]) * 0xFFu;      // letters that are none of ACGTN
+                        badbits |= rev ? 0u : (odd & am);                            // a forward read keeps its letters: all must be ACGTN
+                        cd = (cd & ~odd) | (0x04040404u & odd);                      // reverse strand: complement.get(x, 'N') (bqsr.py:43-45)
+                        const u32 not_n = nonzero_bytes(sv[wd] ^ 0x4E4E4E4Eu);       // bqsr.py:86-88: an N is skipped
+                        const u32 skipped = ((fv[wd] >> 1) & 0x01010101u) | (not_n ^ 0x01010101u);
+                        cd ^= (~cd >> 2) & rev1;                                     // complement on codes (A0 T1 G2 C3; 4 stays 4)
+                        cd = (cd & am) | (0x04040404u & ~am);                        // outside the aligned part: no base, no context
+                        code[wd] = cd; code5[wd] = (cd << 2) + cd;
+                        xw[wd] = fv[wd] & 0x01010101u;                               // K4's error flag
+                        qv[wd] = ov[wd] & cm_ & ~(skipped * 0xFFu);
+                    }
+                } else {
+                    qv[0] = ch.q[0]; qv[1] = ch.q[1]; qv[2] = ch.q[2]; qv[3] = ch.q[3];
+                }
                 if constexpr (NIB) {
                     code[0] = nib_lo(ch.s[0]); code[1] = nib_hi(ch.s[0]); code[2] = nib_lo(ch.s[1]); code[3] = nib_hi(ch.s[1]);
                     const u32 x0 = ch.s[0] ^ ch.c[0], x1 = ch.s[1] ^ ch.c[1];        // recalibrate.py:13-20 on codes
@@ -296,20 +384,20 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                 for (int wd = 0; wd < 4; ++wd) {
                     if constexpr (NIB) {
                         code5[wd] = (code[wd] << 2) + code[wd];
-                    } else {
+                    } else if constexpr (!ALN) {
                         u32 expect;
                         decode4x(ch.s[wd], code[wd], code5[wd], expect);
                         badbits |= expect ^ ch.s[wd];
                         xw[wd] = ch.s[wd] ^ ch.c[wd];
                     }
-                    hiq |= (ch.q[wd] + 0x34343434u) | ch.q[wd];                      // bit 7 of a byte: q > 42
+                    hiq |= (qv[wd] + 0x34343434u) | qv[wd];                          // bit 7 of a byte: q > 42
                 }
                 hiq &= 0x80808080u;
                 const u32 last_code5 = code5[3] >> 24;
                 u32 prev_code5 = wave_shr1(last_code5, carry_code);
                 carry_code = (u32)__builtin_amdgcn_readlane((int)last_code5, 63);
                 u32 prev_char = 0u;
-                if constexpr (!NIB) {
+                if constexpr (!NIB && !ALN) {
                     const u32 last_char = ch.s[3] >> 24;
                     prev_char = wave_shr1(last_char, carry_char);
                     carry_char = (u32)__builtin_amdgcn_readlane((int)last_char, 63);
@@ -319,17 +407,25 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                     const long long read = read0 + ch.off;
                     const bool fits_tables = (u32)(len - p.minlen) <= (u32)(p.maxlen - p.minlen);
                     if (hiq || !fits_tables) flag(p.status, ST_INDEX, read);         // recalibrate.py:114-115; read longer (shorter) than the tables
-                    if constexpr (NIB) {
-                        if (badbits) flag(p.status, ST_LUT, 0);                      // the caller must use byte planes
+                    if constexpr (NIB || ALN) {
+                        if (badbits) flag(p.status, ST_LUT, 0);                      // the caller must use byte planes (ALN: K6's character planes)
                     } else {
                         if (badbits && chunk_type_error(ch.s[0], ch.s[1], ch.s[2], ch.s[3], ch.q[0], ch.q[1], ch.q[2], ch.q[3],
                                                         prev_char, nb, pos0, p.type_minscore))
                             flag(p.status, ST_TYPE, read);                           // compare_reads.py:224,292
                     }
-                    if (!hiq && fits_tables && !(NIB && badbits)) {
+                    if (!hiq && fits_tables && !((NIB || ALN) && badbits)) {
                         // A: pos address less the row term; both mates ascend with the base index
                         const u32 half = second ? (u32)(S + 2 * (S - len)) : 0u;     // column 2*len-1-pos
                         const u32 A = KJ > 0 ? pos_base + 4u * (u32)j : pos_base + (half + (u32)pos0) * 4u;
+                        // ALN: bases before the aligned part have NEGATIVE canonical positions.  They are uncounted, i.e. they land on
+                        // the trash row (the last one) -- up to 15 words before its start when the chunk holds the first aligned
+                        // base: the tail of the row before it, which this form never uses and never flushes (every read has length S:
+                        // columns < 2S + 16 of 3S words; the host sets minlen = S, the flush stops at 2S) as long as S >= 32; a chunk
+                        // wholly outside the aligned part is sent to column 0.  Shorter reads take the per-base clamp.
+                        const bool clamp_each = S < 32;
+                        int colA = ((int)half + c0) * 4;
+                        if constexpr (ALN) { if (!clamp_each && colA < -60) colA = 0; }
                         u32 pc5 = prev_code5 << 24;
 #pragma unroll
                         for (int wd = 0; wd < 4; ++wd) {
@@ -337,7 +433,7 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                             const u32 d5 = pw5 + code[wd];                            // 5*prev + cur per byte, <= 24
                             pc5 = code5[wd];
                             const u32 xwd = xw[wd];
-                            const u32 qn = ~ch.q[wd];
+                            const u32 qn = ~qv[wd];
                             const u32 zero = 0u, both = 0x10001u;
                             auto one_base = [&](auto bsel) {
                                 constexpr int b = decltype(bsel)::value;
@@ -348,7 +444,13 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
 #else
                                 const u32 inc = ((xwd >> (8 * b)) & 0xFFu) != 0u ? 0x10001u : 1u;
 #endif
-                                const u32 a = __umul24(tq, row_bytes) + A + (u32)(KJ > 0 ? 4 * KJ * (4 * wd + b) : 4 * (4 * wd + b));
+                                u32 a;
+                                if constexpr (ALN) {
+                                    const int co = colA + 4 * (4 * wd + b);
+                                    a = __umul24(tq, row_bytes) + pos_base + (u32)(clamp_each ? (co > 0 ? co : 0) : co);
+                                } else {
+                                    a = __umul24(tq, row_bytes) + A + (u32)(KJ > 0 ? 4 * KJ * (4 * wd + b) : 4 * (4 * wd + b));
+                                }
 #ifndef KBBQ_ABL_NOPOS
                                 atomicAdd(reinterpret_cast<u32*>(reinterpret_cast<char*>(lds) + a), inc);   // recalibrate.py:116-117
 #else
@@ -409,6 +511,14 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_accumulate(K1v3Params p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     k1v3_body<SPLIT, DN, NIB, KJ>(p, lds, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
+}
+
+// the aligned-read form (K6 fused into K1): the BAM-sourced tally of gatk/bqsr.py:52-123 straight from the reads as aligned
+template <bool SPLIT, int DN>
+__global__ __launch_bounds__(K1V3_THREADS) void k1v3_aligned(K1v3Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    k1v3_body<SPLIT, DN, false, 0, true>(p, lds, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
 }
 
 // ONE launch over all length bands of a mixed-length input (BASELINE config 5; recalibrate.py:81-101 grows its arrays as the
@@ -795,11 +905,6 @@ __device__ __forceinline__ void load16_upto(const uint8_t* base, long long off, 
     for (int b = 0; b < 16 && off + b < limit; ++b) out[b >> 2] |= (u32)base[off + b] << (8 * (b & 3));
 }
 
-// 0x01 in every byte of x that is non-zero
-__device__ __forceinline__ u32 nonzero_bytes(u32 x)
-{
-    return ((x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u;
-}
 
 __device__ __forceinline__ void set_byte(u32 v[4], int i, u32 val)      // i in 0..15, slow paths only
 {
@@ -819,12 +924,6 @@ __device__ __forceinline__ u32 get_byte(const u32 v[4], int i)
 // 0xFF in the bytes of word w (of a 16-byte vector) whose position p = 4w + k lies in [lo, hi)
 __device__ __forceinline__ u32 range_mask(int lo, int hi, int w) { return byte_mask(hi, w) & ~byte_mask(lo, w); }
 
-__device__ __forceinline__ void reverse16(u32 v[4])                      // byte i <- byte 15 - i
-{
-    const u32 a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
-    v[0] = __builtin_amdgcn_perm(0u, a3, 0x00010203u); v[1] = __builtin_amdgcn_perm(0u, a2, 0x00010203u);
-    v[2] = __builtin_amdgcn_perm(0u, a1, 0x00010203u); v[3] = __builtin_amdgcn_perm(0u, a0, 0x00010203u);
-}
 
 __device__ __forceinline__ void shr_bytes16(u32 v[4], int nb)            // byte i <- byte i + nb (0 <= nb <= 15), zero fill
 {

@@ -321,14 +321,20 @@ def benchmark_bam(bamfile, ref, var_sites, use_oq=False, bedfh=None):
     return _actual_q(*_count_q(qual, err, skip, lens, pitch, 0, reduce=world > 1))
 
 
+LAST_RUN = {}            # what the most recent benchmark_fastq flagged on this rank (tests, KBBQ_TIMING): K4's share of the alignments
+
+
 def benchmark_fastq(fqfile, bamfile, ref, var_sites, bedfh=None):
-    """Under torch.distributed every rank counts a contiguous shard of the FASTQ reads (the alignments they map to
-    are anywhere in the file: each rank flags all of them -- K4 is a fraction of the work) and the counts are summed."""
+    """Under torch.distributed every rank counts a contiguous shard of the FASTQ reads and flags (K4) ONLY the
+    alignments its reads map to: the name join of the reference (benchmark.py:93-104) is one host pass every rank makes
+    over the names -- no flags, no bases -- and tells the rank the span of alignment rows [first, last] its shard needs
+    (a FASTQ made from the BAM keeps its order: about 1 / world of the rows); K4 runs over that span, K5 over the shard,
+    and the 512 per-quality counters are summed with one allreduce."""
     from . import _device as dev
+    import sys
     torch = dev._torch()
     fullskips = get_full_skips(ref, var_sites, bedfh)
     reads = bamfile if isinstance(bamfile, aln.AlignmentFile) else list(bamfile)
-    err, skip, lens, pitch = _flag_batch(reads, _Genome(ref, fullskips), flip_reverse=True, fused=True)
     fq = fastx.NativeFastq(fqfile)
     if isinstance(reads, aln.AlignmentFile):
         idx = _match_native(reads, fq)                               # both sides native: no Python object per read
@@ -342,6 +348,24 @@ def benchmark_fastq(fqfile, bamfile, ref, var_sites, bedfh=None):
     lo, hi = parallel.shard_range(fq.n, rank, world) if world > 1 else (0, fq.n)
     m = hi - lo
     idx = idx[lo:hi]
+    nalign = reads.batch().n if isinstance(reads, aln.AlignmentFile) else len(reads)
+    # the rows K4 walks on this rank: what its FASTQ reads map to, and its own contiguous share of the alignments (so that the
+    # ranks together look at EVERY alignment, as get_error_dict does -- bad input is reported whoever's reads map to it)
+    a_lo, a_hi = parallel.shard_range(nalign, rank, world) if world > 1 else (0, nalign)
+    if m:
+        a_lo, a_hi = min(a_lo, int(idx.min())), max(a_hi, int(idx.max()) + 1)
+    genome = _Genome(ref, fullskips)
+
+    def flag_shard():
+        return _flag_batch(reads, genome, flip_reverse=True, fused=True, rows=(a_lo, a_hi))
+    err, skip, lens, pitch = _on_all_ranks(flag_shard, a_lo)
+    LAST_RUN.clear()
+    LAST_RUN.update(rank=rank, world=world, fastq_reads=m, alignments=nalign, k4_alignments=a_hi - a_lo)
+    from . import _trace
+    if _trace.ON:
+        sys.stderr.write('kbbq benchmark: rank %d of %d counts FASTQ reads [%d, %d) and flagged alignments [%d, %d): %d of %d\n'
+                         % (rank, world, lo, hi, a_lo, a_hi, a_hi - a_lo, nalign))
+    idx = idx - a_lo
     _, _, fqual, fmeta = fq.fill(None, False, m, max(pitch, fastx.pitch_for(S)), first=lo)
     flens = (fmeta & 0xFFFF).astype(np.uint32)
 

@@ -229,6 +229,20 @@ def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxsc
                 N.ptr(batch.seq), N.ptr(batch.cseq), N.ptr(batch.qual), N.ptr(batch.meta)))
             ctx.status()
             return batch
+        # K6 fused into K1 (kbbq_accumulate_aligned_dev): the tally straight from the reads as aligned, nothing written but the
+        # tables -- unless a forward read carries a letter outside ACGTN or the tables do not fit the LDS beside it (both
+        # reported before / without anything reaching `tables`: the attempt counts into tables of its own); then, as before:
+        import os
+        if os.environ.get('KBBQ_TALLY_FUSED') != '0' and pitch == (S + 15) // 16 * 16 and S <= 32767:
+            try:
+                part = dev.Tables(max(R, 1), 2 * S)
+                N.check(N.load().kbbq_accumulate_aligned_dev(ctx.handle, N.ptr(d_seq), N.ptr(d_oq), N.ptr(err), N.ptr(d_clip), N.ptr(d_trim),
+                                                             N.ptr(d_flags), m, pitch, S, max(R, 1), minscore, 6, N.ptr(part.buf)))
+                ctx.status()
+                tables.add(part)
+                return
+            except N.LutNeedsCheckedApply:
+                pass
         # 4-bit sequence planes between K6 and K1 (one byte per base less to write and to read) unless a forward read
         # carries a letter outside ACGTN, the reads are longer than K1's packed form takes, or K1's tables for this
         # minscore do not fit beside it (both refusals come before anything is counted)

@@ -64,16 +64,22 @@ def test_known_answer_of_the_reference(dev, tmp_path):
                                    dict(seed=34, npairs=300, S=100, nrg=5), dict(seed=36, npairs=120, S=170),
                                    dict(seed=35, npairs=100, S=33, contigs=(('a', 1500), ('b', 1200), ('c', 1400)))])
 @pytest.mark.parametrize('minscore', [6, 2, 15])
-def test_tally_matches_oracle(dev, oracle, shape, minscore, tmp_path):
+def test_tally_matches_oracle(dev, oracle, shape, minscore, tmp_path, monkeypatch):
     import oracle_bqsr as OQ
     from kbbq import aln
     from kbbq.gatk import bqsr
     paths = OQ.synth_bqsr_set(str(tmp_path), **shape)
     want = _oracle_vectors(paths, minscore)
-    got = bqsr.bam_to_bqsr_covariates(aln.AlignmentFile(paths['sam']), paths['fa'], _var_pos(paths['vcf']),
-                                      minscore=minscore)
-    for k, g, w in zip(VEC, got, want):
-        assert np.array_equal(g, w), k
+    ctx = dev.context()
+    for fused in ('1', '0'):                               # K6 fused into K1 (the default), and K6 -> K1 through canonical reads
+        monkeypatch.setenv('KBBQ_TALLY_FUSED', fused)
+        ctx.kernel_ms(0, reset=True); ctx.timing(True)
+        got = bqsr.bam_to_bqsr_covariates(aln.AlignmentFile(paths['sam']), paths['fa'], _var_pos(paths['vcf']),
+                                          minscore=minscore)
+        ctx.timing(False)
+        for k, g, w in zip(VEC, got, want):
+            assert np.array_equal(g, w), (k, fused)
+        assert ctx.kernel_ms(0)[1] == 1                    # one tally launch either way (a refusal would show as two)
     assert want[2].sum() > 1000
 
 

@@ -208,11 +208,11 @@ def test_single_end_files_go_two_reads_to_a_row(dev, oracle, nrg, infer, n, tmp_
         assert np.array_equal(g, w)
 
 
-def _run_ranks(world, argv, timeout=300):
+def _run_ranks(world, argv, timeout=300, env=None):
     import os, socket, subprocess, sys
     from conftest import ROOT
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, KBBQ_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, KBBQ_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', **(env or {}))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
            '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.join(ROOT, 'tests', 'dist_cli_worker.py')] + argv
@@ -460,9 +460,16 @@ def test_two_ranks_print_the_reference_benchmark(dev, oracle, name, tmp_path):
     paths = OB.synth_truthset(str(tmp_path), **info['case'])
     for tag, extra in (('bam', []), ('fastq', ['-f', paths['fq']])):
         argv = ['benchmark', '-b', paths['sam'], '-r', paths['fa'], '-v', paths['vcf'], '-d', paths['bed'], '-l', 'lbl'] + extra
-        r = _run_ranks(2, argv)
+        r = _run_ranks(2, argv, env={'KBBQ_TIMING': '1'})
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         assert r.stdout.decode() == info['printed'][tag], tag
+        if tag == 'fastq':
+            # every rank flags (K4) only the alignments its FASTQ shard maps to (+ its own share): about half each, not all
+            import re
+            seen = re.findall(r'rank (\d) of 2 counts FASTQ reads \[\d+, \d+\) and flagged alignments \[\d+, \d+\): (\d+) of (\d+)', r.stderr.decode())
+            assert sorted(x[0] for x in seen) == ['0', '1'], r.stderr.decode()[-1500:]
+            total = int(seen[0][2])
+            assert all(int(k) <= 0.6 * total for _, k, _ in seen) and sum(int(k) for _, k, _ in seen) >= total
 
 
 def test_two_ranks_tally_alignments_like_one(dev, oracle, tmp_path):
