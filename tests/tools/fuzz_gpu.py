@@ -86,6 +86,7 @@ while time.time() < t_end:
         sl = lens[order]
         tb = dev.Tables(nrg, 2 * S)
         ok = True
+        items = []
         for blo, bhi, longest, shortest in fastx.length_bands(sl):
             pitch = fastx.pitch_for(longest)
             idx = order[blo:bhi]
@@ -100,8 +101,24 @@ while time.time() < t_end:
                 ref = dev.Tables(nrg, 2 * S); dev.accumulate(band, ref, minscore)
                 check('band %d..%d %s' % (shortest, longest, 'grouped' if lay is not band else 'rows'), torch.equal(part.buf, ref.buf), info)
             dev.accumulate(band, tb, minscore, s_band=longest, s_min=shortest)
+            st = dev.meta_stats(band)
+            items.append((dev.lay_out(band, nrg, longest, packed=longest <= dev.PACKED_READS and cases % 5 != 0, pairs=False, stats=st), longest, shortest))
         for k, (got, w) in enumerate(zip(tb.to_host(), want[5:9])):
             check('banded tables[%d]' % k, np.array_equal(got, w), info)
+        # all bands in ONE launch per kernel (kbbq_accumulate_bands_dev / kbbq_apply_bands_dev) against the oracle's tables and the
+        # per-band apply of the same layouts
+        try:
+            tm = dev.Tables(nrg, 2 * S)
+            dev.accumulate_bands(items, tm, minscore)
+            for k, (got, w) in enumerate(zip(tm.to_host(), want[5:9])):
+                check('merged bands tables[%d]' % k, np.array_equal(got, w), info)
+            lutm, shapem = dev.solve_lut(tm, minscore=minscore)
+            restore = cases % 2 == 0
+            got_o = dev.apply_bands(items, lutm, shapem, minscore=minscore, restore_order=restore)
+            for (lay, _, _), g in zip(items, got_o):
+                check('merged bands apply', torch.equal(g[:lay.n], dev.apply(lay, lutm, shapem, minscore=minscore, restore_order=restore)[:lay.n]), info)
+        except dev.N.LutNeedsCheckedApply:
+            pass                                       # a band whose shape the table-driven kernels do not serve
     if cases % 50 == 0:
         print('%d cases, %d mismatches, %.0f s left' % (cases, bad, t_end - time.time()), flush=True)
 print('done: %d cases, %d mismatches' % (cases, bad))

@@ -64,6 +64,14 @@ while time.time() < t_end:
             skipped += 1
             continue
         got = product(ga, gb, infer, os.path.join(tmp, 'out.fq'))
+        if got == want and cases % 8 == 0:
+            # the command line as its own process: no torch (kbbq/_hipmem.py), output with -o
+            import subprocess
+            out2 = os.path.join(tmp, 'out2.fq')
+            r = subprocess.run([sys.executable, '-m', 'kbbq.main', 'recalibrate', '-f', ga, gb, '-o', out2] + (['--infer-rg'] if infer else []),
+                               env=dict(os.environ, PYTHONPATH=os.path.join(ROOT, 'kbbq-py_amd')), capture_output=True, timeout=300)
+            got = open(out2, 'rb').read() if r.returncode == 0 and os.path.exists(out2) else b'command failed: ' + r.stderr[-300:]
+            info['command_line'] = True
         if got != want:
             bad += 1
             print('MISMATCH %s (%d vs %d bytes)' % (info, len(got), len(want)), flush=True)
