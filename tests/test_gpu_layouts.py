@@ -428,3 +428,20 @@ def test_all_length_bands_in_one_launch(dev, R, n, S, monkeypatch):
         dev.accumulate_bands(items, dev.Tables(R, 2 * S))
     with pytest.raises(dev.N.LutNeedsCheckedApply):
         dev.apply_bands(items, lut, shape)
+
+
+def test_host_planes_of_a_caller_are_tallied_as_they_are(dev, oracle, tmp_path):
+    """recalibrate._tally_local on bands that carry host planes (a caller's own packing: fastx.pack_pair(bands=True) without
+    to_device): K1 and K2 run on those rows as they are -- no layout pass (a device pass into another layout costs more than it
+    saves for one accumulate + apply)."""
+    from conftest import load_golden
+    from test_gpu_parity import _files
+    from kbbq import fastx, recalibrate
+    info, gold = load_golden('c1_10k_1rg')
+    fa, fb = _files(oracle, info, tmp_path)
+    packed = fastx.pack_pair(fa, fb, False, bands=True)
+    assert all('source' not in band and 'seq' in band for band in packed['bands'])
+    tables = recalibrate._tally_local(packed, 6, 42)
+    for g, k in zip(tables.to_host(), ('pos_errs', 'pos_total', 'dinuc_errs', 'dinuc_total')):
+        assert np.array_equal(g, gold[k]), k
+    assert all(band['laid'] is None and band['batch'] is not None and not band['batch'].nib for band in packed['bands'])
