@@ -893,7 +893,7 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     const bool km = pairs && nib && q.cpr == 19 && !(km_off && !strcmp(km_off, "0"));
     if (km) {
         q.row_bytes = (u32)(((16 * 19 + 31) & ~31) * 4);
-        q.minlen = 0; q.slack_bytes = 0;
+        q.minlen = 0; q.slack_bytes = 0; q.ntrash = 1; q.pos_copies = 1;
         q.dn_flush_iters = std::max(1, 65535 / ((K1V3_THREADS / K1V3_DNREP) * 16 * q.cpr));
         lds3 = (size_t)q.nrows * 128 * K1V3_DNREP + (size_t)q.nrows * q.row_bytes;
         if (lds3 <= (size_t)c->lds_bytes) dn = K1V3_DNREP;
@@ -929,6 +929,28 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     if (!dn) {
         if (fits) { *fits = false; return KBBQ_OK; }     // the caller has another kernel for this shape
         return fail(KBBQ_E_LUT, "%s: %d-base reads with minscore %d do not fit the LDS tables; use plain one-read-per-row planes", who, S, minscore);
+    }
+    // copies of the cycle table for narrow rows (kernel comment at K1v3Params::pos_copies): as many of 4 / 2 as the LDS holds beside
+    // the context table, for rows of up to 12 chunks (wider rows spread a wave's lanes over enough columns); KBBQ_K1_POSCOPIES=1: none
+    // ... and several trash rows (K1v3Params::ntrash) first: the padding behind every read's last base is the hotter spot
+    q.pos_copies = 1; q.ntrash = 1;
+    q.pos_copy_bytes = (u32)q.nrows * q.row_bytes + q.slack_bytes;
+    if (!km && per_cu == 1) {
+        const char* nt_env = getenv("KBBQ_K1_NTRASH");
+        const int most_t = nt_env ? atoi(nt_env) : 8;
+        auto bytes_for = [&](int nt, int pc) {
+            const size_t rows = (size_t)q.nrows - 1 + nt;
+            return rows * 128 * dn + (size_t)pc * (rows * q.row_bytes + q.slack_bytes);
+        };
+        for (int nt = 8; nt >= 2; nt >>= 1)
+            if (nt <= most_t && bytes_for(nt, 1) <= (size_t)c->lds_bytes) { q.ntrash = nt; break; }
+        const char* pc_env = getenv("KBBQ_K1_POSCOPIES");
+        const int most = pc_env ? atoi(pc_env) : 4;
+        if (q.cpr <= 12)
+            for (int pc = 4; pc >= 2; pc >>= 1)
+                if (pc <= most && bytes_for(q.ntrash, pc) <= (size_t)c->lds_bytes) { q.pos_copies = pc; break; }
+        q.pos_copy_bytes = (u32)((size_t)(q.nrows - 1 + q.ntrash) * q.row_bytes + q.slack_bytes);
+        lds3 = bytes_for(q.ntrash, q.pos_copies);
     }
     const bool split = dinuc_minscore > minscore;
     const int64_t nblocks = (nrows + 63) / 64;
@@ -1242,7 +1264,7 @@ int kbbq_accumulate_bands_dev(kbbq_ctx* c, const kbbq_band* bands, int nbands, i
     }
     HIPCHK(hipSetDevice(c->device));
     const char* rc_env = getenv("KBBQ_K1_BAND_ROWCOST");
-    const double row_cost = rc_env ? atof(rc_env) : 3.0;
+    const double row_cost = rc_env ? atof(rc_env) : 1.25;
     for (auto& grp : groups) {
         if (grp.empty()) continue;
         const int threads = setups[grp[0]].threads;
@@ -1597,6 +1619,20 @@ int kbbq_accumulate_aligned_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t
         if (lds3 <= (size_t)c->lds_bytes && (K1V3_THREADS / copies) * 16 * q.cpr <= 65535) { dn = copies; break; }
     }
     if (!dn) return fail(KBBQ_E_LUT, "kbbq_accumulate_aligned_dev: %d-base reads with minscore %d do not fit the LDS tables; tally through kbbq_canonical_reads_rows_dev", S, minscore);
+    {   // several trash rows, then copies of the cycle table for short reads, as the LDS allows (accumulate_rows)
+        q.pos_copies = 1; q.ntrash = 1;
+        auto bytes_for = [&](int nt, int pc) {
+            const size_t rows = (size_t)q.nrows - 1 + nt;
+            return rows * 128 * dn + (size_t)pc * (rows * q.row_bytes + q.slack_bytes);
+        };
+        for (int nt = 8; nt >= 2; nt >>= 1)
+            if (bytes_for(nt, 1) <= (size_t)c->lds_bytes) { q.ntrash = nt; break; }
+        if (q.cpr <= 12)
+            for (int pc = 4; pc >= 2; pc >>= 1)
+                if (bytes_for(q.ntrash, pc) <= (size_t)c->lds_bytes) { q.pos_copies = pc; break; }
+        q.pos_copy_bytes = (u32)((size_t)(q.nrows - 1 + q.ntrash) * q.row_bytes + q.slack_bytes);
+        lds3 = bytes_for(q.ntrash, q.pos_copies);
+    }
     const bool split = dinuc_minscore > minscore;
     const int64_t nblocks = (nreads + 63) / 64;
     const int64_t iters = (nblocks + (K1V3_THREADS / 64) - 1) / (K1V3_THREADS / 64);

@@ -61,6 +61,15 @@ struct K1v3Params {
     const u32* aflags;          // bit 0 reverse strand, bit 1 read 2, bits 16.. read group
     const u32* aclip;           // query_alignment_start | query_alignment_end << 16
     const u32* atrim;           // skipped range lo | hi << 16 (adaptor; lo == hi: none)
+    // copies of the cycle table (1, 2 or 4; KJ == 0 forms): a chunk counts into copy (row slot & (copies - 1)), the flush sums them.
+    // Narrow rows put many lanes of a wave on the same few columns (pitch 48: 21 lanes per column), i.e. onto the same (quality,
+    // column) words: same-address LDS atomics serialise.  Their tables are small, so copies fit the LDS beside the context table.
+    int pos_copies; u32 pos_copy_bytes;      // bytes from one copy to the next (rows + slack)
+    // trash rows (1, 2, 4 or 8; KJ == 0 forms): every uncounted byte -- below minscore, and ALL the padding behind a read's last
+    // base -- is binned on the trash row at its column, so the lanes of a wave that sit on the last chunk of their rows hit the same
+    // few trash words over and over (a 16- to 21-way same-address atomic for narrow rows).  With several trash rows a chunk uses row
+    // (row slot & (ntrash - 1)) of them: the clamp's upper bound becomes a per-chunk value, nothing is added per base.
+    int ntrash;
 };
 
 // nucleotide decode of 4 bases: code (A0 T1 G2 C3, N/other 4), 5*code, and the character each
@@ -162,8 +171,10 @@ template <bool SPLIT, int DN, bool NIB, int KJ, bool ALN = false>
 __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const int bx, const int gx, const int g)
 {
     static_assert(!ALN || (!NIB && KJ == 0), "the aligned-read form reads character planes");
-    const int dn_words = p.nrows * 32 * DN;
-    const int pos_words = p.nrows * (int)(p.row_bytes >> 2) + (int)(p.slack_bytes >> 2);
+    const int ntrash = KJ > 0 ? 1 : p.ntrash;
+    const int dn_words = (p.nrows - 1 + ntrash) * 32 * DN;
+    const int ncopies = KJ > 0 ? 1 : p.pos_copies;
+    const int pos_words = KJ > 0 ? p.nrows * (int)(p.row_bytes >> 2) + (int)(p.slack_bytes >> 2) : ncopies * (int)(p.pos_copy_bytes >> 2);
     u32* dnt = lds;
     u32* pos = lds + dn_words;
     for (int i = threadIdx.x; i < dn_words + pos_words; i += blockDim.x) lds[i] = 0u;
@@ -236,7 +247,23 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                 continue;
             }
             for (int x = lane; x < 3 * S - p.minlen; x += 64) {
-                const u32 v = prow[x];
+                u32 v = prow[x];
+                if (ncopies > 1) {                                            // sum the copies (16-bit halves apart: they are counts)
+                    u32 vt = v & 0xFFFFu, ve = v >> 16;
+                    for (int cpy = 1; cpy < ncopies; ++cpy) {
+                        u32* q = prow + (size_t)cpy * (p.pos_copy_bytes >> 2);
+                        const u32 w = q[x];
+                        if (w) { q[x] = 0u; vt += w & 0xFFFFu; ve += w >> 16; }
+                    }
+                    if (vt | ve) {
+                        prow[x] = 0u;
+                        if (p.gap && x == S) continue;
+                        const int col = x < S ? x : (p.twins ? x - S - p.gap : S2 - 1 - (x - S - p.gap));
+                        atomicAdd(&pos_total[grow + col], (u64)vt);
+                        if (ve) atomicAdd(&pos_errs[grow + col], (u64)ve);
+                    }
+                    continue;
+                }
                 if (v) {
                     prow[x] = 0u;
                     if (p.gap && x == S) continue;                            // the separator byte of a mate-pair row is never counted
@@ -417,7 +444,9 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                     if (!hiq && fits_tables && !((NIB || ALN) && badbits)) {
                         // A: pos address less the row term; both mates ascend with the base index
                         const u32 half = second ? (u32)(S + 2 * (S - len)) : 0u;     // column 2*len-1-pos
-                        const u32 A = KJ > 0 ? pos_base + 4u * (u32)j : pos_base + (half + (u32)pos0) * 4u;
+                        const u32 copy_off = KJ > 0 ? 0u : (u32)(ch.k & (ncopies - 1)) * p.pos_copy_bytes;     // this chunk's copy of the cycle table
+                        const u32 tcl = KJ > 0 ? tclamp : tclamp + (u32)(ch.k & (ntrash - 1));                 // ... and its trash row
+                        const u32 A = KJ > 0 ? pos_base + 4u * (u32)j : pos_base + copy_off + (half + (u32)pos0) * 4u;
                         // ALN: bases before the aligned part have NEGATIVE canonical positions.  They are uncounted, i.e. they land on
                         // the trash row (the last one) -- up to 15 words before its start when the chunk holds the first aligned
                         // base: the tail of the row before it, which this form never uses and never flushes (every read has length S:
@@ -438,7 +467,7 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                             auto one_base = [&](auto bsel) {
                                 constexpr int b = decltype(bsel)::value;
                                 const u32 qi = (qn >> (8 * b)) & 0xFFu;                 // 255 - quality byte
-                                const u32 tq = qi < tclamp ? qi : tclamp;              // below minscore (and padding): trash row
+                                const u32 tq = qi < tcl ? qi : tcl;                    // below minscore (and padding): a trash row
 #ifndef KBBQ_K1_PLAIN_INC
                                 const u32 inc = k1_increment<b>(xwd, zero, both);      // recalibrate.py:13-20: errs << 16 | total
 #else
@@ -447,7 +476,7 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                                 u32 a;
                                 if constexpr (ALN) {
                                     const int co = colA + 4 * (4 * wd + b);
-                                    a = __umul24(tq, row_bytes) + pos_base + (u32)(clamp_each ? (co > 0 ? co : 0) : co);
+                                    a = __umul24(tq, row_bytes) + pos_base + copy_off + (u32)(clamp_each ? (co > 0 ? co : 0) : co);
                                 } else {
                                     a = __umul24(tq, row_bytes) + A + (u32)(KJ > 0 ? 4 * KJ * (4 * wd + b) : 4 * (4 * wd + b));
                                 }

@@ -408,6 +408,12 @@ def test_all_length_bands_in_one_launch(dev, R, n, S, monkeypatch):
     ctx.timing(False)
     assert 1 + alone <= ctx.kernel_ms(0)[1] <= 2 + alone   # one merged launch per workgroup shape (narrow rows: two workgroups per CU) + the bands it does not take
     assert torch.equal(got_t.buf, want_t.buf) and int(got_t.buf.sum()) > 0
+    monkeypatch.setenv('KBBQ_K1_POSCOPIES', '1')          # without the copies of the cycle table / the extra trash rows: the same counts
+    monkeypatch.setenv('KBBQ_K1_NTRASH', '1')
+    single = dev.Tables(R, 2 * S)
+    dev.accumulate_bands(items, single)
+    assert torch.equal(single.buf, want_t.buf)
+    monkeypatch.delenv('KBBQ_K1_POSCOPIES'); monkeypatch.delenv('KBBQ_K1_NTRASH')
     monkeypatch.setenv('KBBQ_K1_BANDS', '0')              # the A/B switch: a launch per band through the same entry point
     again = dev.Tables(R, 2 * S)
     dev.accumulate_bands(items, again)
