@@ -311,7 +311,7 @@ int kbbq_canonical_reads_rows_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uin
  * kbbq_canonical_reads_dev.  Counts ADD into d_tables (R, S2 = 2 S).  3 B/base read instead of 3 + 2 written + 2 read
  * again.  A forward-strand read with a letter outside ACGTN makes kbbq_ctx_status return KBBQ_E_LUT: tally through
  * kbbq_canonical_reads_rows_dev(layout 0), where the reference's TypeError is decided; a shape whose tables do not fit the
- * LDS returns KBBQ_E_LUT at once. */
+ * LDS, and reads shorter than 32 bases, return KBBQ_E_LUT at once (nothing launched). */
 int kbbq_accumulate_aligned_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_oq, const uint8_t* d_flagplane,
                                 const uint32_t* d_clip, const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads,
                                 int pitch, int S, int R, int minscore, int dinuc_minscore, int64_t* d_tables);

@@ -1595,6 +1595,7 @@ int kbbq_accumulate_aligned_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t
     if (minscore < 0 || minscore > KQ - 1 || dinuc_minscore < 0 || dinuc_minscore > 94) return fail(KBBQ_E_ARG, "kbbq_accumulate_aligned_dev: minscore out of range");
     if (nreads == 0) return KBBQ_OK;
     if (!d_seq || !d_oq || !d_flagplane || !d_clip || !d_trim || !d_flags || !d_tables) return fail(KBBQ_E_ARG, "kbbq_accumulate_aligned_dev: NULL pointer");
+    if (S < 32) return fail(KBBQ_E_LUT, "kbbq_accumulate_aligned_dev: reads of %d bases (< 32) are tallied through kbbq_canonical_reads_rows_dev", S);
     HIPCHK(hipSetDevice(c->device));
     K1v3Params q;
     memset(&q, 0, sizeof q);
@@ -1625,11 +1626,14 @@ int kbbq_accumulate_aligned_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t
             const size_t rows = (size_t)q.nrows - 1 + nt;
             return rows * 128 * dn + (size_t)pc * (rows * q.row_bytes + q.slack_bytes);
         };
+        const char* nt_env = getenv("KBBQ_K1_NTRASH");
+        const char* pc_env = getenv("KBBQ_K1_POSCOPIES");
+        const int most_t = nt_env ? atoi(nt_env) : 8, most = pc_env ? atoi(pc_env) : 4;
         for (int nt = 8; nt >= 2; nt >>= 1)
-            if (bytes_for(nt, 1) <= (size_t)c->lds_bytes) { q.ntrash = nt; break; }
+            if (nt <= most_t && bytes_for(nt, 1) <= (size_t)c->lds_bytes) { q.ntrash = nt; break; }
         if (q.cpr <= 12)
             for (int pc = 4; pc >= 2; pc >>= 1)
-                if (bytes_for(q.ntrash, pc) <= (size_t)c->lds_bytes) { q.pos_copies = pc; break; }
+                if (pc <= most && bytes_for(q.ntrash, pc) <= (size_t)c->lds_bytes) { q.pos_copies = pc; break; }
         q.pos_copy_bytes = (u32)((size_t)(q.nrows - 1 + q.ntrash) * q.row_bytes + q.slack_bytes);
         lds3 = bytes_for(q.ntrash, q.pos_copies);
     }

@@ -450,11 +450,10 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                         // ALN: bases before the aligned part have NEGATIVE canonical positions.  They are uncounted, i.e. they land on
                         // the trash row (the last one) -- up to 15 words before its start when the chunk holds the first aligned
                         // base: the tail of the row before it, which this form never uses and never flushes (every read has length S:
-                        // columns < 2S + 16 of 3S words; the host sets minlen = S, the flush stops at 2S) as long as S >= 32; a chunk
-                        // wholly outside the aligned part is sent to column 0.  Shorter reads take the per-base clamp.
-                        const bool clamp_each = S < 32;
+                        // columns < 2S + 16 of 3S words; the host sets minlen = S, the flush stops at 2S) as long as S >= 32 (the host
+                        // sends shorter reads through K6); a chunk wholly outside the aligned part is sent to column 0.
                         int colA = ((int)half + c0) * 4;
-                        if constexpr (ALN) { if (!clamp_each && colA < -60) colA = 0; }
+                        if constexpr (ALN) { if (colA < -60) colA = 0; }
                         u32 pc5 = prev_code5 << 24;
 #pragma unroll
                         for (int wd = 0; wd < 4; ++wd) {
@@ -476,7 +475,7 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                                 u32 a;
                                 if constexpr (ALN) {
                                     const int co = colA + 4 * (4 * wd + b);
-                                    a = __umul24(tq, row_bytes) + pos_base + copy_off + (u32)(clamp_each ? (co > 0 ? co : 0) : co);
+                                    a = __umul24(tq, row_bytes) + pos_base + copy_off + (u32)co;
                                 } else {
                                     a = __umul24(tq, row_bytes) + A + (u32)(KJ > 0 ? 4 * KJ * (4 * wd + b) : 4 * (4 * wd + b));
                                 }
