@@ -796,3 +796,40 @@ def test_pmc_traffic_belongs_to_the_current_kernel_sources():
         for kernel in ('k1_accumulate', 'k2_apply'):
             assert 1.5 < pmc[layout][kernel]['hbm_bytes_per_base'] < 3.6
     assert bench.pmc_traffic('pairs_nib', 'k2_apply') == pmc['pairs_nib']['k2_apply']['hbm_bytes_per_base']
+
+
+def test_hipmem_host_tensors_behave_like_the_torch_subset_they_replace():
+    """kbbq/_hipmem.py (device memory, page-locked slabs and events for the command line without torch): the host-side half --
+    tensors over NumPy memory, slices along the first axis, reinterpreting views, copies -- needs no GPU; the device half is
+    exercised by tests/test_gpu_parity.py::test_the_command_line_runs_without_torch."""
+    from kbbq import _hipmem as H
+    a = np.arange(48, dtype=np.uint8).reshape(6, 8)
+    t = H.from_numpy(a)
+    assert t.shape == (6, 8) and t.dtype == np.uint8 and t.numel() == 48 and not t.is_cuda and t.device == H.CPU
+    assert np.array_equal(t.numpy(), a) and t.numpy().ctypes.data == a.ctypes.data          # no copy
+    s = t[2:5]
+    assert s.shape == (3, 8) and np.array_equal(s.numpy(), a[2:5]) and s.data_ptr() == a.ctypes.data + 16
+    assert t[4:99].shape == (2, 8) and t[5:2].shape == (0, 8)
+    with pytest.raises(IndexError):
+        t[::2]
+    with pytest.raises(IndexError):
+        t[1:2, 1:2]
+    v = s.view(H.int32)                                                                     # bytes reinterpreted, last axis rescaled
+    assert v.shape == (3, 2) and np.array_equal(v.numpy(), a[2:5].view(np.int32))
+    assert s.view(24).shape == (24,) and s.view(-1, 4).shape == (6, 4)
+    with pytest.raises(ValueError):
+        s.view(5, 5)
+    z = H.zeros(3, 8, dtype=H.uint8)
+    assert not z.numpy().any()
+    z.copy_(s)
+    assert np.array_equal(z.numpy(), a[2:5])
+    z[1:2].copy_(np.full((1, 8), 7, dtype=np.uint8))
+    assert z.numpy()[1].tolist() == [7] * 8 and z.numpy()[0].tolist() == a[2].tolist()
+    with pytest.raises(ValueError):
+        z.copy_(t)
+    e = H.empty((4, 2), dtype=H.int64)
+    assert e.shape == (4, 2) and e.nbytes == 64 and H.empty_like(e).shape == (4, 2)
+    assert e.cpu() is e and e.to('cpu') is e
+    with pytest.raises(ValueError):
+        H.from_numpy(a[:, ::2])
+    assert H._device_of('cuda:3') == H.Device('cuda', 3) and H._device_of(None) == H.CPU
