@@ -173,3 +173,16 @@ def test_group_rows_host_refuses_a_group_beyond_r():
     perm, seg = np.empty(2, dtype=np.int64), np.empty(3, dtype=np.int64)
     with pytest.raises(ValueError):
         N.check(N.load().kbbq_group_rows_host(N.ptr(meta), 2, 0, 2, N.ptr(perm), N.ptr(seg)))
+
+
+def test_scalar_twins_of_the_simd_host_code():
+    """The packer's 4-bit packing (SSSE3) has a scalar twin for other hosts: KBBQ_NO_SIMD=1 in a fresh process runs the layout and reader
+    tests on it."""
+    import os, subprocess, sys
+    if os.environ.get('KBBQ_NO_SIMD'):
+        pytest.skip('already the scalar run')
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', os.path.join(here, 'test_packer_layouts.py'), os.path.join(here, 'test_host_logic.py'),
+                        '-k', 'fill_rows or fastq or pack_pair or reader or packer'], env=dict(os.environ, KBBQ_NO_SIMD='1'), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert ' passed' in r.stdout
