@@ -543,6 +543,13 @@ def extra_aligned(torch, dev, n=4_000_000, L=150, G=200_000_000, ins=0.05, reps=
         N.check(lib.kbbq_accumulate_aligned_dev(ctx.handle, N.ptr(seq), N.ptr(oq), N.ptr(err), N.ptr(clip), N.ptr(trim), N.ptr(flags), n, pitch, L,
                                                 1, 6, 6, N.ptr(tables.buf)))
 
+    plane = torch.empty((n, pitch), dtype=torch.uint8, device='cuda')
+
+    def k461():                             # K4 folded in as well: reads of one M operation never meet a plane of flags
+        N.check(lib.kbbq_tally_aligned_dev(ctx.handle, N.ptr(seq), N.ptr(oq), N.ptr(lens), n, pitch, L, N.ptr(start), N.ptr(ref_len),
+                                           N.ptr(cig_off), N.ptr(cig_n), N.ptr(cigar), N.ptr(fused), G, N.ptr(clip), N.ptr(trim), N.ptr(flags),
+                                           N.ptr(plane), 1, 6, 6, N.ptr(tables.buf)))
+
     out = {'workload': '%d aligned reads x %d bp, %d Mb random genome, %.0f %% of the reads with a 2-base insertion, half '
                        'reverse-strand; HIP events on the launch stream, %d launches each' % (n, L, G // 1000000, ins * 100, reps),
            'bytes_per_base': 'algorithmic, by the arrays of the reference: K4 3 read (read, reference, site mask) + 2 written (errors, '
@@ -554,7 +561,7 @@ def extra_aligned(torch, dev, n=4_000_000, L=150, G=200_000_000, ins=0.05, reps=
     bases = n * L
     for name, fn, bpb in (('k4_find_errors', lambda: k4(flip), 5), ('k5_count_q', k5, 3),
                           ('k4_find_errors_tally', lambda: k4(noflip), 5), ('k6_canonical_reads', k6, 7),
-                          ('k1_on_canonical_reads', k1, 3), ('k61_fused_tally', k61, 3),
+                          ('k1_on_canonical_reads', k1, 3), ('k61_fused_tally', k61, 3), ('k461_whole_tally_one_pass', k461, 3),
                           ('k6_canonical_reads_character_planes', lambda: k6(False, batch), 7),
                           ('k1_on_canonical_reads_character_planes', lambda: k1(batch), 3),
                           ('k4_find_errors_two_planes', lambda: k4(flip, True), 5), ('k5_count_q_two_planes', lambda: k5(True), 3),
@@ -575,10 +582,18 @@ def extra_aligned(torch, dev, n=4_000_000, L=150, G=200_000_000, ins=0.05, reps=
     tables.buf.zero_(); k61()
     ctx.status()
     out['k61_fused_tally']['verified'] = bool(torch.equal(tables.buf, want)) and int(want.sum()) > 0
+    tables.buf.zero_(); plane.fill_(0xA5); k461()
+    ctx.status()
+    out['k461_whole_tally_one_pass']['verified'] = bool(torch.equal(tables.buf, want))
+    out['k461_whole_tally_one_pass']['note'] = ('wall time of kbbq_tally_aligned_dev (HIP events around the call): the records / classification pass, '
+                                                'K4 over the reads that are not one M operation (here %.0f %% insertion reads and the reads at the genome\'s end) '
+                                                'and the tally kernel that compares the other reads with the reference itself' % (ins * 100))
     out['whole_tally_ms'] = {'k4_k6_k1': out['k4_find_errors_tally']['avg_ms'] + out['k6_canonical_reads']['avg_ms'] + out['k1_on_canonical_reads']['avg_ms'],
                              'k4_fused': out['k4_find_errors_tally']['avg_ms'] + out['k61_fused_tally']['avg_ms'],
+                             'one_pass': out['k461_whole_tally_one_pass']['avg_ms'],
                              'note': 'gatk.bqsr.bam_to_bqsr_covariates on the device: K4 (flags) then K6 -> K1 (canonical reads written and read back: 3 + 2 + 2 '
-                                     'B/base) or the fused kernel (kbbq_accumulate_aligned_dev: 3 B/base read, nothing written)'}
+                                     'B/base), K4 then the fused kernel (kbbq_accumulate_aligned_dev: 3 + 3 B/base), or everything in one pass '
+                                     '(kbbq_tally_aligned_dev: 3 B/base for reads of one M operation; what gatk.bqsr runs)'}
     return out
 
 

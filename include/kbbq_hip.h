@@ -315,6 +315,24 @@ int kbbq_canonical_reads_rows_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uin
 int kbbq_accumulate_aligned_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_oq, const uint8_t* d_flagplane,
                                 const uint32_t* d_clip, const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads,
                                 int pitch, int S, int R, int minscore, int dinuc_minscore, int64_t* d_tables);
+/* kbbq_tally_aligned_dev: kbbq_find_errors_dev (no flip, one plane of flags, fused reference) + kbbq_accumulate_aligned_dev --
+ * the whole device side of gatk.bqsr.bam_to_bqsr_covariates (gatk/bqsr.py:52-123: compare_reads.find_read_errors per read,
+ * compare_reads.py:84-139, then the covariate counts) -- with ONE pass over the reads for every read that is a single
+ * M / = / X operation over all of its bases: the tally kernel compares such a read with its reference window itself (read
+ * bytes, OQ, reference: 3 B/base instead of 6 for the two calls).  Every other read (insertions, deletions, clips in the
+ * CIGAR, more or odd operations, a window at the very end of the genome) is listed on the device, kbbq_find_errors_dev's kernel
+ * runs over the listed reads only and writes THEIR rows of d_flagplane, which the tally kernel reads for them.  d_flagplane:
+ * [nreads, pitch] scratch of the caller's (contents on entry irrelevant; rows of listed reads hold their flags afterwards).
+ * d_genome: FUSED reference (bit 7 of a byte = the site's skip flag), genome_len bytes.  d_len[i] == S for every read (the
+ * caller's promise, as for kbbq_accumulate_aligned_dev).  Counts ADD into d_tables and equal those of the two calls; the
+ * same statuses arrive through kbbq_ctx_status (KBBQ_E_INDEX / KBBQ_E_RANGE from the CIGAR walk, KBBQ_E_LUT for a forward
+ * read with a letter outside ACGTN); a shape the tally kernel does not serve returns KBBQ_E_LUT before anything is launched. */
+int kbbq_tally_aligned_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_oq, const uint32_t* d_len, int64_t nreads,
+                           int pitch, int S, const int64_t* d_ref_start, const int32_t* d_ref_len,
+                           const uint32_t* d_cig_off, const uint32_t* d_cig_n, const uint32_t* d_cigar,
+                           const uint8_t* d_genome, int64_t genome_len,
+                           const uint32_t* d_clip, const uint32_t* d_trim, const uint32_t* d_flags,
+                           uint8_t* d_flagplane, int R, int minscore, int dinuc_minscore, int64_t* d_tables);
 int kbbq_count_q_dev(kbbq_ctx* ctx, const uint8_t* d_qual, const uint8_t* d_err, const uint8_t* d_skip,
                      const uint32_t* d_len, int64_t nreads, int pitch, int qoffset, int64_t* d_counts512);
 

@@ -59,13 +59,42 @@ struct K4v2Params {
     K4Params base;
     const K4Rec* recs;               // [nreads]
     const uint8_t* idle16;           // any 16 readable bytes: what a chunk without a window of its own loads instead
+    // only SOME reads (kbbq_tally_aligned_dev: the reads that are not one M / = / X operation): work item i is read rows[i],
+    // *nrows of them (a count k4_read_records left on the device); NULL: every read of the batch
+    const u32* rows; const u32* nrows;
 };
 
-struct K4RecParams { const u32* len; const int* ref_len; const u32* cig_off; const u32* cig_n; const u32* cigar; long long nreads; K4Rec* recs; };
+struct K4RecParams {
+    const u32* len; const int* ref_len; const u32* cig_off; const u32* cig_n; const u32* cigar; long long nreads; K4Rec* recs;
+    // kbbq_tally_aligned_dev: which reads need k4v2_find_errors at all?  A read that is ONE M / = / X operation over all of its
+    // bases, reference window inside the genome for every 16-byte chunk of its row, is compared with the reference by the tally
+    // kernel itself (k1v3_aligned_ref): aflags_out = aflags_in | 4 for it; every other read is appended to rows[*nrows].
+    const u32* aflags_in; u32* aflags_out; u32* rows; u32* nrows;
+    const long long* ref_start; long long genome_len; int pitch;
+};
 
+#define K4_LIST_BUF 1024          // listed reads a workgroup collects in LDS before it appends them to rows[] with ONE global atomic
 __global__ __launch_bounds__(256) void k4_read_records(K4RecParams p)
 {
-    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < p.nreads; r += (long long)gridDim.x * blockDim.x) {
+    // (the list: one global atomic per listed read -- 800 K of them on one address for 16 M reads with 5 % indel reads -- took
+    //  2.5 ms; collected per workgroup in LDS and appended K4_LIST_BUF at a time they cost nothing measurable)
+    __shared__ u32 buf[K4_LIST_BUF];
+    __shared__ u32 nbuf, base;
+    const bool listing = p.aflags_out != nullptr;
+    if (listing) { if (threadIdx.x == 0) nbuf = 0u; __syncthreads(); }
+    auto flush = [&]() {                                       // every thread of the workgroup calls this
+        __syncthreads();
+        const u32 k = nbuf;
+        if (threadIdx.x == 0 && k) base = atomicAdd(p.nrows, k);
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < k; i += blockDim.x) p.rows[base + i] = buf[i];
+        __syncthreads();
+        if (threadIdx.x == 0) nbuf = 0u;
+        __syncthreads();
+    };
+    for (long long r0 = (long long)blockIdx.x * blockDim.x; r0 < p.nreads; r0 += (long long)gridDim.x * blockDim.x) {
+        const long long r = r0 + threadIdx.x;
+        if (r < p.nreads) {
         const u32 nc = p.cig_n[r];
         const int n = (int)p.len[r], rl = p.ref_len[r];
         const u32* ops = p.cigar + p.cig_off[r];
@@ -103,8 +132,24 @@ __global__ __launch_bounds__(256) void k4_read_records(K4RecParams p)
         K4Rec rec;
         rec.lo = make_uint4(w0[0], w1[0], w0[1], w1[1]);
         rec.hi = make_uint4(w0[2], w1[2], w0[3], w1[3]);
-        p.recs[r] = rec;
+        bool simple = false;
+        if (listing) {
+            // one operation, M / = / X, covering exactly the read (the record above: range [0, n), shift 0), and every chunk's
+            // window [g0 + 16 j, g0 + 16 j + 16) readable
+            const long long g0 = p.ref_start[r];
+            simple = ok && nc == 1 && n > 0 && w0[0] == ((u32)n << 16) && w1[0] == (1u << 29)
+                     && g0 >= 0 && g0 + p.pitch <= p.genome_len;
+            p.aflags_out[r] = (p.aflags_in[r] & ~4u) | (simple ? 4u : 0u);
+            if (!simple) buf[atomicAdd(&nbuf, 1u)] = (u32)r;
+        }
+        if (!simple) p.recs[r] = rec;                          // nobody reads the record of a read the tally kernel compares itself
+        }
+        if (listing) {                                          // room for the next iteration's 256 reads?  (a uniform decision)
+            __syncthreads();
+            if (nbuf > K4_LIST_BUF - 256) flush();
+        }
     }
+    if (listing) flush();
 }
 
 // the sequential walk of the first form for ONE chunk (compare_reads.py:100-137), operation by operation in CIGAR order
@@ -185,7 +230,7 @@ __device__ __forceinline__ void k4_walk_chunk(const K4Params& p, long long r, in
     }
 }
 
-struct K4v2Meta { int n; u32 f; long long g0; K4Rec rec; bool valid; };
+struct K4v2Meta { int n; u32 f; long long g0; K4Rec rec; bool valid; long long r; };
 // a chunk's composition out of two windows: byte ranges (relative to the chunk) of the two M operations and of the gap,
 // 4 bits each; kind: 0 simple-or-two-window, 1 queued
 struct K4v2Win {
@@ -215,13 +260,15 @@ __global__ __launch_bounds__(256) void k4v2_find_errors(K4v2Params q)
     const long long gstep = (long long)gridDim.x * step;
     const bool idle = (rpb && slot >= rpb) || j0 >= cpr;
     constexpr bool fused = FUSED;
+    const long long nitems = q.rows ? (long long)*q.nrows : p.nreads;       // work items: reads, or the listed reads
     auto next = [&](K4Item it) { it.j += 256; if (it.j >= cpr) { it.j = j0; it.rb += gstep; } return it; };
-    auto live = [&](const K4Item& it) { return !idle && it.rb + slot < p.nreads; };
+    auto live = [&](const K4Item& it) { return !idle && it.rb + slot < nitems; };
     // stage A: the read's fields and its inline operations (independent loads: one round trip)
     auto fetch_meta = [&](const K4Item& it, K4v2Meta& m) {
         m.valid = live(it);
-        const long long r = m.valid ? it.rb + slot : 0;
-        m.n = (int)p.len[r]; m.f = p.flip[r]; m.g0 = p.ref_start[r];
+        const long long r = m.valid ? (q.rows ? (long long)q.rows[it.rb + slot] : it.rb + slot) : 0;
+        m.r = r;
+        m.n = (int)p.len[r]; m.f = p.flip ? p.flip[r] : 0u; m.g0 = p.ref_start[r];
         m.rec = q.recs[r];
     };
     // stage B: where do this chunk's input positions sit?  (registers only)  then the read bytes and THE window.
@@ -234,7 +281,7 @@ __global__ __launch_bounds__(256) void k4v2_find_errors(K4v2Params q)
         w.cnt = w.has ? out_hi - out_lo : 0;
         w.in_lo = w.has ? (m.f ? n - out_hi : out_lo) : 0;
         const int a = w.in_lo, b = w.in_lo + w.cnt;
-        load16_any(p.seq, w.has ? (long long)(it.rb + slot) * p.pitch + a : 0ll, w.sw);   // the chunk's read bytes (may run into the next row)
+        load16_any(p.seq, w.has ? m.r * p.pitch + a : 0ll, w.sw);   // the chunk's read bytes (may run into the next row)
         // the four operation records against [a, b): independent range tests, no branches
         const u32 r0[4] = {m.rec.lo.x, m.rec.lo.z, m.rec.hi.x, m.rec.hi.z}, r1[4] = {m.rec.lo.y, m.rec.lo.w, m.rec.hi.y, m.rec.hi.w};
         const bool ok = w.has && (r1[0] >> 29) != K4_KIND_BAD;
@@ -290,7 +337,7 @@ __global__ __launch_bounds__(256) void k4v2_find_errors(K4v2Params q)
     // one chunk through the sequential walk, from scratch (fields, read bytes, operations, windows: all fetched here)
     auto walk_and_store = [&](long long r, int j) {
         const int n = (int)p.len[r], rl = p.ref_len[r];
-        const bool f = p.flip[r] != 0;
+        const bool f = p.flip && p.flip[r] != 0;
         const int out_lo = 16 * j, out_hi = out_lo + 16 < n ? out_lo + 16 : n;
         const int cnt = out_hi - out_lo, in_lo = f ? n - out_hi : out_lo;
         u32 sw[4], ev[4] = {0u, 0u, 0u, 0u}, kv[4] = {0u, 0u, 0u, 0u};
@@ -322,7 +369,7 @@ __global__ __launch_bounds__(256) void k4v2_find_errors(K4v2Params q)
         fetch_meta(it2, m2);
         fetch_win(it1, m1, w1);
         {
-            const long long r = it0.rb + slot;
+            const long long r = m0.r;
             const int j = it0.j;
             u32 ev[4] = {0u, 0u, 0u, 0u}, kv[4] = {0u, 0u, 0u, 0u};
             bool store = true;

@@ -51,6 +51,8 @@ struct kbbq_ctx {
     int wgplan_n = 0;
     void* d_ops4 = nullptr;           // K4: one 32-byte record of the first CIGAR operations per read (grown on demand)
     size_t ops4_bytes = 0;
+    void* d_tally = nullptr;          // kbbq_tally_aligned_dev: [count | flags words of the reads | rows K4 still has to look at] (grown on demand)
+    size_t tally_bytes = 0;
     void* d_rowlut = nullptr;         // K2 on one-read-per-row planes: the LUT narrowed to the rows' pitch (grown on demand)
     size_t rowlut_bytes = 0;
     bool timing = false;
@@ -120,6 +122,10 @@ int kbbq_ctx_create(int device, kbbq_ctx** out)
     (void)hipFuncSetAttribute((const void*)(k1v3_aligned<true, K1V3_DNREP>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k1v3_aligned<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k1v3_aligned<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_aligned_ref<false, K1V3_DNREP>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_aligned_ref<true, K1V3_DNREP>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_aligned_ref<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)(k1v3_aligned_ref<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k1v3_bands<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k1v3_bands<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k1v3_bands<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
@@ -141,6 +147,7 @@ int kbbq_ctx_destroy(kbbq_ctx* c)
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_ops4) (void)hipFree(c->d_ops4);
     if (c->d_rowlut) (void)hipFree(c->d_rowlut);
+    if (c->d_tally) (void)hipFree(c->d_tally);
     if (c->d_wgplan) (void)hipFree(c->d_wgplan);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1492,6 +1499,26 @@ int kbbq_unpack_nibbles_dev(kbbq_ctx* c, const uint8_t* d_nib, int64_t nbases, u
     return KBBQ_OK;
 }
 
+// the first four operations of every read inline, one 32-byte record per read (context-owned scratch); with aflags_out also
+// the classification kbbq_tally_aligned_dev needs (K4RecParams)
+static int k4_records(kbbq_ctx* c, const K4Params& p, const u32* aflags_in, u32* aflags_out, u32* rows, u32* nrows, int pitch)
+{
+    const size_t need = (size_t)p.nreads * sizeof(K4Rec);
+    if (c->ops4_bytes < need) {
+        if (c->d_ops4) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_ops4); c->d_ops4 = nullptr; c->ops4_bytes = 0; }
+        HIPCHK(hipMalloc(&c->d_ops4, need));
+        c->ops4_bytes = need;
+    }
+    K4RecParams ip; ip.len = p.len; ip.ref_len = p.ref_len; ip.cig_off = p.cig_off; ip.cig_n = p.cig_n; ip.cigar = p.cigar;
+    ip.nreads = p.nreads; ip.recs = (K4Rec*)c->d_ops4;
+    ip.aflags_in = aflags_in; ip.aflags_out = aflags_out; ip.rows = rows; ip.nrows = nrows;
+    ip.ref_start = p.ref_start; ip.genome_len = p.genome_len; ip.pitch = pitch;
+    int gi = (int)std::min<int64_t>((p.nreads + 255) / 256, (int64_t)c->cus * 16);
+    hipLaunchKernelGGL(k4_read_records, dim3((unsigned)std::max(gi, 1)), dim3(256), 0, c->stream, ip);
+    HIPCHK(hipGetLastError());
+    return KBBQ_OK;
+}
+
 // ---- K4 / K5: benchmark path --------------------------------------------
 int kbbq_find_errors_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint32_t* d_len, int64_t nreads, int pitch,
                          const int64_t* d_ref_start, const int32_t* d_ref_len,
@@ -1520,18 +1547,10 @@ int kbbq_find_errors_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint32_t* d_le
         HIPCHK(hipGetLastError());
         return KBBQ_OK;
     }
-    // the first four operations of every read inline, one 16-byte record per read (context-owned scratch)
-    const size_t need = (size_t)nreads * sizeof(K4Rec);
-    if (c->ops4_bytes < need) {
-        if (c->d_ops4) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_ops4); c->d_ops4 = nullptr; c->ops4_bytes = 0; }
-        HIPCHK(hipMalloc(&c->d_ops4, need));
-        c->ops4_bytes = need;
-    }
-    K4RecParams ip; ip.len = d_len; ip.ref_len = d_ref_len; ip.cig_off = d_cig_off; ip.cig_n = d_cig_n; ip.cigar = d_cigar;
-    ip.nreads = nreads; ip.recs = (K4Rec*)c->d_ops4;
-    int gi = (int)std::min<int64_t>((nreads + 255) / 256, (int64_t)c->cus * 16);
-    hipLaunchKernelGGL(k4_read_records, dim3((unsigned)std::max(gi, 1)), dim3(256), 0, c->stream, ip);
+    int rc4 = k4_records(c, p, nullptr, nullptr, nullptr, nullptr, 0);
+    if (rc4) return rc4;
     K4v2Params q; q.base = p; q.recs = (const K4Rec*)c->d_ops4; q.idle16 = reinterpret_cast<const uint8_t*>(c->d_status);
+    q.rows = nullptr; q.nrows = nullptr;
     if (d_skipmask) hipLaunchKernelGGL(k4v2_find_errors<false>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, q);
     else hipLaunchKernelGGL(k4v2_find_errors<true>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, q);
     HIPCHK(hipGetLastError());
@@ -1583,9 +1602,12 @@ int kbbq_canonical_reads_rows_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8
 // K6 fused into K1 (k1v3_aligned): the BAM-sourced tally straight from the reads as aligned -- 3 B/base read (sequence, OQ,
 // K4's plane of flags), nothing written but the count tables; kbbq_canonical_reads_rows_dev + kbbq_accumulate_rows_dev moved
 // 3 + 2 + 2 B/base for the same tables.
-int kbbq_accumulate_aligned_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_oq, const uint8_t* d_flagplane,
-                                const uint32_t* d_clip, const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads,
-                                int pitch, int S, int R, int minscore, int dinuc_minscore, int64_t* d_tables)
+// d_genome / d_g0 non-NULL: the REF form (k1v3_aligned_ref) -- reads whose d_flags word has bit 2 set are compared with the
+// reference by the kernel itself (kbbq_tally_aligned_dev)
+static int accumulate_aligned(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_oq, const uint8_t* d_flagplane,
+                              const uint32_t* d_clip, const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads,
+                              int pitch, int S, int R, int minscore, int dinuc_minscore, int64_t* d_tables,
+                              const uint8_t* d_genome, const int64_t* d_g0, bool dry_run = false)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
     int rc = check_planes("kbbq_accumulate_aligned_dev", nreads, pitch, d_seq, d_oq, d_flagplane);
@@ -1601,6 +1623,7 @@ int kbbq_accumulate_aligned_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t
     memset(&q, 0, sizeof q);
     q.seq = d_seq; q.cseq = d_flagplane; q.qual = d_oq; q.meta = nullptr;
     q.aflags = d_flags; q.aclip = d_clip; q.atrim = d_trim;
+    q.genome = d_genome; q.ag0 = reinterpret_cast<const long long*>(d_g0);
     q.nreads = nreads; q.pitch = pitch; q.cpr = pitch / 16; q.cpr_magic = magic_for(q.cpr);
     q.R = R; q.S = S; q.gS2 = 2 * S; q.minscore = minscore; q.type_minscore = dinuc_minscore;
     q.qlo_m1 = 32u + (u32)minscore; q.dlo = 33u + (u32)dinuc_minscore;
@@ -1620,6 +1643,7 @@ int kbbq_accumulate_aligned_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t
         if (lds3 <= (size_t)c->lds_bytes && (K1V3_THREADS / copies) * 16 * q.cpr <= 65535) { dn = copies; break; }
     }
     if (!dn) return fail(KBBQ_E_LUT, "kbbq_accumulate_aligned_dev: %d-base reads with minscore %d do not fit the LDS tables; tally through kbbq_canonical_reads_rows_dev", S, minscore);
+    if (dry_run) return KBBQ_OK;                      // the caller only asked whether this shape is served
     {   // several trash rows, then copies of the cycle table for short reads, as the LDS allows (accumulate_rows)
         q.pos_copies = 1; q.ntrash = 1;
         auto bytes_for = [&](int nt, int pc) {
@@ -1644,7 +1668,15 @@ int kbbq_accumulate_aligned_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t
     dim3 grid((unsigned)gx, (unsigned)R, 1), block(K1V3_THREADS, 1, 1);
     {
         Timed t(c, 0);
-        if (dn == K1V3_DNREP) {
+        if (d_genome) {
+            if (dn == K1V3_DNREP) {
+                if (split) hipLaunchKernelGGL((k1v3_aligned_ref<true, K1V3_DNREP>), grid, block, lds3, c->stream, q);
+                else hipLaunchKernelGGL((k1v3_aligned_ref<false, K1V3_DNREP>), grid, block, lds3, c->stream, q);
+            } else {
+                if (split) hipLaunchKernelGGL((k1v3_aligned_ref<true, 8>), grid, block, lds3, c->stream, q);
+                else hipLaunchKernelGGL((k1v3_aligned_ref<false, 8>), grid, block, lds3, c->stream, q);
+            }
+        } else if (dn == K1V3_DNREP) {
             if (split) hipLaunchKernelGGL((k1v3_aligned<true, K1V3_DNREP>), grid, block, lds3, c->stream, q);
             else hipLaunchKernelGGL((k1v3_aligned<false, K1V3_DNREP>), grid, block, lds3, c->stream, q);
         } else {
@@ -1654,6 +1686,77 @@ int kbbq_accumulate_aligned_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t
     }
     HIPCHK(hipGetLastError());
     return KBBQ_OK;
+}
+
+int kbbq_accumulate_aligned_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_oq, const uint8_t* d_flagplane,
+                                const uint32_t* d_clip, const uint32_t* d_trim, const uint32_t* d_flags, int64_t nreads,
+                                int pitch, int S, int R, int minscore, int dinuc_minscore, int64_t* d_tables)
+{
+    return accumulate_aligned(c, d_seq, d_oq, d_flagplane, d_clip, d_trim, d_flags, nreads, pitch, S, R, minscore, dinuc_minscore,
+                              d_tables, nullptr, nullptr);
+}
+
+// The whole BAM-sourced tally (gatk/bqsr.py:52-123: find_read_errors per read, then the covariate counts) with ONE pass over
+// the reads for everything but the reads K4 has to walk.  kbbq_find_errors_dev + kbbq_accumulate_aligned_dev move read bytes
+// and the reference in, a plane of flags out and read bytes, flags and OQ in again: 6 B/base.  Here k4_read_records sorts the
+// reads: one M / = / X operation over all bases, every 16-byte reference window readable -> the tally kernel compares read and
+// reference itself (k1v3_aligned_ref: read bytes, OQ, reference window = 3 B/base); every other read (indels, clips in the
+// CIGAR, anything odd) is listed, k4v2_find_errors writes the rows of d_flagplane of just those reads, and the tally kernel
+// reads them there.  d_flagplane: [nreads, pitch] scratch of the caller's, contents on entry irrelevant.  The reference must
+// carry the site flags in bit 7 (d_skipmask == NULL in kbbq_find_errors_dev's terms).  Every read has S bases (d_len[i] == S
+// is the caller's promise, as for kbbq_accumulate_aligned_dev).  Counts are what kbbq_find_errors_dev (no flip) followed by
+// kbbq_accumulate_aligned_dev count; the same statuses are raised (KBBQ_E_LUT: use kbbq_canonical_reads_rows_dev).
+int kbbq_tally_aligned_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_oq, const uint32_t* d_len, int64_t nreads,
+                           int pitch, int S, const int64_t* d_ref_start, const int32_t* d_ref_len,
+                           const uint32_t* d_cig_off, const uint32_t* d_cig_n, const uint32_t* d_cigar,
+                           const uint8_t* d_genome, int64_t genome_len,
+                           const uint32_t* d_clip, const uint32_t* d_trim, const uint32_t* d_flags,
+                           uint8_t* d_flagplane, int R, int minscore, int dinuc_minscore, int64_t* d_tables)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    if (nreads < 0 || nreads > 0xFFFFFFFFll || pitch <= 0 || (pitch & 15) || genome_len < 0) return fail(KBBQ_E_ARG, "kbbq_tally_aligned_dev: bad nreads/pitch/genome_len");
+    if (nreads == 0) return KBBQ_OK;
+    if (!d_seq || !d_oq || !d_len || !d_ref_start || !d_ref_len || !d_cig_off || !d_cig_n || !d_cigar || !d_genome || !d_clip || !d_trim
+        || !d_flags || !d_flagplane || !d_tables) return fail(KBBQ_E_ARG, "kbbq_tally_aligned_dev: NULL pointer");
+    if (((uintptr_t)d_seq | (uintptr_t)d_oq | (uintptr_t)d_flagplane) & 15) return fail(KBBQ_E_ARG, "kbbq_tally_aligned_dev: planes must be 16-byte aligned");
+    // what the tally kernel refuses it refuses before anything is launched (same checks, same codes)
+    if (S <= 0 || S > pitch || S > 32767 || pitch != ((S + 15) & ~15)) return fail(KBBQ_E_ARG, "kbbq_tally_aligned_dev: rows of S = %d bases have pitch %d (got %d)", S, (S + 15) & ~15, pitch);
+    if (S < 32) return fail(KBBQ_E_LUT, "kbbq_tally_aligned_dev: reads of %d bases (< 32) are tallied through kbbq_canonical_reads_rows_dev", S);
+    int rc = accumulate_aligned(c, d_seq, d_oq, d_flagplane, d_clip, d_trim, d_flags, nreads, pitch, S, R, minscore, dinuc_minscore,
+                                d_tables, d_genome, d_ref_start, true);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t need = 16 + 2 * (size_t)nreads * sizeof(u32);
+    if (c->tally_bytes < need) {
+        if (c->d_tally) { HIPCHK(hipStreamSynchronize(c->stream)); (void)hipFree(c->d_tally); c->d_tally = nullptr; c->tally_bytes = 0; }
+        HIPCHK(hipMalloc(&c->d_tally, need));
+        c->tally_bytes = need;
+    }
+    u32* count = reinterpret_cast<u32*>(c->d_tally);
+    u32* aflags2 = count + 4;
+    u32* rows = aflags2 + nreads;
+    HIPCHK(hipMemsetAsync(count, 0, 16, c->stream));
+    K4Params p;
+    p.seq = d_seq; p.len = d_len; p.nreads = nreads; p.pitch = pitch;
+    p.ref_start = (const long long*)d_ref_start; p.ref_len = d_ref_len;
+    p.cig_off = d_cig_off; p.cig_n = d_cig_n; p.cigar = d_cigar;
+    p.genome = d_genome; p.skipmask = nullptr; p.genome_len = genome_len; p.flip = nullptr; p.err = d_flagplane; p.skip = nullptr;
+    p.status = c->d_status;
+    rc = k4_records(c, p, d_flags, aflags2, rows, count, pitch);
+    if (rc) return rc;
+    {   // K4 over the listed reads only: their number is on the device, the grid is sized for a share of the reads (a workgroup
+        // beyond the list's end finds nothing to do) -- KBBQ_TALLY_K4_SHARE: 1 / share of the reads' grid, default 8
+        const int rpb4 = (pitch / 16) <= 256 ? 256 / (pitch / 16) : 1;
+        const char* sh = getenv("KBBQ_TALLY_K4_SHARE");
+        const int share = sh && atoi(sh) > 0 ? atoi(sh) : 8;
+        const int gx = bounded_grid(((nreads + share - 1) / share + rpb4 - 1) / rpb4, c, 64, "KBBQ_K4_GRID");
+        K4v2Params q; q.base = p; q.recs = (const K4Rec*)c->d_ops4; q.idle16 = reinterpret_cast<const uint8_t*>(c->d_status);
+        q.rows = rows; q.nrows = count;
+        hipLaunchKernelGGL(k4v2_find_errors<true>, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, q);
+        HIPCHK(hipGetLastError());
+    }
+    return accumulate_aligned(c, d_seq, d_oq, d_flagplane, d_clip, d_trim, aflags2, nreads, pitch, S, R, minscore, dinuc_minscore,
+                              d_tables, d_genome, d_ref_start);
 }
 
 int kbbq_count_q_dev(kbbq_ctx* c, const uint8_t* d_qual, const uint8_t* d_err, const uint8_t* d_skip,

@@ -61,6 +61,11 @@ struct K1v3Params {
     const u32* aflags;          // bit 0 reverse strand, bit 1 read 2, bits 16.. read group
     const u32* aclip;           // query_alignment_start | query_alignment_end << 16
     const u32* atrim;           // skipped range lo | hi << 16 (adaptor; lo == hi: none)
+    // REF form (K4 folded in as well, for reads that are ONE M / = / X operation over all their bases): bit 2 of a read's aflags
+    // word says "no plane of flags for this read: compare it with the reference here" -- cseq is then only read for the other
+    // reads (k4v2_find_errors wrote their rows), and a chunk of such a read loads 16 bytes of `genome` (bit 7 of a byte: the
+    // site's skip flag) at ag0[read] + its offset in the read instead
+    const uint8_t* genome; const long long* ag0;
     // copies of the cycle table (1, 2 or 4; KJ == 0 forms): a chunk counts into copy (row slot & (copies - 1)), the flush sums them.
     // Narrow rows put many lanes of a wave on the same few columns (pitch 48: 21 lanes per column), i.e. onto the same (quality,
     // column) words: same-address LDS atomics serialise.  Their tables are small, so copies fit the LDS beside the context table.
@@ -127,6 +132,16 @@ __device__ __forceinline__ u32 nonzero_bytes(u32 x)
     return ((x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u;
 }
 
+// 16 bytes starting at ANY byte offset: one global_load_dwordx4 with an unaligned address (the
+// amdhsa targets run with unaligned access mode on; the compiler itself emits this for a
+// 1-byte-aligned 16-byte copy).  The caller guarantees the 16 bytes are readable.
+__device__ __forceinline__ void load16_any(const uint8_t* base, long long off, u32 out[4])
+{
+    uint4 v;
+    __builtin_memcpy(&v, base + off, 16);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+
 __device__ __forceinline__ void reverse16(u32 v[4])                      // byte i <- byte 15 - i
 {
     const u32 a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
@@ -136,7 +151,7 @@ __device__ __forceinline__ void reverse16(u32 v[4])                      // byte
 
 typedef __attribute__((address_space(3))) u32 lds_u32;
 
-struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int k; int j; int nb; u32 fl, clip, trim; int jj; };
+struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int k; int j; int nb; u32 fl, clip, trim; int jj; u32 g0lo, g0hi; };
 
 // LDS: dn [nrows][32][16] u32 context counts (errs << 16 | total), 16 copies (copy = lane & 15:
 //          the table is tiny and hot -- measured 15 LDS cycles per wave-atomic unreplicated --
@@ -167,10 +182,11 @@ struct K1Chunk { u32 s[4], c[4], q[4]; u32 mk; u32 off; int k; int j; int nb; u3
 // [qs, qe), inside the trimmed range, where K4 set the skip flag or where it is N (bqsr.py:86-88); bases outside the
 // aligned part are no context either (code 4).  The error flag is K4's bit 0.  A forward read with a letter outside ACGTN
 // is reported (ST_LUT): the caller repeats the tally through K6's character planes, where the reference's TypeError is decided.
-template <bool SPLIT, int DN, bool NIB, int KJ, bool ALN = false>
+template <bool SPLIT, int DN, bool NIB, int KJ, bool ALN = false, bool REF = false>
 __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const int bx, const int gx, const int g)
 {
     static_assert(!ALN || (!NIB && KJ == 0), "the aligned-read form reads character planes");
+    static_assert(!REF || ALN, "the reference comparison belongs to the aligned-read form");
     const int ntrash = KJ > 0 ? 1 : p.ntrash;
     const int dn_words = (p.nrows - 1 + ntrash) * 32 * DN;
     const int ncopies = KJ > 0 ? 1 : p.pos_copies;
@@ -280,11 +296,15 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
         if (blk < nblocks) {
             const long long read0 = seg_lo + (blk << 6);
             const long long myread = read0 + lane;
-            u32 m, afl = 0u, aclip = 0u, atrim = 0u;
+            u32 m, afl = 0u, aclip = 0u, atrim = 0u, ag0lo = 0u, ag0hi = 0u;
             if constexpr (ALN) {
                 afl = myread < seg_hi ? p.aflags[myread] : 0u;
                 aclip = myread < seg_hi ? p.aclip[myread] : 0u;
                 atrim = myread < seg_hi ? p.atrim[myread] : 0u;
+                if constexpr (REF) {
+                    const long long g0 = myread < seg_hi ? p.ag0[myread] : 0ll;
+                    ag0lo = (u32)g0; ag0hi = (u32)((u64)g0 >> 32);
+                }
                 m = myread < seg_hi ? ((u32)p.S | ((afl >> 16) << 16) | ((afl & 2u) << 30)) : 0u;     // every read has the common length S
             } else {
                 m = myread < seg_hi ? p.meta[myread] : 0u;
@@ -302,6 +322,10 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                     afl = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)(match ? afl : 0u));
                     aclip = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)(match ? aclip : 0u));
                     atrim = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)(match ? atrim : 0u));
+                    if constexpr (REF) {
+                        ag0lo = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)(match ? ag0lo : 0u));
+                        ag0hi = (u32)__builtin_amdgcn_ds_permute(dst << 2, (int)(match ? ag0hi : 0u));
+                    }
                 }
             }
             const uint8_t* bseq = p.seq + (size_t)read0 * (NIB ? p.pitch >> 1 : p.pitch);
@@ -329,6 +353,7 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                 if constexpr (ALN) {
                     ch.fl = bperm(afl, k); ch.clip = bperm(aclip, k); ch.trim = bperm(atrim, k);
                     if (ch.fl & 1u) ch.jj = p.cpr - 1 - ch.j;          // a reverse-strand read: its chunks last to first
+                    if constexpr (REF) { ch.g0lo = bperm(ag0lo, k); ch.g0hi = bperm(ag0hi, k); }
                 }
                 // lanes without work re-read the block's first chunk (valid memory, result unused)
 #ifndef KBBQ_ABL_NOLOAD
@@ -340,6 +365,16 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                     const uint2 sv = *reinterpret_cast<const uint2*>(bseq + (rowoff >> 1));
                     const uint2 cv = *reinterpret_cast<const uint2*>(bcseq + (rowoff >> 1));
                     ch.s[0] = sv.x; ch.s[1] = sv.y; ch.c[0] = cv.x; ch.c[1] = cv.y;
+                } else if constexpr (REF) {
+                    // a one-operation read: the chunk's reference window (any byte offset) instead of its row of K4's flags --
+                    // ONE unconditional 16-byte load from whichever address applies (a load under a branch would be waited for
+                    // at the branch's end)
+                    const uint4 sv = *reinterpret_cast<const uint4*>(bseq + rowoff);
+                    const bool inref = ch.nb > 0 && (ch.fl & 4u) != 0u;
+                    const long long g0 = (long long)(((u64)ch.g0hi << 32) | (u64)ch.g0lo);
+                    const uint8_t* src = inref ? p.genome + g0 + 16 * ch.jj : bcseq + rowoff;
+                    load16_any(src, 0, ch.c);
+                    ch.s[0] = sv.x; ch.s[1] = sv.y; ch.s[2] = sv.z; ch.s[3] = sv.w;
                 } else {
                     const uint4 sv = *reinterpret_cast<const uint4*>(bseq + rowoff);
                     const uint4 cv = *reinterpret_cast<const uint4*>(bcseq + rowoff);
@@ -375,6 +410,15 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                     u32 counted = aligned & ~bits(tlo - i0, thi - i0);               // ... and not trimmed away (adaptor)
                     u32 sv[4] = {ch.s[0], ch.s[1], ch.s[2], ch.s[3]}, fv[4] = {ch.c[0], ch.c[1], ch.c[2], ch.c[3]};
                     u32 ov[4] = {ch.q[0], ch.q[1], ch.q[2], ch.q[3]};
+                    if constexpr (REF) {
+                        // compare_reads.py:109-114 for a chunk inside the read's one M / = / X operation, as k4v2_find_errors' plain
+                        // path makes them: error = read byte != reference byte, skip = the site's flag (bit 7 of the reference byte)
+                        if (ch.fl & 4u) {
+#pragma unroll
+                            for (int wd = 0; wd < 4; ++wd)
+                                fv[wd] = nonzero_bytes(sv[wd] ^ (fv[wd] & 0x7F7F7F7Fu)) | ((fv[wd] >> 6) & 0x02020202u);
+                        }
+                    }
                     if (rev) {
                         reverse16(sv); reverse16(fv); reverse16(ov);
                         aligned = __brev(aligned) >> 16; counted = __brev(counted) >> 16;
@@ -547,6 +591,14 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_aligned(K1v3Params p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     k1v3_body<SPLIT, DN, false, 0, true>(p, lds, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
+}
+
+// ... and K4 folded in for reads of one M / = / X operation (kbbq_tally_aligned_dev): read bytes, OQ and the reference window
+template <bool SPLIT, int DN>
+__global__ __launch_bounds__(K1V3_THREADS) void k1v3_aligned_ref(K1v3Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    k1v3_body<SPLIT, DN, false, 0, true, true>(p, lds, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
 }
 
 // ONE launch over all length bands of a mixed-length input (BASELINE config 5; recalibrate.py:81-101 grows its arrays as the
@@ -913,16 +965,6 @@ struct K4Params {
     long long genome_len;            // bytes in genome / skipmask
     uint8_t* err; uint8_t* skip; u64* status;
 };
-
-// 16 bytes starting at ANY byte offset: one global_load_dwordx4 with an unaligned address (the
-// amdhsa targets run with unaligned access mode on; the compiler itself emits this for a
-// 1-byte-aligned 16-byte copy).  The caller guarantees the 16 bytes are readable.
-__device__ __forceinline__ void load16_any(const uint8_t* base, long long off, u32 out[4])
-{
-    uint4 v;
-    __builtin_memcpy(&v, base + off, 16);
-    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
-}
 
 // the same, for windows that may run past the end of the array (`limit` = its size in bytes): bytes past
 // the end read as zero.  Only the last chunk of the last rows / of the genome ever takes the byte path.

@@ -82,6 +82,7 @@ PROTOTYPES = {
     'kbbq_solve_dev': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'kbbq_find_errors_dev': (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     'kbbq_accumulate_aligned_dev': (_i, [_vp] * 7 + [_i64, _i, _i, _i, _i, _i, _vp]),
+    'kbbq_tally_aligned_dev': (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i] + [_vp] * 6 + [_i64] + [_vp] * 4 + [_i, _i, _i, _vp]),
     'kbbq_count_q_dev': (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     'kbbq_pair_pitch': (_i, [_i]),
     'kbbq_pair_lut_bytes': (_sz, [_i, _i, _i]),

@@ -131,33 +131,47 @@ def _read_arrays(reads, genome, flip_reverse, rows=None):
     return n, lens, pitch, seq, ref_start, ref_len, cig_off, cig_n, np.array(cigar, dtype=np.uint32), flip
 
 
-def _flag_batch(reads, genome, flip_reverse, keep=None, rows=None, fused=False):
-    """K4 over aligned reads (an aln.AlignmentFile or a list of read objects) -> (err, skip) device planes
-    [n, pitch], lens (host).  `keep`, a dict, receives the device seq plane for callers that go on to K6.
-    rows = (lo, hi): only those alignments (one rank's shard).  fused: ONE plane of flags (bit 0 error, bit 1 skip)
-    comes back as `err` and `skip` is None -- the form K5 / K6 read when they are the only consumers."""
+def _upload_reads(reads, genome, flip_reverse, rows=None):
+    """The arrays K4 reads, on the device: dict(n, lens (host), pitch, seq, len, cigar, ref_start, ref_len, flip, cig_off, cig_n)
+    of an aln.AlignmentFile or a list of read objects; rows = (lo, hi): only those alignments (one rank's shard)."""
     from . import _device as dev
-    from . import _native as N
     torch = dev._torch()
     n, lens, pitch, seq, ref_start, ref_len, cig_off, cig_n, cigar, flip = _read_arrays(reads, genome, flip_reverse, rows)
     pad = lambda a, dt: np.ascontiguousarray(a if len(a) else np.zeros(1), dtype=dt)
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    d_seq, d_len = up(seq), up(pad(lens, np.uint32).view(np.int32))
-    d_cigar = up(pad(cigar, np.uint32).view(np.int32))
+    return dict(n=n, lens=lens, pitch=pitch, seq=up(seq), len=up(pad(lens, np.uint32).view(np.int32)),
+                cigar=up(pad(cigar, np.uint32).view(np.int32)), ref_start=up(pad(ref_start, np.int64)),
+                ref_len=up(pad(ref_len, np.int32)), flip=up(pad(flip, np.uint8)),
+                cig_off=up(pad(cig_off, np.uint32).view(np.int32)), cig_n=up(pad(cig_n, np.uint32).view(np.int32)))
+
+
+def _find_errors(u, genome, fused=False):
+    """K4 over uploaded reads (_upload_reads) -> (err, skip) device planes [n, pitch]; fused: ONE plane of flags (bit 0 error,
+    bit 1 skip) comes back as `err` and `skip` is None -- the form K5 / K6 read when they are the only consumers."""
+    from . import _device as dev
+    from . import _native as N
+    torch = dev._torch()
+    n, pitch = u['n'], u['pitch']
     err = torch.zeros((max(n, 1), pitch), dtype=torch.uint8, device='cuda')
     skip = None if fused else torch.zeros((max(n, 1), pitch), dtype=torch.uint8, device='cuda')
-    if keep is not None:
-        keep['seq'] = d_seq
     ctx = dev.context()
-    # keep every device tensor referenced until the kernel has run (N.ptr only takes the address)
-    d_rs, d_rl, d_flip = up(pad(ref_start, np.int64)), up(pad(ref_len, np.int32)), up(pad(flip, np.uint8))
-    d_co, d_cn = up(pad(cig_off, np.uint32).view(np.int32)), up(pad(cig_n, np.uint32).view(np.int32))
-    N.check(N.load().kbbq_find_errors_dev(ctx.handle, N.ptr(d_seq), N.ptr(d_len), n, pitch,
-                                          N.ptr(d_rs), N.ptr(d_rl), N.ptr(d_co), N.ptr(d_cn),
-                                          N.ptr(d_cigar), N.ptr(genome.genome), N.ptr(genome.mask), genome.length,
-                                          N.ptr(d_flip), N.ptr(err), N.ptr(skip)))
+    N.check(N.load().kbbq_find_errors_dev(ctx.handle, N.ptr(u['seq']), N.ptr(u['len']), n, pitch,
+                                          N.ptr(u['ref_start']), N.ptr(u['ref_len']), N.ptr(u['cig_off']), N.ptr(u['cig_n']),
+                                          N.ptr(u['cigar']), N.ptr(genome.genome), N.ptr(genome.mask), genome.length,
+                                          N.ptr(u['flip']), N.ptr(err), N.ptr(skip)))
     ctx.status()
-    return err, skip, lens, pitch
+    return err, skip
+
+
+def _flag_batch(reads, genome, flip_reverse, keep=None, rows=None, fused=False):
+    """K4 over aligned reads (an aln.AlignmentFile or a list of read objects) -> (err, skip) device planes
+    [n, pitch], lens (host).  `keep`, a dict, receives the device seq plane for callers that go on to K6.
+    rows = (lo, hi): only those alignments (one rank's shard).  fused: see _find_errors."""
+    u = _upload_reads(reads, genome, flip_reverse, rows)
+    if keep is not None:
+        keep['seq'] = u['seq']
+    err, skip = _find_errors(u, genome, fused)
+    return err, skip, u['lens'], u['pitch']
 
 
 def _match_native(bam, fq):

@@ -213,13 +213,33 @@ def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxsc
     tables = dev.Tables(max(R, 1), 2 * S)
 
     def shard():
-        kept = {}
-        err, skip, _, pitch = benchmark._flag_batch(reads, genome, flip_reverse=False, keep=kept, rows=(lo, hi), fused=True)
+        import os
+        u = benchmark._upload_reads(reads, genome, False, rows=(lo, hi))
+        pitch = u['pitch']
         oq = reads.batch().plane(2, pitch, lo, m) if native else oq_all[lo:hi, :pitch]
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-        d_seq, d_oq = kept['seq'], up(oq)
+        d_seq, d_oq = u['seq'], up(oq)
         d_len, d_clip, d_trim, d_flags = (up(x[lo:hi].view(np.int32)) for x in (lens, clip, trim, flags))
         ctx = dev.context()
+        mode = os.environ.get('KBBQ_TALLY_FUSED', '2')
+        fits = pitch == (S + 15) // 16 * 16 and S <= 32767
+        # K4 and K6 both folded into K1 (kbbq_tally_aligned_dev): reads that are one M / = / X operation are compared with the
+        # reference by the tally kernel itself, K4 only looks at the others -- 3 B/base instead of 6.  Needs the site flags in
+        # bit 7 of the reference bytes (benchmark._Genome: an ASCII reference); refusals as below, counted into tables of its own.
+        if mode == '2' and fits and genome.mask is None:
+            try:
+                part = dev.Tables(max(R, 1), 2 * S)
+                plane = torch.empty((max(m, 1), pitch), dtype=torch.uint8, device='cuda')     # rows of the reads K4 looks at
+                N.check(N.load().kbbq_tally_aligned_dev(
+                    ctx.handle, N.ptr(d_seq), N.ptr(d_oq), N.ptr(u['len']), m, pitch, S, N.ptr(u['ref_start']), N.ptr(u['ref_len']),
+                    N.ptr(u['cig_off']), N.ptr(u['cig_n']), N.ptr(u['cigar']), N.ptr(genome.genome), genome.length,
+                    N.ptr(d_clip), N.ptr(d_trim), N.ptr(d_flags), N.ptr(plane), max(R, 1), minscore, 6, N.ptr(part.buf)))
+                ctx.status()
+                tables.add(part)
+                return
+            except N.LutNeedsCheckedApply:
+                pass
+        err, skip = benchmark._find_errors(u, genome, fused=True)
 
         def canonical(nib):
             batch = dev.ReadBatch(m, pitch, with_corrected=True, nib=nib)
@@ -232,8 +252,7 @@ def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxsc
         # K6 fused into K1 (kbbq_accumulate_aligned_dev): the tally straight from the reads as aligned, nothing written but the
         # tables -- unless a forward read carries a letter outside ACGTN or the tables do not fit the LDS beside it (both
         # reported before / without anything reaching `tables`: the attempt counts into tables of its own); then, as before:
-        import os
-        if os.environ.get('KBBQ_TALLY_FUSED') != '0' and pitch == (S + 15) // 16 * 16 and S <= 32767:
+        if mode != '0' and fits:
             try:
                 part = dev.Tables(max(R, 1), 2 * S)
                 N.check(N.load().kbbq_accumulate_aligned_dev(ctx.handle, N.ptr(d_seq), N.ptr(d_oq), N.ptr(err), N.ptr(d_clip), N.ptr(d_trim),

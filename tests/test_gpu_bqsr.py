@@ -71,7 +71,7 @@ def test_tally_matches_oracle(dev, oracle, shape, minscore, tmp_path, monkeypatc
     paths = OQ.synth_bqsr_set(str(tmp_path), **shape)
     want = _oracle_vectors(paths, minscore)
     ctx = dev.context()
-    for fused in ('1', '0'):                               # K6 fused into K1 (the default), and K6 -> K1 through canonical reads
+    for fused in ('2', '1', '0'):                          # one pass (the default: K4 and K6 folded into K1), K4 -> fused K6 + K1, K4 -> K6 -> K1
         monkeypatch.setenv('KBBQ_TALLY_FUSED', fused)
         ctx.kernel_ms(0, reset=True); ctx.timing(True)
         got = bqsr.bam_to_bqsr_covariates(aln.AlignmentFile(paths['sam']), paths['fa'], _var_pos(paths['vcf']),
@@ -223,3 +223,91 @@ def test_canonical_reads_on_four_bit_planes_equal_the_character_planes(dev, L):
     odd[(~rev).nonzero()[0], (lo[~rev][0] + 1).long()] = ord('R')
     with pytest.raises(N.LutNeedsCheckedApply):
         canonical(True, odd)
+
+
+@pytest.mark.parametrize('L,G', [(150, 200_000), (37, 5_000), (100, 1_000), (32, 40)])
+def test_the_one_pass_tally_counts_what_k4_then_the_fused_kernel_count(dev, L, G):
+    """kbbq_tally_aligned_dev == kbbq_find_errors_dev (one plane of flags, no flip) + kbbq_accumulate_aligned_dev on the same
+    arrays: reads of one M operation (compared with the reference by the tally kernel itself), insertions, deletions, soft
+    clips, = / X operations, more than four operations, reads at both ends of the genome, both strands, several read groups."""
+    import torch
+    from kbbq import _native as N
+    rng = np.random.default_rng(1000 + L)
+    n, pitch = 5003, (L + 15) // 16 * 16
+    genome = rng.choice(np.frombuffer(b'ACGTN', dtype=np.uint8), size=G, p=[.24, .24, .24, .24, .04])
+    sites = (rng.random(G) < 0.05).astype(np.uint8)
+    cig, cig_off, cig_n, ref_len = [], np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.int32)
+    start = np.zeros(n, np.int64)
+    seq = np.zeros((n, pitch), dtype=np.uint8)
+    kinds = rng.integers(0, 10, n)
+    for i in range(n):
+        k = kinds[i]
+        if k <= 4:
+            ops = [(0, L)]                                               # one M: the tally kernel's own comparison
+        elif k == 5:
+            a = int(rng.integers(1, L - 2)); ops = [(0, a), (1, int(rng.integers(1, 3))), (0, 0)]      # insertion
+        elif k == 6:
+            a = int(rng.integers(1, L - 1)); ops = [(0, a), (2, int(rng.integers(1, max(2, min(20, G - L + 1))))), (0, L - a)]  # deletion
+        elif k == 7:
+            a = int(rng.integers(1, min(10, L - 1))); ops = [(4, a), (0, L - a)]                         # soft clip
+        elif k == 8:
+            a = int(rng.integers(1, L - 1)); ops = [(7, a), (8, L - a)]                                  # = then X
+        else:
+            parts = np.diff(np.concatenate([[0], np.sort(rng.choice(np.arange(1, L), size=5, replace=False)), [L]]))
+            ops = [(0, int(x)) for x in parts]                                                           # six operations
+        ops = [(o, l) for o, l in ops]
+        used = sum(l for o, l in ops if o in (0, 1, 4, 7, 8))
+        ops = [(o, (l if (o, l) != (0, 0) else L - used)) for o, l in ops]
+        rl = sum(l for o, l in ops if o in (0, 2, 3, 7, 8))
+        edge = rng.integers(0, 40)
+        start[i] = 0 if edge == 0 else (G - rl if edge == 1 else int(rng.integers(0, G - rl + 1)))
+        ref_len[i] = rl
+        cig_off[i] = len(cig); cig_n[i] = len(ops)
+        cig += [(l << 4) | o for o, l in ops]
+        # the read: the reference along its CIGAR, with substitutions
+        r, g = [], int(start[i])
+        for o, l in ops:
+            if o in (0, 7, 8):
+                r.append(genome[g:g + l]); g += l
+            elif o in (1, 4):
+                r.append(rng.choice(np.frombuffer(b'ACGT', dtype=np.uint8), size=l))
+            else:
+                g += l
+        r = np.concatenate(r)
+        assert len(r) == L
+        sub = rng.random(L) < 0.05
+        r = np.where(sub, rng.choice(np.frombuffer(b'ACGT', dtype=np.uint8), size=L), r)
+        seq[i, :L] = r
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_seq, d_gen = up(seq), up(genome | (sites << 7))
+    d_start, d_rl, d_co, d_cn = up(start), up(ref_len), up(cig_off.view(np.int32)), up(cig_n.view(np.int32))
+    d_cig = up(np.array(cig, dtype=np.uint32).view(np.int32))
+    d_len = up(np.full(n, L, np.int32))
+    d_oq = up(rng.integers(33, 33 + 43, (n, pitch)).astype(np.uint8))
+    lo = rng.integers(0, L // 3 + 1, n); hi = L - rng.integers(0, L // 3 + 1, n)
+    d_clip = up((lo | (hi << 16)).astype(np.int32))
+    tl = rng.integers(0, L, n)
+    d_trim = up(np.where(rng.integers(0, 4, n) == 0, tl | (np.minimum(tl + 9, L) << 16), 0).astype(np.int32))
+    d_flags = up((rng.integers(0, 4, n) | (rng.integers(0, 3, n) << 16)).astype(np.int32))
+    ctx, lib = dev.context(), N.load()
+    plane = torch.zeros((n, pitch), dtype=torch.uint8, device='cuda')
+    N.check(lib.kbbq_find_errors_dev(ctx.handle, N.ptr(d_seq), N.ptr(d_len), n, pitch, N.ptr(d_start), N.ptr(d_rl), N.ptr(d_co), N.ptr(d_cn),
+                                     N.ptr(d_cig), N.ptr(d_gen), None, G, N.ptr(torch.zeros(n, dtype=torch.uint8, device='cuda')), N.ptr(plane), None))
+    ctx.status()
+    for minscore in (6, 2):
+        want, got = dev.Tables(3, 2 * L), dev.Tables(3, 2 * L)
+        N.check(lib.kbbq_accumulate_aligned_dev(ctx.handle, N.ptr(d_seq), N.ptr(d_oq), N.ptr(plane), N.ptr(d_clip), N.ptr(d_trim), N.ptr(d_flags),
+                                                n, pitch, L, 3, minscore, 6, N.ptr(want.buf)))
+        ctx.status()
+        scratch = torch.full((n, pitch), 0xA5, dtype=torch.uint8, device='cuda')       # whatever it held before
+        N.check(lib.kbbq_tally_aligned_dev(ctx.handle, N.ptr(d_seq), N.ptr(d_oq), N.ptr(d_len), n, pitch, L, N.ptr(d_start), N.ptr(d_rl),
+                                           N.ptr(d_co), N.ptr(d_cn), N.ptr(d_cig), N.ptr(d_gen), G, N.ptr(d_clip), N.ptr(d_trim), N.ptr(d_flags),
+                                           N.ptr(scratch), 3, minscore, 6, N.ptr(got.buf)))
+        ctx.status()
+        assert torch.equal(got.buf, want.buf) and int(want.buf.sum()) > 0
+        # only the rows of the reads K4 had to look at were written, and they hold K4's flags
+        touched = (scratch != 0xA5).any(1).cpu().numpy()
+        one_m = (kinds <= 4) & (start + pitch <= G)
+        assert not touched[one_m].any()
+        others = np.flatnonzero(~one_m)
+        assert torch.equal(scratch[torch.from_numpy(others).cuda()], plane[torch.from_numpy(others).cuda()])
