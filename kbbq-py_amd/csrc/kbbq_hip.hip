@@ -1272,6 +1272,13 @@ int kbbq_accumulate_bands_dev(kbbq_ctx* c, const kbbq_band* bands, int nbands, i
     HIPCHK(hipSetDevice(c->device));
     const char* rc_env = getenv("KBBQ_K1_BAND_ROWCOST");
     const double row_cost = rc_env ? atof(rc_env) : 1.25;
+    // ... and a chunk of a WIDE row costs more than a chunk of a narrow one (larger tables to zero and flush, 8 instead of 16 copies
+    // of the context table, more cycle columns for the same lanes): with equal cost per chunk the widest band of BASELINE config 5
+    // ended 25 % after the narrowest (KBBQ_K1_BANDS_DBG=1 prints every band's workgroup end times): + 1 % per chunk of row width
+    const char* sl_env = getenv("KBBQ_K1_BAND_SLOPE");
+    const double slope = sl_env ? atof(sl_env) : 0.01;
+    const char* d8_env = getenv("KBBQ_K1_BAND_DN8");          // a band on 8 copies of the context table: twice the same-address atomics there
+    const double dn8_cost = d8_env ? atof(d8_env) : 1.06;
     for (auto& grp : groups) {
         if (grp.empty()) continue;
         const int threads = setups[grp[0]].threads;
@@ -1285,7 +1292,7 @@ int kbbq_accumulate_bands_dev(kbbq_ctx* c, const kbbq_band* bands, int nbands, i
         size_t lds = 0;
         for (size_t k : grp) {
             const K1Setup& su = setups[k];
-            weight.push_back((double)su.q.nreads * (su.q.cpr + row_cost));
+            weight.push_back((double)su.q.nreads * (su.q.cpr + row_cost) * (1.0 + slope * su.q.cpr) * (su.dn == K1V3_DNREP ? 1.0 : dn8_cost));
             cap.push_back(std::max<int64_t>(1, su.iters));
             lds = std::max(lds, su.lds);
         }
@@ -1298,6 +1305,8 @@ int kbbq_accumulate_bands_dev(kbbq_ctx* c, const kbbq_band* bands, int nbands, i
         t.wg_start[grp.size()] = run;
         const bool split = setups[grp[0]].split;
         dim3 grid((unsigned)run, (unsigned)R, 1), block((unsigned)threads, 1, 1);
+        unsigned long long* dbg = nullptr;                    // KBBQ_K1_BANDS_DBG=1: when did every band's workgroups start and end?
+        if (getenv("KBBQ_K1_BANDS_DBG")) { HIPCHK(hipMalloc((void**)&dbg, sizeof(unsigned long long) * 2 * (size_t)run)); t.dbg = dbg; }
         {
             Timed tm(c, 0);
             if (nib_of_merge) {
@@ -1309,6 +1318,22 @@ int kbbq_accumulate_bands_dev(kbbq_ctx* c, const kbbq_band* bands, int nbands, i
             }
         }
         HIPCHK(hipGetLastError());
+        if (dbg) {
+            std::vector<unsigned long long> h(2 * (size_t)run);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpy(h.data(), dbg, h.size() * sizeof h[0], hipMemcpyDeviceToHost));
+            (void)hipFree(dbg);
+            unsigned long long t0 = ~0ull;
+            for (int w = 0; w < run; ++w) t0 = std::min(t0, h[(size_t)w]);
+            for (size_t j = 0; j < grp.size(); ++j) {
+                unsigned long long s1 = 0, e0 = ~0ull, e1 = 0;
+                for (int w = t.wg_start[j]; w < t.wg_start[j + 1]; ++w) {
+                    s1 = std::max(s1, h[(size_t)w] - t0); e0 = std::min(e0, h[(size_t)run + w] - t0); e1 = std::max(e1, h[(size_t)run + w] - t0);
+                }
+                fprintf(stderr, "[k1v3_bands] band %zu pitch %3d rows %9lld: %3d workgroups, last start %7.1f us, ends %7.1f .. %7.1f us\n", j, t.band[j].pitch,
+                        (long long)t.band[j].nreads, t.wg_start[j + 1] - t.wg_start[j], s1 / 100.0, e0 / 100.0, e1 / 100.0);
+            }
+        }
     }
     return KBBQ_OK;
 }

@@ -612,6 +612,7 @@ struct K1BandsParams {
     int nbands;
     int wg_start[K1V3_MAX_BANDS + 1];     // band b owns workgroups [wg_start[b], wg_start[b + 1]) of blockIdx.x
     int dn[K1V3_MAX_BANDS];               // copies of the context table: K1V3_DNREP or 8
+    unsigned long long* dbg;              // diagnostic (KBBQ_K1_BANDS_DBG): [2 * workgroups] start / end of every workgroup (s_memrealtime, 100 MHz)
     K1v3Params band[K1V3_MAX_BANDS];
 };
 
@@ -623,8 +624,10 @@ __global__ __launch_bounds__(K1V3_THREADS) void k1v3_bands(K1BandsParams t)
     while (b + 1 < t.nbands && (int)blockIdx.x >= t.wg_start[b + 1]) ++b;
     const K1v3Params& p = t.band[b];
     const int bx = (int)blockIdx.x - t.wg_start[b], gx = t.wg_start[b + 1] - t.wg_start[b];
+    if (t.dbg && threadIdx.x == 0 && blockIdx.y == 0) t.dbg[blockIdx.x] = wall_clock64();
     if (t.dn[b] == K1V3_DNREP) k1v3_body<SPLIT, K1V3_DNREP, NIB, 0>(p, lds, bx, gx, (int)blockIdx.y);
     else k1v3_body<SPLIT, 8, NIB, 0>(p, lds, bx, gx, (int)blockIdx.y);
+    if (t.dbg && threadIdx.x == 0 && blockIdx.y == 0) t.dbg[gridDim.x + blockIdx.x] = wall_clock64();
 }
 
 // ---------------------------------------------------------------- K2 (table-driven)
