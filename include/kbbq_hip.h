@@ -134,6 +134,11 @@ int kbbq_accumulate_ex_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d
 int kbbq_accumulate_band_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_cseq, const uint8_t* d_qual,
                              const uint32_t* d_meta, int64_t nreads, int pitch, int R, int S2, int S_band, int S_min,
                              int minscore, int dinuc_minscore, int64_t* d_tables);
+/* Host-buffer form (what a ctypes binding of the reference calls with NumPy arrays; ADDS into the four count arrays):
+ * the rows travel slab by slab through page-locked staging of the context's own -- host threads copy slab k + 1 while the
+ * copy engine uploads slab k and the kernel runs on slab k - 1 -- so device memory is two slabs whatever the input's size
+ * (KBBQ_STAGE_MB: staging bytes per slab, default 96 MB) and the call runs at the PCIe rate of its 3 planes.  A read the
+ * kernel flags is reported with its index in the WHOLE input; nothing is added to the caller's arrays then.            */
 int kbbq_accumulate(kbbq_ctx* ctx, const uint8_t* seq, const uint8_t* cseq,
                     const uint8_t* qual, const uint32_t* meta,
                     int64_t nreads, int pitch, int R, int S2, int minscore,
@@ -173,6 +178,9 @@ int kbbq_apply_dev(kbbq_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_qual,
                    const uint32_t* d_meta, int64_t nreads, int pitch,
                    int R, int Qt, int S2, int minscore,
                    const void* d_lut_blob, int mode, uint8_t* d_qual_out);
+/* Host-buffer form: LUT built on the host (kbbq_build_lut), rows through the same page-locked slabs as kbbq_accumulate --
+ * upload of slab k + 1, kernel on slab k and download of slab k - 1 overlap (PCIe is full duplex).  On an error status the
+ * read index is that of the WHOLE input and the contents of qual_out are unspecified.                                  */
 int kbbq_apply(kbbq_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint32_t* meta,
                int64_t nreads, int pitch, int R, int Qt, int S2, int D, int minscore,
                const int64_t* meanq, const int64_t* rgdq, const int64_t* qdq,

@@ -7,6 +7,7 @@
 #include "kbbq_aligned_kernels.h"
 #include "kbbq_k2_tile.h"
 #include "../../include/kbbq_hip.h"
+#include "host_threads.h"
 
 #include <algorithm>
 #include <climits>
@@ -14,7 +15,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 static thread_local std::string g_err;
@@ -53,6 +56,11 @@ struct kbbq_ctx {
     size_t ops4_bytes = 0;
     void* d_tally = nullptr;          // kbbq_tally_aligned_dev: [count | flags words of the reads | rows K4 still has to look at] (grown on demand)
     size_t tally_bytes = 0;
+    // kbbq_accumulate / kbbq_apply (host buffers): two page-locked staging slabs and their device twins, a copy stream and
+    // the events that order host copy -> upload -> kernel -> download slab by slab (grown on demand, kept for the next call)
+    void* stage_host[2] = {nullptr, nullptr}; void* stage_dev[2] = {nullptr, nullptr}; size_t stage_bytes = 0;
+    hipStream_t stage_stream = nullptr;
+    hipEvent_t stage_up[2] = {nullptr, nullptr}, stage_used[2] = {nullptr, nullptr}, stage_down[2] = {nullptr, nullptr};
     void* d_rowlut = nullptr;         // K2 on one-read-per-row planes: the LUT narrowed to the rows' pitch (grown on demand)
     size_t rowlut_bytes = 0;
     bool timing = false;
@@ -148,6 +156,14 @@ int kbbq_ctx_destroy(kbbq_ctx* c)
     if (c->d_ops4) (void)hipFree(c->d_ops4);
     if (c->d_rowlut) (void)hipFree(c->d_rowlut);
     if (c->d_tally) (void)hipFree(c->d_tally);
+    for (int b = 0; b < 2; ++b) {
+        if (c->stage_host[b]) (void)hipHostFree(c->stage_host[b]);
+        if (c->stage_dev[b]) (void)hipFree(c->stage_dev[b]);
+        if (c->stage_up[b]) (void)hipEventDestroy(c->stage_up[b]);
+        if (c->stage_used[b]) (void)hipEventDestroy(c->stage_used[b]);
+        if (c->stage_down[b]) (void)hipEventDestroy(c->stage_down[b]);
+    }
+    if (c->stage_stream) (void)hipStreamDestroy(c->stage_stream);
     if (c->d_wgplan) (void)hipFree(c->d_wgplan);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1811,28 +1827,135 @@ struct DevBuf {
     hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
 };
 
+// ---- host-buffer entry points: slabs of rows through page-locked staging -------------------------------------------------
+// A caller's NumPy arrays are pageable memory: hipMemcpy from them goes through the runtime's own small staging buffers, one
+// plane after the other, and the kernel starts when the last byte has arrived.  Here the rows travel in slabs: host threads
+// copy slab k + 1 into a page-locked buffer while the copy engine uploads slab k and the kernel runs on slab k - 1 (apply: the
+// new qualities of slab k - 2 come back meanwhile, PCIe being full duplex); device memory is two slabs, whatever the input's size.
+static size_t stage_slab_rows(int pitch, int planes, int64_t nreads)
+{
+    const char* e = getenv("KBBQ_STAGE_MB");                       // staging bytes per slab (all planes), default 96 MB
+    const size_t budget = (size_t)(e && atoi(e) > 0 ? atoi(e) : 96) << 20;
+    size_t rows = budget / ((size_t)pitch * planes + 4);
+    rows = std::max<size_t>(rows & ~(size_t)63, 64);
+    return (size_t)std::min<int64_t>((int64_t)rows, std::max<int64_t>(nreads, 1));
+}
+
+static int stage_prepare(kbbq_ctx* c, size_t bytes)
+{
+    if (!c->stage_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->stage_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            HIPCHK(hipEventCreateWithFlags(&c->stage_up[b], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->stage_used[b], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->stage_down[b], hipEventDisableTiming));
+        }
+    }
+    if (c->stage_bytes < bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(c->stage_stream));
+        for (int b = 0; b < 2; ++b) {
+            if (c->stage_host[b]) { (void)hipHostFree(c->stage_host[b]); c->stage_host[b] = nullptr; }
+            if (c->stage_dev[b]) { (void)hipFree(c->stage_dev[b]); c->stage_dev[b] = nullptr; }
+        }
+        c->stage_bytes = 0;
+        for (int b = 0; b < 2; ++b) {
+            HIPCHK(hipHostMalloc(&c->stage_host[b], bytes, hipHostMallocDefault));
+            HIPCHK(hipMalloc(&c->stage_dev[b], bytes));
+        }
+        c->stage_bytes = bytes;
+    }
+    return KBBQ_OK;
+}
+
+// copy `bytes` with all host threads (a slab is tens of MB: one thread moves ~10 GB/s, PCIe takes ~55)
+static void threaded_copy(void* dst, const void* src, size_t bytes)
+{
+    const unsigned nt = kbbq_threads_for(bytes / 4);
+    if (nt <= 1 || bytes < ((size_t)4 << 20)) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes + nt - 1) / nt + 4095) & ~(size_t)4095;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t lo = std::min(bytes, (size_t)t * per), hi = std::min(bytes, lo + per);
+        if (lo < hi) th.emplace_back([=]() { memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// The status words hold the SMALLEST flagged read index of every kind over all launches since they were last read; slabs number
+// their reads from 0, so after a pipelined run that flagged something the slabs are looked at again one by one (input errors
+// are the rare case): the first slab that reproduces a status decides, its read index made file-wide.
+static int first_offender(kbbq_ctx* c, int64_t nreads, size_t slab, const std::function<int(int64_t, int64_t)>& run_slab)
+{
+    for (int64_t lo = 0; lo < nreads; lo += (int64_t)slab) {
+        const int64_t m = std::min<int64_t>((int64_t)slab, nreads - lo);
+        int rc = run_slab(lo, m);
+        if (rc) return rc;
+        int64_t idx = -1;
+        rc = kbbq_ctx_status(c, &idx);
+        if (rc) {
+            if (idx >= 0) {
+                const std::string what = g_err;
+                const size_t colon = what.find(": ");
+                return fail(rc, "read %lld%s", (long long)(lo + idx), colon == std::string::npos ? "" : what.c_str() + colon);
+            }
+            return rc;
+        }
+    }
+    return KBBQ_OK;
+}
+
 int kbbq_accumulate(kbbq_ctx* c, const uint8_t* seq, const uint8_t* cseq, const uint8_t* qual,
                     const uint32_t* meta, int64_t nreads, int pitch, int R, int S2, int minscore,
                     int64_t* pos_errs, int64_t* pos_total, int64_t* dinuc_errs, int64_t* dinuc_total)
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
     if (nreads < 0 || pitch <= 0 || (pitch & 15)) return fail(KBBQ_E_ARG, "kbbq_accumulate: bad nreads/pitch");
+    if (nreads > 0 && (!seq || !cseq || !qual || !meta)) return fail(KBBQ_E_ARG, "kbbq_accumulate: NULL plane");
+    if (R <= 0 || S2 <= 0 || !pos_errs || !pos_total || !dinuc_errs || !dinuc_total) return fail(KBBQ_E_ARG, "kbbq_accumulate: bad tables");
     HIPCHK(hipSetDevice(c->device));
-    const size_t plane = (size_t)nreads * pitch;
     const size_t npos = (size_t)R * KQ * S2, ndn = (size_t)R * KQ * KND;
-    DevBuf ds, dc, dq, dm, dt;
-    HIPCHK(ds.alloc(plane)); HIPCHK(dc.alloc(plane)); HIPCHK(dq.alloc(plane));
-    HIPCHK(dm.alloc((size_t)nreads * 4)); HIPCHK(dt.alloc(kbbq_tables_count(R, S2) * 8));
-    HIPCHK(hipMemcpyAsync(ds.p, seq, plane, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dc.p, cseq, plane, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dq.p, qual, plane, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dm.p, meta, (size_t)nreads * 4, hipMemcpyHostToDevice, c->stream));
+    DevBuf dt;
+    HIPCHK(dt.alloc(kbbq_tables_count(R, S2) * 8));
     HIPCHK(hipMemsetAsync(dt.p, 0, kbbq_tables_count(R, S2) * 8, c->stream));
-    int rc = kbbq_accumulate_dev(c, (const uint8_t*)ds.p, (const uint8_t*)dc.p, (const uint8_t*)dq.p,
-                                 (const uint32_t*)dm.p, nreads, pitch, R, S2, minscore, (int64_t*)dt.p);
+    const size_t slab = stage_slab_rows(pitch, 3, nreads);
+    const size_t plane = slab * (size_t)pitch, set = 3 * plane + slab * 4;
+    int rc = stage_prepare(c, set);
     if (rc) return rc;
+    auto launch = [&](int b, int64_t m) {
+        const uint8_t* d = (const uint8_t*)c->stage_dev[b];
+        return kbbq_accumulate_dev(c, d, d + plane, d + 2 * plane, (const uint32_t*)(d + 3 * plane), m, pitch, R, S2, minscore, (int64_t*)dt.p);
+    };
+    auto stage_in = [&](int b, int64_t lo, int64_t m) {
+        uint8_t* h = (uint8_t*)c->stage_host[b];
+        const size_t off = (size_t)lo * pitch, nb = (size_t)m * pitch;
+        threaded_copy(h, seq + off, nb); threaded_copy(h + plane, cseq + off, nb); threaded_copy(h + 2 * plane, qual + off, nb);
+        memcpy(h + 3 * plane, meta + lo, (size_t)m * 4);
+    };
+    int64_t k = 0;
+    for (int64_t lo = 0; lo < nreads; lo += (int64_t)slab, ++k) {
+        const int b = (int)(k & 1);
+        const int64_t m = std::min<int64_t>((int64_t)slab, nreads - lo);
+        if (k >= 2) HIPCHK(hipEventSynchronize(c->stage_up[b]));              // the page-locked slab has been uploaded: free again
+        stage_in(b, lo, m);
+        if (k >= 2) HIPCHK(hipStreamWaitEvent(c->stage_stream, c->stage_used[b], 0));   // the device slab's kernel has run
+        HIPCHK(hipMemcpyAsync(c->stage_dev[b], c->stage_host[b], set, hipMemcpyHostToDevice, c->stage_stream));
+        HIPCHK(hipEventRecord(c->stage_up[b], c->stage_stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->stage_up[b], 0));
+        rc = launch(b, m);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->stage_used[b], c->stream));
+    }
     rc = kbbq_ctx_status(c, nullptr);
-    if (rc) return rc;
+    if (rc) {
+        // something was flagged: which read of the WHOLE input comes first?  (nothing reaches the caller's tables)
+        HIPCHK(hipStreamSynchronize(c->stage_stream));
+        rc = first_offender(c, nreads, slab, [&](int64_t lo, int64_t m) {
+            stage_in(0, lo, m);
+            HIPCHK(hipMemcpyAsync(c->stage_dev[0], c->stage_host[0], set, hipMemcpyHostToDevice, c->stream));
+            return launch(0, m);
+        });
+        return rc ? rc : fail(KBBQ_E_HIP, "kbbq_accumulate: a status reported by the pipelined run did not reproduce slab by slab");
+    }
     std::vector<int64_t> h(kbbq_tables_count(R, S2));
     HIPCHK(hipMemcpyAsync(h.data(), dt.p, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1848,26 +1971,75 @@ int kbbq_apply(kbbq_ctx* c, const uint8_t* seq, const uint8_t* qual, const uint3
 {
     if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
     if (nreads < 0 || pitch <= 0 || (pitch & 15)) return fail(KBBQ_E_ARG, "kbbq_apply: bad nreads/pitch");
+    if (nreads > 0 && (!seq || !qual || !meta || !qual_out)) return fail(KBBQ_E_ARG, "kbbq_apply: NULL plane");
     HIPCHK(hipSetDevice(c->device));
     std::vector<int64_t> lut((kbbq_lut_bytes(R, Qt, S2) + 7) / 8);      // 8-byte words: aligned storage
     int flags = 0;
     int rc = kbbq_build_lut(R, Qt, S2, D, minscore, meanq, rgdq, qdq, posdq, dinucdq, lut.data(), &flags);
     if (rc) return rc;
-    const size_t plane = (size_t)nreads * pitch;
-    DevBuf ds, dq, dm, dl, dout;
-    HIPCHK(ds.alloc(plane)); HIPCHK(dq.alloc(plane)); HIPCHK(dout.alloc(plane));
-    HIPCHK(dm.alloc((size_t)nreads * 4)); HIPCHK(dl.alloc(lut.size() * 8));
-    HIPCHK(hipMemcpyAsync(ds.p, seq, plane, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dq.p, qual, plane, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dm.p, meta, (size_t)nreads * 4, hipMemcpyHostToDevice, c->stream));
+    DevBuf dl;
+    HIPCHK(dl.alloc(lut.size() * 8));
     HIPCHK(hipMemcpyAsync(dl.p, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, c->stream));
-    rc = kbbq_apply_dev(c, (const uint8_t*)ds.p, (const uint8_t*)dq.p, (const uint32_t*)dm.p, nreads, pitch,
-                        R, Qt, S2, minscore, dl.p, flags ? KBBQ_APPLY_CHECKED : KBBQ_APPLY_FAST, (uint8_t*)dout.p);
+    // a slab: seq | qual | out | meta (the output plane travels back from the same device slab)
+    const size_t slab = stage_slab_rows(pitch, 3, nreads);
+    const size_t plane = slab * (size_t)pitch, set = 3 * plane + slab * 4;
+    rc = stage_prepare(c, set);
     if (rc) return rc;
+    const int mode = flags ? KBBQ_APPLY_CHECKED : KBBQ_APPLY_FAST;
+    auto launch = [&](int b, int64_t m) {
+        uint8_t* d = (uint8_t*)c->stage_dev[b];
+        return kbbq_apply_dev(c, d, d + plane, (const uint32_t*)(d + 3 * plane), m, pitch, R, Qt, S2, minscore, dl.p, mode, d + 2 * plane);
+    };
+    auto stage_in = [&](int b, int64_t lo, int64_t m) {
+        uint8_t* h = (uint8_t*)c->stage_host[b];
+        const size_t off = (size_t)lo * pitch, nb = (size_t)m * pitch;
+        threaded_copy(h, seq + off, nb); threaded_copy(h + plane, qual + off, nb);
+        memcpy(h + 3 * plane, meta + lo, (size_t)m * 4);
+    };
+    auto upload = [&](int b, int64_t m, hipStream_t st) -> int {        // seq + qual, then the sidecars (the output plane lies between)
+        HIPCHK(hipMemcpyAsync(c->stage_dev[b], c->stage_host[b], 2 * plane, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync((uint8_t*)c->stage_dev[b] + 3 * plane, (uint8_t*)c->stage_host[b] + 3 * plane, (size_t)m * 4, hipMemcpyHostToDevice, st));
+        return KBBQ_OK;
+    };
+    struct Out { int64_t lo, m; };
+    Out pending[2] = {{0, 0}, {0, 0}};                                   // downloads in flight, by buffer
+    auto stage_out = [&](int b) -> int {                                 // wait for buffer b's download and hand its rows to the caller
+        if (!pending[b].m) return KBBQ_OK;
+        HIPCHK(hipEventSynchronize(c->stage_down[b]));
+        threaded_copy(qual_out + (size_t)pending[b].lo * pitch, (uint8_t*)c->stage_host[b] + 2 * plane, (size_t)pending[b].m * pitch);
+        pending[b].m = 0;
+        return KBBQ_OK;
+    };
+    int64_t k = 0;
+    for (int64_t lo = 0; lo < nreads; lo += (int64_t)slab, ++k) {
+        const int b = (int)(k & 1);
+        const int64_t m = std::min<int64_t>((int64_t)slab, nreads - lo);
+        rc = stage_out(b);                                                // slab k - 2 (same buffers): downloaded -> the caller's rows
+        if (rc) return rc;
+        stage_in(b, lo, m);
+        rc = upload(b, m, c->stage_stream);                               // the copy stream is in order: behind slab k - 2's download
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->stage_up[b], c->stage_stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->stage_up[b], 0));
+        rc = launch(b, m);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(c->stage_used[b], c->stream));
+        HIPCHK(hipStreamWaitEvent(c->stage_stream, c->stage_used[b], 0));
+        HIPCHK(hipMemcpyAsync((uint8_t*)c->stage_host[b] + 2 * plane, (uint8_t*)c->stage_dev[b] + 2 * plane, (size_t)m * pitch, hipMemcpyDeviceToHost, c->stage_stream));
+        HIPCHK(hipEventRecord(c->stage_down[b], c->stage_stream));
+        pending[b] = {lo, m};
+    }
     rc = kbbq_ctx_status(c, nullptr);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(qual_out, dout.p, plane, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (rc) {
+        HIPCHK(hipStreamSynchronize(c->stage_stream));
+        rc = first_offender(c, nreads, slab, [&](int64_t lo, int64_t m) {
+            stage_in(0, lo, m);
+            int r2 = upload(0, m, c->stream);
+            return r2 ? r2 : launch(0, m);
+        });
+        return rc ? rc : fail(KBBQ_E_HIP, "kbbq_apply: a status reported by the pipelined run did not reproduce slab by slab");
+    }
+    for (int b = 0; b < 2; ++b) { rc = stage_out((int)((k + b) & 1)); if (rc) return rc; }     // the older of the two first
     return KBBQ_OK;
 }
 

@@ -201,6 +201,49 @@ def test_host_buffer_entry_points(dev, oracle):
     assert np.array_equal(out[inside].astype(np.int32) - 33, ref[inside])
 
 
+def test_host_buffer_entry_points_run_slab_by_slab(dev, oracle, monkeypatch):
+    """kbbq_accumulate / kbbq_apply move a caller's rows through page-locked slabs (upload, kernel and download of successive
+    slabs overlapping): with slabs of a few thousand rows -- KBBQ_STAGE_MB -- the tables and qualities are those of the
+    oracle, a second call re-uses the staging, and a read the kernels flag is reported with its index in the WHOLE input
+    (every slab numbers its rows from 0) without anything reaching the caller's tables."""
+    import re
+    from kbbq import _native as N
+    monkeypatch.setenv('KBBQ_STAGE_MB', '1')                       # 1 MB of staging per slab: ~2 100 rows of 160 bytes x 3 planes
+    n, R, S2 = 30_001, 2, 300
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 77, nrg=R)
+    ctx, lib = dev.context(), N.load()
+    tabs = [np.zeros((R, 43, S2), np.int64), np.zeros((R, 43, S2), np.int64), np.zeros((R, 43, 16), np.int64), np.zeros((R, 43, 16), np.int64)]
+    for _ in range(2):
+        N.check(lib.kbbq_accumulate(ctx.handle, N.ptr(seq), N.ptr(cseq), N.ptr(qual), N.ptr(meta), n, seq.shape[1], R, S2, 6, *[N.ptr(t) for t in tabs]))
+    want = oracle.accumulate(seq, cseq, qual, meta, R, 150)
+    for g, w in zip(tabs, want[5:]):
+        assert np.array_equal(g, 2 * w)
+    dqs = oracle.get_delta_qs(*want)
+    a = [np.ascontiguousarray(x, dtype=np.int64) for x in (want[0],) + dqs]
+    out = np.full_like(qual, 0xEE)
+    N.check(lib.kbbq_apply(ctx.handle, N.ptr(seq), N.ptr(qual), N.ptr(meta), n, seq.shape[1], R, 43, S2, 17, 6, *[N.ptr(x) for x in a], N.ptr(out)))
+    ref = oracle.apply(seq, qual, meta, want[0], *dqs)
+    inside = np.arange(seq.shape[1])[None, :] < (meta & 0xFFFF)[:, None]
+    assert np.array_equal(out[inside].astype(np.int32) - 33, ref[inside]) and not (out == 0xEE).all(1).any()
+    # the device-plane entry point on the same rows writes the same bytes
+    d_out = dev.apply(dev.ReadBatch.from_host(seq, qual, meta), *dev.solve_lut(dev.Tables.from_host(*want[5:9])))
+    assert np.array_equal(d_out.cpu().numpy()[inside], out[inside])
+    # a quality above 42 (IndexError of the reference) in a late slab, an earlier slab clean; then a second one before it
+    bad = qual.copy()
+    bad[25_000, 3] = 33 + 43
+    before = [t.copy() for t in tabs]
+    for first in (25_000, 7_777):
+        bad[first, 3] = 33 + 43
+        with pytest.raises(IndexError) as e:
+            N.check(lib.kbbq_accumulate(ctx.handle, N.ptr(seq), N.ptr(cseq), N.ptr(bad), N.ptr(meta), n, seq.shape[1], R, S2, 6, *[N.ptr(t) for t in tabs]))
+        assert int(re.search(r'read (\d+)', str(e.value)).group(1)) == first
+        assert all(np.array_equal(t, b) for t, b in zip(tabs, before))
+        with pytest.raises(IndexError) as e:
+            N.check(lib.kbbq_apply(ctx.handle, N.ptr(seq), N.ptr(bad), N.ptr(meta), n, seq.shape[1], R, 43, S2, 17, 6, *[N.ptr(x) for x in a], N.ptr(out)))
+        assert int(re.search(r'read (\d+)', str(e.value)).group(1)) == first
+    ctx.status()                                                    # nothing left behind
+
+
 # ------------------------------------------------------------------ K3: model solve
 def test_k3_delta_q_matches_reference_grid_and_oracle(dev, oracle):
     from kbbq import compare_reads
