@@ -120,8 +120,11 @@ int kbbq_ctx_create(int device, kbbq_ctx** out)
     (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<true, K1V3_DNREP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<true, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<false, K1V3_DNREP, true, 19>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<true, K1V3_DNREP, true, 19>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+#define KBBQ_KM_ATTR(KJ_) \
+    (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<false, K1V3_DNREP, true, KJ_>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes); \
+    (void)hipFuncSetAttribute((const void*)(k1v3_accumulate<true, K1V3_DNREP, true, KJ_>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    KBBQ_KM_ATTR(13) KBBQ_KM_ATTR(19)
+#undef KBBQ_KM_ATTR
     (void)hipFuncSetAttribute((const void*)(k2v3_apply<false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k2v3_apply<true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2t_apply, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
@@ -911,15 +914,27 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     // instead of 16 free the rest: reads of up to ~300 bases still run this kernel.
     const int trim = (!pairs && S_min > 0) ? std::min(S_min, S) : 0;
     int dn = 0; size_t lds3 = 0;
-    // mate-pair rows of 19 chunks (2 x 150 bp) on 4-bit planes: the chunk-position-major cycle table (kernel comment)
+    // mate-pair rows of 19 or 13 chunks (2 x 150, 2 x 100 bp) on 4-bit planes: the chunk-position-major cycle table (kernel comment), the
+    // 13-chunk form with several trash rows (K1v3Params::ntrash; 19 chunks were measured with 4 and 8 of them: nothing; KBBQ_K1_KM_NTRASH
+    // overrides).  Measured for the other lengths instruments emit (scripts/time_km_widths.py): 2 x 100 bp 1.37 -> 1.31 ms per 3 Gbases; 2 x 50 bp
+    // (7 chunks) is FASTER position-major with its copies of the cycle table (1.52 against 1.64 ms); 2 x 75 / 2 x 125 / 2 x 250 bp never
+    // take mate-pair rows (2 S + 1 rounds up to twice the single read's pitch: no bytes saved).  KBBQ_K1_KM=0: none, =19: only 19 chunks.
     const char* km_off = getenv("KBBQ_K1_KM");
-    const bool km = pairs && nib && q.cpr == 19 && !(km_off && !strcmp(km_off, "0"));
+    const bool km_width = q.cpr == 19 || (q.cpr == 13 && !(km_off && !strcmp(km_off, "19")));
+    const bool km = pairs && nib && km_width && !(km_off && !strcmp(km_off, "0"));
+    bool km_ok = false; int km_ntrash = 1;                 // the form applies AND its tables fit
     if (km) {
-        q.row_bytes = (u32)(((16 * 19 + 31) & ~31) * 4);
+        q.row_bytes = (u32)(((16 * q.cpr + 31) & ~31) * 4);
         q.minlen = 0; q.slack_bytes = 0; q.ntrash = 1; q.pos_copies = 1;
         q.dn_flush_iters = std::max(1, 65535 / ((K1V3_THREADS / K1V3_DNREP) * 16 * q.cpr));
-        lds3 = (size_t)q.nrows * 128 * K1V3_DNREP + (size_t)q.nrows * q.row_bytes;
-        if (lds3 <= (size_t)c->lds_bytes) dn = K1V3_DNREP;
+        const char* kt = getenv("KBBQ_K1_KM_NTRASH");
+        int want_t = kt ? atoi(kt) : (q.cpr == 19 ? 1 : 8);
+        for (int nt = 8; nt >= 1; nt >>= 1) {
+            if (nt > want_t) continue;
+            const size_t rows = (size_t)q.nrows - 1 + nt;
+            lds3 = rows * 128 * K1V3_DNREP + rows * q.row_bytes;
+            if (lds3 <= (size_t)c->lds_bytes) { dn = K1V3_DNREP; km_ok = true; km_ntrash = nt; break; }
+        }
     }
     // An experiment kept behind KBBQ_K1_TWO=1 (round 3; measured, not adopted): narrow rows (the short bands of a mixed-length
     // input) run K1 at half the rate of wide ones -- a 64-row block is a few steps of work behind two dependent loads -- and
@@ -958,7 +973,8 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     // ... and several trash rows (K1v3Params::ntrash) first: the padding behind every read's last base is the hotter spot
     q.pos_copies = 1; q.ntrash = 1;
     q.pos_copy_bytes = (u32)q.nrows * q.row_bytes + q.slack_bytes;
-    if (!km && per_cu == 1) {
+    if (km_ok) { q.ntrash = km_ntrash; q.pos_copy_bytes = (u32)((size_t)(q.nrows - 1 + q.ntrash) * q.row_bytes); }
+    if (!km_ok && per_cu == 1) {
         const char* nt_env = getenv("KBBQ_K1_NTRASH");
         const int most_t = nt_env ? atoi(nt_env) : 8;
         auto bytes_for = [&](int nt, int pc) {
@@ -979,7 +995,7 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     const int64_t nblocks = (nrows + 63) / 64;
     const int64_t iters = (nblocks + (threads / 64) - 1) / (threads / 64);
     if (setup_only) {
-        setup_only->q = q; setup_only->dn = dn; setup_only->km = km && dn == K1V3_DNREP; setup_only->split = split;
+        setup_only->q = q; setup_only->dn = dn; setup_only->km = km_ok; setup_only->split = split;
         setup_only->lds = lds3; setup_only->iters = iters; setup_only->threads = threads;
         return KBBQ_OK;
     }
@@ -987,9 +1003,13 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     dim3 grid((unsigned)gx, (unsigned)R, 1), block((unsigned)threads, 1, 1);
     {
         Timed t(c, 0);
-        if (km && dn == K1V3_DNREP) {
-            if (split) hipLaunchKernelGGL((k1v3_accumulate<true, K1V3_DNREP, true, 19>), grid, block, lds3, c->stream, q);
-            else hipLaunchKernelGGL((k1v3_accumulate<false, K1V3_DNREP, true, 19>), grid, block, lds3, c->stream, q);
+        if (km_ok) {
+#define KBBQ_KM_LAUNCH(KJ_) case KJ_: \
+                if (split) hipLaunchKernelGGL((k1v3_accumulate<true, K1V3_DNREP, true, KJ_>), grid, block, lds3, c->stream, q); \
+                else hipLaunchKernelGGL((k1v3_accumulate<false, K1V3_DNREP, true, KJ_>), grid, block, lds3, c->stream, q); \
+                break;
+            switch (q.cpr) { KBBQ_KM_LAUNCH(13) KBBQ_KM_LAUNCH(19) }
+#undef KBBQ_KM_LAUNCH
         } else if (nib) {
             if (dn == K1V3_DNREP) {
                 if (split) hipLaunchKernelGGL((k1v3_accumulate<true, K1V3_DNREP, true>), grid, block, lds3, c->stream, q);

@@ -187,10 +187,10 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
 {
     static_assert(!ALN || (!NIB && KJ == 0), "the aligned-read form reads character planes");
     static_assert(!REF || ALN, "the reference comparison belongs to the aligned-read form");
-    const int ntrash = KJ > 0 ? 1 : p.ntrash;
+    const int ntrash = p.ntrash;                       // (the host gives the 19-chunk form one trash row: several were measured, nothing)
     const int dn_words = (p.nrows - 1 + ntrash) * 32 * DN;
     const int ncopies = KJ > 0 ? 1 : p.pos_copies;
-    const int pos_words = KJ > 0 ? p.nrows * (int)(p.row_bytes >> 2) + (int)(p.slack_bytes >> 2) : ncopies * (int)(p.pos_copy_bytes >> 2);
+    const int pos_words = KJ > 0 ? (p.nrows - 1 + ntrash) * (int)(p.row_bytes >> 2) + (int)(p.slack_bytes >> 2) : ncopies * (int)(p.pos_copy_bytes >> 2);
     u32* dnt = lds;
     u32* pos = lds + dn_words;
     for (int i = threadIdx.x; i < dn_words + pos_words; i += blockDim.x) lds[i] = 0u;
@@ -489,7 +489,7 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                         // A: pos address less the row term; both mates ascend with the base index
                         const u32 half = second ? (u32)(S + 2 * (S - len)) : 0u;     // column 2*len-1-pos
                         const u32 copy_off = KJ > 0 ? 0u : (u32)(ch.k & (ncopies - 1)) * p.pos_copy_bytes;     // this chunk's copy of the cycle table
-                        const u32 tcl = KJ > 0 ? tclamp : tclamp + (u32)(ch.k & (ntrash - 1));                 // ... and its trash row
+                        const u32 tcl = tclamp + (u32)(ch.k & (ntrash - 1));                                   // ... and its trash row
                         const u32 A = KJ > 0 ? pos_base + 4u * (u32)j : pos_base + copy_off + (half + (u32)pos0) * 4u;
                         // ALN: bases before the aligned part have NEGATIVE canonical positions.  They are uncounted, i.e. they land on
                         // the trash row (the last one) -- up to 15 words before its start when the chunk holds the first aligned

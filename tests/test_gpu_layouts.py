@@ -166,10 +166,11 @@ def test_corrupt_nibble_planes_are_reported(dev):
         dev.accumulate(laid, dev.Tables(1, 2 * S))
 
 
+@pytest.mark.parametrize('S', [150, 100])                  # 19 and 13 chunks per mate-pair row: both chunk-position-major forms of K1
 @pytest.mark.parametrize('minscore', [2, 6, 20])
-def test_minscore_on_packed_rows(dev, oracle, minscore):
-    n, S, R = 4000, 150, 2
-    b = dev.ReadBatch.synthetic(0, n, n, seed=31, nrg=R, qlo=2)
+def test_minscore_on_packed_rows(dev, oracle, minscore, S):
+    n, R = 4000, 2
+    b = dev.ReadBatch.synthetic(0, n, n, seed=31, nrg=R, qlo=2, len_lo=S, len_hi=S)
     seq, cseq, qual, meta = _host(b, n)
     want, ref = _oracle_run(oracle, seq, cseq, qual, meta, R, S, minscore=minscore)
     laid = dev.lay_out(b, R, S, packed=True)
