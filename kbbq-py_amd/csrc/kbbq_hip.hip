@@ -1149,6 +1149,7 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
             t.wg_start = c->d_wgplan;
             if (interleave) {
                 K2tOrderParams op; op.wg_start = c->d_wgplan; op.R = R;
+                { const char* x = getenv("KBBQ_K2_XCD"); op.xcd = x ? atoi(x) : 8; }      // "0": ranks as they are (A/B timing)
                 op.order = reinterpret_cast<int2*>(c->d_wgplan + ((R + 2) & ~1));           // 8-byte aligned behind the starts
                 hipLaunchKernelGGL(k2t_order, dim3((unsigned)((gt + 255) / 256)), dim3(256), 0, c->stream, op);
                 t.order = op.order;

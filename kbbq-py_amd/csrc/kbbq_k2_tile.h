@@ -56,7 +56,11 @@ __global__ void k2t_plan(K2tPlanParams p)
 // TOGETHER: workgroup (g, i) gets the rank of its relative position (2 i + 1) / (2 n_g) among all workgroups (ties by
 // group), so that at any moment the running workgroups of all groups store into the same stretch of the output and
 // their partial lines meet in the cache.  One thread per workgroup, R comparisons each.
-struct K2tOrderParams { const int* wg_start; int R; int2* order; };
+// ... and on the same XCD: workgroups are handed to the 8 XCDs round-robin by their number (number mod 8), each XCD has an L2 of its
+// own, and partial lines of two XCDs cannot meet before the memory side.  Adjacent rows of the output belong to DIFFERENT groups at
+// the SAME relative position, i.e. to R consecutive ranks: inside every window of 8 R ranks, rank R q + g (q = 0..7) becomes
+// workgroup number q + 8 g of the window, so the R groups' workgroups of one position share XCD q (`xcd` = 8; 0: ranks as they are).
+struct K2tOrderParams { const int* wg_start; int R; int2* order; int xcd; };
 __global__ __launch_bounds__(256) void k2t_order(K2tOrderParams p)
 {
     const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -73,6 +77,11 @@ __global__ __launch_bounds__(256) void k2t_order(K2tOrderParams p)
         const long long M = h < g ? A / ng : (A + ng - 1) / ng - 1;   // largest admissible k
         long long cnt = (M + 1) / 2;
         rank += cnt < nh ? cnt : nh;
+    }
+    if (p.xcd > 0) {
+        const long long total = p.wg_start[p.R], win = (long long)p.xcd * p.R;
+        const long long base = rank - rank % win;
+        if (base + win <= total) { const long long r = rank - base; rank = base + r / p.R + (long long)p.xcd * (r % p.R); }
     }
     p.order[rank] = make_int2(g, i);
 }
