@@ -908,6 +908,7 @@ static int accumulate_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, c
     q.maxlen = pairs ? S2 + 1 : S; q.gap = pairs ? 1 : 0; q.twins = (pairs && twins) ? 1 : 0;
     q.seg = reinterpret_cast<const long long*>(d_seg);
     q.tables = reinterpret_cast<u64*>(d_tables); q.status = c->d_status;
+    q.genome = nullptr; q.ag0 = nullptr;
     // LDS geometry.  A cycle row has one word per first-in-pair position [0, S) and per second-in-pair index
     // S + 2(S - len) + pos <= 3S - len - 1: 3S words serve any length.  When that does not fit (reads of ~200 bases
     // and more), a band whose shortest read is S_min needs only 3S - S_min words, and 8 copies of the context table
@@ -1131,6 +1132,7 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
         t.Qt = KQ; t.S2 = S2; t.maxlen = q.maxlen; t.lut = q.full; t.lut_bytes = (int)((rg_bytes + 15) & ~(size_t)15);
         t.rb = q.rb; t.ctx_off = q.ctx_off; t.W = q.W; t.seg = reinterpret_cast<const long long*>(d_seg); t.R = R; t.wg_start = nullptr; t.order = nullptr;
         t.perm = reinterpret_cast<const long long*>(d_perm); t.pitch = pitch; t.out = d_out; t.status = c->d_status;
+        { const char* x = getenv("KBBQ_K2_XCD_TILES"); t.xcd_tiles = x ? atoi(x) : 1; }
         const int64_t per_wg = (int64_t)(K2T_THREADS / 64) * 64 * K2T_STEPS;
         int64_t gt = (t.nchunks + per_wg - 1) / per_wg;
         if (d_seg) {
@@ -1441,6 +1443,7 @@ int kbbq_apply_bands_dev(kbbq_ctx* c, const kbbq_band* bands, int nbands, int R,
         q.rb = (u32)full_lut_row_bytes(Sb); q.W = (u32)full_lut_width(Sb); q.ctx_off = 2u * q.W;
         q.lut = f.out; q.lut_bytes = (int)((((size_t)(33 + KQ) * q.rb) + 15) & ~(size_t)15);
         q.seg = nullptr; q.wg_start = nullptr; q.order = nullptr; q.R = R; q.perm = nullptr; q.pitch = b.pitch; q.out = b.d_out; q.status = c->d_status;
+        { const char* x = getenv("KBBQ_K2_XCD_TILES"); q.xcd_tiles = x ? atoi(x) : 1; }
         lds = std::max(lds, (size_t)q.lut_bytes);
         t.wg_start[k] = (int)run;
         run += (q.nchunks + per_wg - 1) / per_wg;

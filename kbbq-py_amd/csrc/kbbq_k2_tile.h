@@ -22,6 +22,8 @@
 
 struct K2tParams {
     const uint8_t* seq; const uint8_t* qual; const u32* meta;
+    int xcd_tiles;                 // workgroup b of a batch's T workgroups takes tile (b % 8) * (T / 8) + b / 8: every XCD (workgroup number mod 8) walks a
+                                   // contiguous eighth of the planes instead of every eighth tile -- 2.5-3 % on the headline's K2 (KBBQ_K2_XCD_TILES=0: tile b)
     long long nchunks;             // rows * cpr
     int cpr; u32 cpr_magic;        // ceil(2^32 / cpr): exact quotients for the small numerators used below
     int Qt; int S2; int maxlen;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void k2t_order(K2tOrderParams p)
 
 // the kernel's body for workgroup `bx` of the batch `p` describes (k2t_apply: blockIdx.x; k2t_bands: the workgroup's
 // number within its length band)
-__device__ __forceinline__ void k2t_body(const K2tParams& p, u32* lds, const int bx)
+__device__ __forceinline__ void k2t_body(const K2tParams& p, u32* lds, const int bx, const int ntiles)
 {
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -96,18 +98,24 @@ __device__ __forceinline__ void k2t_body(const K2tParams& p, u32* lds, const int
     // this workgroup's read group and chunk range (grouped rows), or everything
     int g = 0;
     long long chunk_lo = 0, chunk_hi = p.nchunks, wg = bx;
+    long long tiles = ntiles;                                       // workgroups that share this batch (group): the XCDs' eighths are cut from them
     if (p.seg) {
         if (bx >= p.wg_start[p.R]) return;
         if (p.order) {
             const int2 o = p.order[bx];
-            g = o.x; wg = o.y;
+            g = o.x; wg = o.y; tiles = 0;                           // (stores through the permutation: k2t_order places the workgroups)
         } else {
             int lo = 0, hi = p.R;                                   // largest g with wg_start[g] <= bx
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.wg_start[mid] <= bx) lo = mid; else hi = mid; }
             g = lo;
             wg = (long long)bx - p.wg_start[g];
+            tiles = p.wg_start[g + 1] - p.wg_start[g];
         }
         chunk_lo = p.seg[g] * p.cpr; chunk_hi = p.seg[g + 1] * p.cpr;
+    }
+    if (p.xcd_tiles) {
+        tiles &= ~7ll;                                              // whole eighths only; the last few workgroups keep their tiles
+        if (wg < tiles) wg = (wg & 7) * (tiles >> 3) + (wg >> 3);
     }
     const long long base = chunk_lo + (wg * nwaves + wave) * (64 * K2T_STEPS);
     // chunk -> (row, chunk in row): ONE wave-uniform division for the wave's first chunk, small numerators per lane
@@ -205,7 +213,7 @@ __device__ __forceinline__ void k2t_body(const K2tParams& p, u32* lds, const int
 __global__ __launch_bounds__(K2T_THREADS) void k2t_apply(K2tParams p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
-    k2t_body(p, lds, (int)blockIdx.x);
+    k2t_body(p, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ONE launch over all length bands of a mixed-length input (k1v3_bands' counterpart): workgroup blockIdx.x belongs to the
@@ -223,5 +231,5 @@ __global__ __launch_bounds__(K2T_THREADS) void k2t_bands(K2tBandsParams t)
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     int lo = 0, hi = t.nbands;                                      // largest b with wg_start[b] <= blockIdx.x
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (t.wg_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
-    k2t_body(t.band[lo], lds, (int)blockIdx.x - t.wg_start[lo]);
+    k2t_body(t.band[lo], lds, (int)blockIdx.x - t.wg_start[lo], t.wg_start[lo + 1] - t.wg_start[lo]);
 }

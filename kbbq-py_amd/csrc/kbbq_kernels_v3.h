@@ -291,6 +291,8 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
         }
     };
 
+    // (every XCD's workgroups walking a contiguous eighth of the rows instead of every eighth iteration: measured, four alternating
+    //  rounds on the headline layout, 3.40-3.44 against 3.36-3.43 ms -- nothing; K2's short-lived tiles do gain from it, kbbq_k2_tile.h)
     for (long long it = bx; it < iters; it += gx) {
         const long long blk = it * nwaves + wave;
         if (blk < nblocks) {
