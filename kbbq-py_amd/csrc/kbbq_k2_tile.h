@@ -114,8 +114,9 @@ __device__ __forceinline__ void k2t_body(const K2tParams& p, u32* lds, const int
         chunk_lo = p.seg[g] * p.cpr; chunk_hi = p.seg[g + 1] * p.cpr;
     }
     if (p.xcd_tiles) {
-        tiles &= ~7ll;                                              // whole eighths only; the last few workgroups keep their tiles
-        if (wg < tiles) wg = (wg & 7) * (tiles >> 3) + (wg >> 3);
+        const long long P = p.xcd_tiles == 1 ? 8 : p.xcd_tiles;     // parts (1: one per XCD; other counts for the experiment: multiples of 8 give an XCD several)
+        tiles -= tiles % P;                                         // whole parts only; the last few workgroups keep their tiles
+        if (wg < tiles) wg = (wg % P) * (tiles / P) + wg / P;
     }
     const long long base = chunk_lo + (wg * nwaves + wave) * (64 * K2T_STEPS);
     // chunk -> (row, chunk in row): ONE wave-uniform division for the wave's first chunk, small numerators per lane
