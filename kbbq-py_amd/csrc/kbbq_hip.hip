@@ -615,6 +615,7 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
         q.full_bytes = (int)full_bytes;
         q.rb = (u32)full_lut_row_bytes(Sb); q.W = (u32)full_lut_width(Sb); q.ctx_off = 2u * q.W;
         q.maxlen = Sb; q.pairs = 0; q.seg = nullptr; q.rpb = 64; q.perm = nullptr;
+        { const char* x = getenv("KBBQ_K2_PARTS"); q.parts = x ? atoi(x) : 8; }      // fronts of the persistent traversal (0 / 1: one)
         q.out = d_out; q.status = c->d_status;
 #ifdef K2V3_PER_CU
         int per_cu = K2V3_PER_CU;
@@ -1114,6 +1115,7 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
     q.perm = reinterpret_cast<const long long*>(d_perm);
     q.out = d_out; q.status = c->d_status;
     int per_cu = std::max(1, std::min<int>((int)(c->lds_bytes / lds), (K2V3_WAVES * 4 * 64) / K2V3_THREADS));
+    { const char* x = getenv("KBBQ_K2_PARTS"); q.parts = x ? atoi(x) : 8; }      // fronts of the persistent traversal (0 / 1: one)
     q.rpb = 64;      // the persistent kernel's wave block; smaller blocks were measured slower (profiles/r01_traversal_microbench.md)
     const int64_t nblocks = (nrows + q.rpb - 1) / q.rpb;
     const int64_t want = (nblocks + (K2V3_THREADS / 64) - 1) / (K2V3_THREADS / 64);
@@ -1533,6 +1535,7 @@ int kbbq_lay_out_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_cseq, c
     p.pairs = pairs; p.nib = nib; p.status = c->d_status;
     const int rpb7 = (p.dpitch / 16) <= 256 ? 256 / (p.dpitch / 16) : 1;      // destination rows per workgroup iteration
     const int gx = bounded_grid((p.nrows + rpb7 - 1) / rpb7, c, 256, "KBBQ_K7_GRID");
+    { const char* x = getenv("KBBQ_K7_PARTS"); p.parts = x ? atoi(x) : 8; }
     hipLaunchKernelGGL(k7_lay_out, dim3((unsigned)std::max(gx, 1)), dim3(256), 0, c->stream, p);
     HIPCHK(hipGetLastError());
     return KBBQ_OK;

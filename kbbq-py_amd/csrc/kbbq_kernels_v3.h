@@ -664,6 +664,9 @@ struct K2v3Params {
     int pairs;                 // mate-pair rows: rows the fast path cannot serve are reported (KBBQ_E_LUT), not emulated
     const long long* seg;      // rows grouped by read group: slice blockIdx.y stages only its group's LUT rows; NULL: all groups
     int rpb;                   // rows per wave block (<= 64): a wave's contiguous footprint is rpb * pitch bytes per plane
+    int parts;                 // > 1: the workgroups walk the rows as `parts` sequential fronts (workgroup b: part b % parts) instead of one: the 2 read +
+                               // 1 written traversal of 50 M character rows 4.68-4.78 -> 4.44-4.48 ms with 4 ... 32 fronts (KBBQ_K2_PARTS, default 8; kbbq_k2_tile.h
+                               // has the same for the short-lived kernel; K1's read-only traversal does not care)
     const long long* perm;     // rows grouped by read group: row i is stored as row perm[i] of `out` (straight back into input order); NULL: row i
     uint8_t* out; u64* status;
 };
@@ -693,8 +696,15 @@ __global__ __launch_bounds__(K2V3_THREADS) __attribute__((amdgpu_waves_per_eu(K2
     const int dk1 = 64 / p.cpr, dj1 = 64 - dk1 * p.cpr;
     const int dkn = (64 * K2V3_NBUF) / p.cpr, djn = 64 * K2V3_NBUF - dkn * p.cpr;
 
-    for (long long blk = (long long)blockIdx.x * nwaves + wave; blk < nblocks;
-         blk += (long long)gridDim.x * nwaves) {
+    long long blk0 = (long long)blockIdx.x * nwaves + wave, blk_step = (long long)gridDim.x * nwaves, blk_end = nblocks;
+    if (p.parts > 1 && (int)gridDim.x % p.parts == 0) {
+        const long long per = (nblocks + p.parts - 1) / p.parts;
+        const int part = (int)blockIdx.x % p.parts;
+        blk0 = part * per + (long long)((int)blockIdx.x / p.parts) * nwaves + wave;
+        blk_step = (long long)((int)gridDim.x / p.parts) * nwaves;
+        blk_end = (part + 1) * per < nblocks ? (part + 1) * per : nblocks;
+    }
+    for (long long blk = blk0; blk < blk_end; blk += blk_step) {
         const long long read0 = seg_lo + blk * p.rpb;
         const long long myread = read0 + lane;
         const int n = (int)((seg_hi - read0) < p.rpb ? (seg_hi - read0) : p.rpb);

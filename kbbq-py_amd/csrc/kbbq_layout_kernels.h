@@ -190,6 +190,7 @@ struct LayOutParams {
     long long nrows;                                  // destination rows
     long long nsrc;                                   // source reads (pairs: 2 * nrows, or one less -- the last row's second half stays empty)
     int pitch, dpitch, S, pairs, nib;
+    int parts;                                        // sequential fronts of the traversal (k7_lay_out; KBBQ_K7_PARTS, default 8)
     u64* status;
 };
 
@@ -231,9 +232,20 @@ __global__ __launch_bounds__(256) void k7_lay_out(LayOutParams p)
     const int j0 = (int)threadIdx.x - slot * cpr;
     const bool idle = cpr <= 256 && slot >= rpb;
     const long long limit = p.nsrc * (long long)p.pitch;                // bytes in a source plane (perm is a permutation)
-    for (long long rb = (long long)blockIdx.x * rpb; rb < p.nrows; rb += (long long)gridDim.x * rpb) {
+    // The workgroups walk the destination rows as `parts` sequential fronts, workgroup b in part b % parts (round 3): neighbouring blocks of
+    // rows -- 13 rows of 304 bytes do not end on a cache line -- are then written by workgroups of the SAME XCD (numbers 8 apart), whose partial
+    // lines meet in one L2, and a read + write traversal likes several fronts better than one (kbbq_k2_tile.h).  parts <= 1: one front.
+    long long rb0 = (long long)blockIdx.x * rpb, rb_step = (long long)gridDim.x * rpb, rb_end = p.nrows;
+    if (p.parts > 1 && (int)gridDim.x % p.parts == 0) {
+        const long long per = ((p.nrows + p.parts - 1) / p.parts + rpb - 1) / rpb * rpb;      // rows of a part: whole blocks
+        const int part = (int)blockIdx.x % p.parts;
+        rb0 = part * per + (long long)((int)blockIdx.x / p.parts) * rpb;
+        rb_step = (long long)((int)gridDim.x / p.parts) * rpb;
+        rb_end = (part + 1) * per < p.nrows ? (part + 1) * per : p.nrows;
+    }
+    for (long long rb = rb0; rb < rb_end; rb += rb_step) {
         const long long d = rb + slot;
-        if (idle || d >= p.nrows) continue;
+        if (idle || d >= rb_end) continue;
         const long long r = p.perm ? p.perm[d] : d;
         for (int j = j0; j < cpr; j += 256) {
             u32 o[3][4];
