@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""The short-lived K2 with its tiles cut into P parts (KBBQ_K2_XCD_TILES = P: workgroup b walks part b % P; 1 = 8, 0 = tile b for workgroup b), headline
+layout, three alternating rounds.  usage (GPU box): python scripts/time_k2_parts.py"""
 import os, sys
 sys.path.insert(0, 'kbbq-py_amd'); sys.path.insert(0, '.')
 import torch, bench
