@@ -721,6 +721,7 @@ def run_rank(args):
 
     from kbbq import _device as dev
     from kbbq import parallel
+    host_binding = parallel.bind_host_threads(local) if use_dist else None     # threads = CPUs / LOCAL_WORLD_SIZE, on the GPU's NUMA node
 
     n, R, S = args.reads, args.rgs, READ_LEN
     res = Resident(dev, torch, rank, n, world, R, args.layout)
@@ -738,6 +739,13 @@ def run_rank(args):
     ranks_seen = dist.get_world_size() if use_dist else 1
     backend = dist.get_backend() if use_dist else None
     verified = res.verify()
+    verified_ranks = [verified]
+    if use_dist:
+        # EVERY rank checks the output of its own batch; the line carries the AND over the ranks (None: nothing was kept to check)
+        every = [None] * world
+        dist.all_gather_object(every, verified)
+        verified_ranks = every
+        verified = None if any(v is None for v in every) else all(every)
     layout_name = res.name
     layout_pass_ms = res.layout_ms.get('lay_out')
     layout_key = res.batch.layout_key() if hasattr(res.batch, 'layout_key') else ('reads' if args.layout == 'reads' else 'pairs')
@@ -778,10 +786,11 @@ def run_rank(args):
                        'layout_inclusive_bases_per_s': (None if layout_pass_ms is None else
                                                         bases_per_rank * world / ((step_ms + layout_pass_ms) * 1e-3)),
                        'parallelism': 'reads sharded x%d, 1 allreduce of count tables' % world},
-            'verified': verified,
-            'verified_how': 'after the timed region: the new qualities of the first 1 M reads of the resident batch (in the '
-                            "headline's layout, as the last step left them) == the persistent apply kernel on the same reads as "
-                            'character rows, one read per row',
+            'verified': verified, 'verified_per_rank': verified_ranks,
+            'verified_how': 'after the timed region, on EVERY rank (the line carries the AND): the new qualities of the first 1 M reads of '
+                            "the rank's resident batch (in the headline's layout, as the last step left them) == the persistent apply "
+                            'kernel on the same reads as character rows, one read per row',
+            'host_binding': host_binding,
             'ranks_seen': ranks_seen, 'backend': backend,
             'allreduce_ms_per_step': ar_ms,
             'per_rank_ms_per_step': {'min': min(per_rank_ms), 'max': max(per_rank_ms), 'ranks': per_rank_ms},

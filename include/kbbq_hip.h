@@ -67,6 +67,17 @@ typedef struct kbbq_ctx kbbq_ctx;
 int         kbbq_abi_version(void);
 const char* kbbq_last_error(void);
 int         kbbq_device_count(int* count);
+/* One process per GPU (torch.distributed.run): the host threads a rank starts, and where they run.
+ * kbbq_host_threads: threads the library's host stages (scan, fill, format) start for `work_bytes` of work -- at most this
+ * process's SHARE of the CPUs it may use: usable CPUs / LOCAL_WORLD_SIZE (the launcher's variable; KBBQ_LOCAL_RANKS for
+ * other launchers; KBBQ_HOST_THREADS overrides the ceiling), so eight ranks of one node do not start eight times the
+ * host's threads.  kbbq_bind_host_to_device / _to_pci: bind the calling thread, and every thread started from it
+ * afterwards, to the CPUs of the NUMA node the GPU (PCI address as hipDeviceGetPCIBusId prints it) hangs on; *numa_node
+ * = -1 and nothing changed when the system names none.  The reference has no counterpart: it is single-threaded
+ * (recalibrate.py:56-57,141-156 walk the reads in one Python loop).                                                    */
+int         kbbq_host_threads(size_t work_bytes);
+int         kbbq_bind_host_to_pci(const char* pci_bus_id, int* numa_node, int* ncpus);
+int         kbbq_bind_host_to_device(int device, int* numa_node, int* ncpus);
 int         kbbq_ctx_create(int device, kbbq_ctx** out);
 int         kbbq_ctx_destroy(kbbq_ctx* ctx);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream).  NULL selects the

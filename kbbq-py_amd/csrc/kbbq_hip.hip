@@ -59,7 +59,8 @@ struct kbbq_ctx {
     // kbbq_accumulate / kbbq_apply (host buffers): two page-locked staging slabs and their device twins, a copy stream and
     // the events that order host copy -> upload -> kernel -> download slab by slab (grown on demand, kept for the next call)
     void* stage_host[2] = {nullptr, nullptr}; void* stage_dev[2] = {nullptr, nullptr}; size_t stage_bytes = 0;
-    hipStream_t stage_stream = nullptr;
+    hipStream_t stage_stream = nullptr;      // uploads
+    hipStream_t stage_down_stream = nullptr; // downloads (kbbq_apply): a stream of their own, so that slab k + 1 goes up while slab k comes back
     hipEvent_t stage_up[2] = {nullptr, nullptr}, stage_used[2] = {nullptr, nullptr}, stage_down[2] = {nullptr, nullptr};
     void* d_rowlut = nullptr;         // K2 on one-read-per-row planes: the LUT narrowed to the rows' pitch (grown on demand)
     size_t rowlut_bytes = 0;
@@ -85,6 +86,15 @@ int kbbq_device_count(int* count)
     if (e != hipSuccess) { *count = 0; return fail(KBBQ_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
     *count = n;
     return KBBQ_OK;
+}
+
+// host_affinity.cpp with the PCI address of HIP device `device`: a rank of a multi-GPU job binds its host threads to the
+// NUMA node of ITS GPU (kbbq/parallel.py init_from_env, bench.py)
+int kbbq_bind_host_to_device(int device, int* numa_node, int* ncpus)
+{
+    char busid[64] = {0};
+    HIPCHK(hipDeviceGetPCIBusId(busid, (int)sizeof busid, device));
+    return kbbq_bind_host_to_pci(busid, numa_node, ncpus);
 }
 
 int kbbq_ctx_create(int device, kbbq_ctx** out)
@@ -167,6 +177,7 @@ int kbbq_ctx_destroy(kbbq_ctx* c)
         if (c->stage_down[b]) (void)hipEventDestroy(c->stage_down[b]);
     }
     if (c->stage_stream) (void)hipStreamDestroy(c->stage_stream);
+    if (c->stage_down_stream) (void)hipStreamDestroy(c->stage_down_stream);
     if (c->d_wgplan) (void)hipFree(c->d_wgplan);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1134,7 +1145,7 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
         t.Qt = KQ; t.S2 = S2; t.maxlen = q.maxlen; t.lut = q.full; t.lut_bytes = (int)((rg_bytes + 15) & ~(size_t)15);
         t.rb = q.rb; t.ctx_off = q.ctx_off; t.W = q.W; t.seg = reinterpret_cast<const long long*>(d_seg); t.R = R; t.wg_start = nullptr; t.order = nullptr;
         t.perm = reinterpret_cast<const long long*>(d_perm); t.pitch = pitch; t.out = d_out; t.status = c->d_status;
-        { const char* x = getenv("KBBQ_K2_XCD_TILES"); t.xcd_tiles = x ? atoi(x) : 1; }
+        { const char* x = getenv("KBBQ_K2_XCD_TILES"); t.xcd_tiles = x ? std::max(0, atoi(x)) : 1; }
         const int64_t per_wg = (int64_t)(K2T_THREADS / 64) * 64 * K2T_STEPS;
         int64_t gt = (t.nchunks + per_wg - 1) / per_wg;
         if (d_seg) {
@@ -1312,14 +1323,14 @@ int kbbq_accumulate_bands_dev(kbbq_ctx* c, const kbbq_band* bands, int nbands, i
     }
     HIPCHK(hipSetDevice(c->device));
     const char* rc_env = getenv("KBBQ_K1_BAND_ROWCOST");
-    const double row_cost = rc_env ? atof(rc_env) : 1.25;
+    const double row_cost = rc_env ? std::max(0.0, atof(rc_env)) : 1.25;     // the knobs are clamped: a zero or negative weight would leave every band one workgroup
     // ... and a chunk of a WIDE row costs more than a chunk of a narrow one (larger tables to zero and flush, 8 instead of 16 copies
     // of the context table, more cycle columns for the same lanes): with equal cost per chunk the widest band of BASELINE config 5
     // ended 25 % after the narrowest (KBBQ_K1_BANDS_DBG=1 prints every band's workgroup end times): + 1 % per chunk of row width
     const char* sl_env = getenv("KBBQ_K1_BAND_SLOPE");
-    const double slope = sl_env ? atof(sl_env) : 0.01;
+    const double slope = sl_env ? std::max(0.0, atof(sl_env)) : 0.01;
     const char* d8_env = getenv("KBBQ_K1_BAND_DN8");          // a band on 8 copies of the context table: twice the same-address atomics there
-    const double dn8_cost = d8_env ? atof(d8_env) : 1.06;
+    const double dn8_cost = d8_env ? std::max(1.0, atof(d8_env)) : 1.06;
     for (auto& grp : groups) {
         if (grp.empty()) continue;
         const int threads = setups[grp[0]].threads;
@@ -1445,7 +1456,7 @@ int kbbq_apply_bands_dev(kbbq_ctx* c, const kbbq_band* bands, int nbands, int R,
         q.rb = (u32)full_lut_row_bytes(Sb); q.W = (u32)full_lut_width(Sb); q.ctx_off = 2u * q.W;
         q.lut = f.out; q.lut_bytes = (int)((((size_t)(33 + KQ) * q.rb) + 15) & ~(size_t)15);
         q.seg = nullptr; q.wg_start = nullptr; q.order = nullptr; q.R = R; q.perm = nullptr; q.pitch = b.pitch; q.out = b.d_out; q.status = c->d_status;
-        { const char* x = getenv("KBBQ_K2_XCD_TILES"); q.xcd_tiles = x ? atoi(x) : 1; }
+        { const char* x = getenv("KBBQ_K2_XCD_TILES"); q.xcd_tiles = x ? std::max(0, atoi(x)) : 1; }
         lds = std::max(lds, (size_t)q.lut_bytes);
         t.wg_start[k] = (int)run;
         run += (q.nchunks + per_wg - 1) / per_wg;
@@ -1872,6 +1883,7 @@ static int stage_prepare(kbbq_ctx* c, size_t bytes)
 {
     if (!c->stage_stream) {
         HIPCHK(hipStreamCreateWithFlags(&c->stage_stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&c->stage_down_stream, hipStreamNonBlocking));
         for (int b = 0; b < 2; ++b) {
             HIPCHK(hipEventCreateWithFlags(&c->stage_up[b], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&c->stage_used[b], hipEventDisableTiming));
@@ -1879,7 +1891,7 @@ static int stage_prepare(kbbq_ctx* c, size_t bytes)
         }
     }
     if (c->stage_bytes < bytes) {
-        HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(c->stage_stream));
+        HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(c->stage_stream)); HIPCHK(hipStreamSynchronize(c->stage_down_stream));
         for (int b = 0; b < 2; ++b) {
             if (c->stage_host[b]) { (void)hipHostFree(c->stage_host[b]); c->stage_host[b] = nullptr; }
             if (c->stage_dev[b]) { (void)hipFree(c->stage_dev[b]); c->stage_dev[b] = nullptr; }
@@ -1906,6 +1918,17 @@ static void threaded_copy(void* dst, const void* src, size_t bytes)
         if (lo < hi) th.emplace_back([=]() { memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
     }
     for (auto& t : th) t.join();
+}
+
+// Every exit of a pipelined run that leaves before its last slab -- a launch or a copy failed -- waits for what is still in
+// flight: the staging buffers and their events belong to the context, and the next call's first two slabs do not wait on
+// events of an earlier call.
+static int stage_drain(kbbq_ctx* c, int rc)
+{
+    if (c->stage_stream) (void)hipStreamSynchronize(c->stage_stream);
+    if (c->stage_down_stream) (void)hipStreamSynchronize(c->stage_down_stream);
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
 }
 
 // The status words hold the SMALLEST flagged read index of every kind over all launches since they were last read; slabs number
@@ -1958,20 +1981,25 @@ int kbbq_accumulate(kbbq_ctx* c, const uint8_t* seq, const uint8_t* cseq, const 
         threaded_copy(h, seq + off, nb); threaded_copy(h + plane, cseq + off, nb); threaded_copy(h + 2 * plane, qual + off, nb);
         memcpy(h + 3 * plane, meta + lo, (size_t)m * 4);
     };
-    int64_t k = 0;
-    for (int64_t lo = 0; lo < nreads; lo += (int64_t)slab, ++k) {
-        const int b = (int)(k & 1);
-        const int64_t m = std::min<int64_t>((int64_t)slab, nreads - lo);
-        if (k >= 2) HIPCHK(hipEventSynchronize(c->stage_up[b]));              // the page-locked slab has been uploaded: free again
-        stage_in(b, lo, m);
-        if (k >= 2) HIPCHK(hipStreamWaitEvent(c->stage_stream, c->stage_used[b], 0));   // the device slab's kernel has run
-        HIPCHK(hipMemcpyAsync(c->stage_dev[b], c->stage_host[b], set, hipMemcpyHostToDevice, c->stage_stream));
-        HIPCHK(hipEventRecord(c->stage_up[b], c->stage_stream));
-        HIPCHK(hipStreamWaitEvent(c->stream, c->stage_up[b], 0));
-        rc = launch(b, m);
-        if (rc) return rc;
-        HIPCHK(hipEventRecord(c->stage_used[b], c->stream));
-    }
+    auto pipelined = [&]() -> int {
+        int64_t k = 0;
+        for (int64_t lo = 0; lo < nreads; lo += (int64_t)slab, ++k) {
+            const int b = (int)(k & 1);
+            const int64_t m = std::min<int64_t>((int64_t)slab, nreads - lo);
+            if (k >= 2) HIPCHK(hipEventSynchronize(c->stage_up[b]));              // the page-locked slab has been uploaded: free again
+            stage_in(b, lo, m);
+            if (k >= 2) HIPCHK(hipStreamWaitEvent(c->stage_stream, c->stage_used[b], 0));   // the device slab's kernel has run
+            HIPCHK(hipMemcpyAsync(c->stage_dev[b], c->stage_host[b], set, hipMemcpyHostToDevice, c->stage_stream));
+            HIPCHK(hipEventRecord(c->stage_up[b], c->stage_stream));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->stage_up[b], 0));
+            const int r2 = launch(b, m);
+            if (r2) return r2;
+            HIPCHK(hipEventRecord(c->stage_used[b], c->stream));
+        }
+        return KBBQ_OK;
+    };
+    rc = pipelined();
+    if (rc) return stage_drain(c, rc);
     rc = kbbq_ctx_status(c, nullptr);
     if (rc) {
         // something was flagged: which read of the WHOLE input comes first?  (nothing reaches the caller's tables)
@@ -2037,28 +2065,38 @@ int kbbq_apply(kbbq_ctx* c, const uint8_t* seq, const uint8_t* qual, const uint3
         pending[b].m = 0;
         return KBBQ_OK;
     };
+    // Order of a slab k in buffers b = k & 1: [host] wait for slab k - 2's download (stage_out: everything of slab k - 2 on these
+    // buffers has then finished, kernel included) -> host copy in -> upload (upload stream) -> kernel (launch stream, behind the
+    // upload's event) -> download (DOWNLOAD stream, behind the kernel's event).  Uploads and downloads are on different streams,
+    // so slab k + 1 goes up while slab k's kernel runs and slab k's (or k - 1's) new qualities come back: both directions of
+    // PCIe busy at once (with both on one in-order stream the order was strictly U k, K k, D k, U k + 1).
     int64_t k = 0;
-    for (int64_t lo = 0; lo < nreads; lo += (int64_t)slab, ++k) {
-        const int b = (int)(k & 1);
-        const int64_t m = std::min<int64_t>((int64_t)slab, nreads - lo);
-        rc = stage_out(b);                                                // slab k - 2 (same buffers): downloaded -> the caller's rows
-        if (rc) return rc;
-        stage_in(b, lo, m);
-        rc = upload(b, m, c->stage_stream);                               // the copy stream is in order: behind slab k - 2's download
-        if (rc) return rc;
-        HIPCHK(hipEventRecord(c->stage_up[b], c->stage_stream));
-        HIPCHK(hipStreamWaitEvent(c->stream, c->stage_up[b], 0));
-        rc = launch(b, m);
-        if (rc) return rc;
-        HIPCHK(hipEventRecord(c->stage_used[b], c->stream));
-        HIPCHK(hipStreamWaitEvent(c->stage_stream, c->stage_used[b], 0));
-        HIPCHK(hipMemcpyAsync((uint8_t*)c->stage_host[b] + 2 * plane, (uint8_t*)c->stage_dev[b] + 2 * plane, (size_t)m * pitch, hipMemcpyDeviceToHost, c->stage_stream));
-        HIPCHK(hipEventRecord(c->stage_down[b], c->stage_stream));
-        pending[b] = {lo, m};
-    }
+    auto pipelined = [&]() -> int {
+        for (int64_t lo = 0; lo < nreads; lo += (int64_t)slab, ++k) {
+            const int b = (int)(k & 1);
+            const int64_t m = std::min<int64_t>((int64_t)slab, nreads - lo);
+            int r2 = stage_out(b);                                            // slab k - 2 (same buffers): downloaded -> the caller's rows
+            if (r2) return r2;
+            stage_in(b, lo, m);
+            r2 = upload(b, m, c->stage_stream);
+            if (r2) return r2;
+            HIPCHK(hipEventRecord(c->stage_up[b], c->stage_stream));
+            HIPCHK(hipStreamWaitEvent(c->stream, c->stage_up[b], 0));
+            r2 = launch(b, m);
+            if (r2) return r2;
+            HIPCHK(hipEventRecord(c->stage_used[b], c->stream));
+            HIPCHK(hipStreamWaitEvent(c->stage_down_stream, c->stage_used[b], 0));
+            HIPCHK(hipMemcpyAsync((uint8_t*)c->stage_host[b] + 2 * plane, (uint8_t*)c->stage_dev[b] + 2 * plane, (size_t)m * pitch, hipMemcpyDeviceToHost, c->stage_down_stream));
+            HIPCHK(hipEventRecord(c->stage_down[b], c->stage_down_stream));
+            pending[b] = {lo, m};
+        }
+        return KBBQ_OK;
+    };
+    rc = pipelined();
+    if (rc) return stage_drain(c, rc);
     rc = kbbq_ctx_status(c, nullptr);
     if (rc) {
-        HIPCHK(hipStreamSynchronize(c->stage_stream));
+        (void)stage_drain(c, rc);
         rc = first_offender(c, nreads, slab, [&](int64_t lo, int64_t m) {
             stage_in(0, lo, m);
             int r2 = upload(0, m, c->stream);
@@ -2066,7 +2104,7 @@ int kbbq_apply(kbbq_ctx* c, const uint8_t* seq, const uint8_t* qual, const uint3
         });
         return rc ? rc : fail(KBBQ_E_HIP, "kbbq_apply: a status reported by the pipelined run did not reproduce slab by slab");
     }
-    for (int b = 0; b < 2; ++b) { rc = stage_out((int)((k + b) & 1)); if (rc) return rc; }     // the older of the two first
+    for (int b = 0; b < 2; ++b) { rc = stage_out((int)((k + b) & 1)); if (rc) return stage_drain(c, rc); }     // the older of the two first
     return KBBQ_OK;
 }
 

@@ -20,7 +20,25 @@ from . import _native as N
 
 uint8, int32, int64, float64 = np.dtype(np.uint8), np.dtype(np.int32), np.dtype(np.int64), np.dtype(np.float64)
 
-_current = [0]           # the device this process works on
+import threading
+
+
+class _Current(threading.local):
+    """The device the calling THREAD works on (torch's current device is thread-local too: the egress pipeline's worker
+    selects its output's device without touching what the main thread reads -- ADVICE r3).  This module is single-device in
+    practice (the command line without torch drives one GPU); the kbbq context's calls made from the egress thread are
+    copies, an event and a stream synchronisation on the context's one stream, made while the main thread waits in the
+    pipeline's last stage and enqueues nothing itself."""
+    index = 0
+
+    def __getitem__(self, i):
+        return self.index
+
+    def __setitem__(self, i, value):
+        self.index = int(value)
+
+
+_current = _Current()    # _current[0]: kept as the spelling the rest of the module uses
 
 
 class Device:

@@ -62,6 +62,13 @@ def report(reset=True):
         total = sum(s for s, _ in _acc.values())
         sys.stderr.write('kbbq stages: ' + '  '.join('%s %.3fs' % (n, s) for n, (s, _) in _acc.items())
                          + '  (sum %.3fs)\n' % total)
+        try:
+            from .parallel import HOST_BINDING as hb
+            if hb:
+                sys.stderr.write('kbbq host: %d host threads (1 / %d of the CPUs the job may use), NUMA node %s, %d CPUs in the mask\n'
+                                 % (hb['host_threads'], hb['local_ranks'], hb['numa_node'] if hb['numa_node'] >= 0 else 'not named', hb['cpus']))
+        except Exception:
+            pass
         if TIMELINE:
             t0 = _process_start()
             sys.stderr.write('kbbq timeline (s since the process started; this module was imported at %.3f, now %.3f):\n'

@@ -707,9 +707,10 @@ def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None,
     try:
         with stage('fill'):
             if bands:
-                keep = to_device             # a band the kernels refuse in its layout is re-filled as character rows: the
-                return dict(common, other=B if to_device else None,      # caller closes B after the tally (close_later)
-                            bands=_fill_bands(A, B, infer_rg_flag, lo, hi, to_device, R, S))
+                filled = _fill_bands(A, B, infer_rg_flag, lo, hi, to_device, R, S)
+                keep = to_device             # only once the bands exist (a fill that raises must not leak B's mapping: ADVICE r3); a
+                return dict(common, other=B if to_device else None, bands=filled)    # band the kernels refuse in its layout is re-filled
+                                                                                     # as character rows: the caller closes B after the tally
             seq, cseq, qual, meta = A.fill(B, infer_rg_flag, hi - lo, pitch, first=lo)
         return dict(common, seq=seq, cseq=cseq, qual=qual, meta=meta)
     finally:

@@ -99,6 +99,7 @@ def init_from_env():
     if torch.cuda.is_available():
         local = local % torch.cuda.device_count() if backend != 'nccl' else local
         torch.cuda.set_device(local)
+        bind_host_threads(local)
     # stdout is the recalibrated FASTQ: the communication libraries' own banners (Gloo's "connected to peer
     # ranks", RCCL's version line under NCCL_DEBUG) go to stderr -- they appear while the group is set up and
     # at the first collective, so both happen under the redirection
@@ -122,6 +123,30 @@ def init_from_env():
         os.dup2(saved, 1)
         os.close(saved)
     return world_rank()
+
+
+HOST_BINDING = {}        # what bind_host_threads did for this process (stage reports, bench.py's line)
+
+
+def bind_host_threads(device):
+    """A rank's host side under the launcher: its scan / fill / format threads are 1 / LOCAL_WORLD_SIZE of the CPUs the job
+    may use (csrc/host_threads.h reads the launcher's variable itself) and run on the NUMA node its GPU hangs on
+    (kbbq_bind_host_to_device; KBBQ_NUMA_BIND=0 leaves the affinity alone).  Returns and records {numa_node, cpus,
+    host_threads}."""
+    import ctypes
+    import os
+    from . import _native as N
+    lib = N.load()
+    node, ncpus = ctypes.c_int(-1), ctypes.c_int(0)
+    if os.environ.get('KBBQ_NUMA_BIND', '1') != '0':
+        try:
+            N.check(lib.kbbq_bind_host_to_device(int(device), ctypes.byref(node), ctypes.byref(ncpus)))
+        except Exception:                    # noqa: BLE001 -- binding is an optimisation: a box that refuses it still runs
+            node.value = -1
+    HOST_BINDING.update(numa_node=node.value, cpus=ncpus.value or len(os.sched_getaffinity(0)),
+                        host_threads=int(lib.kbbq_host_threads(1 << 40)),
+                        local_ranks=int(os.environ.get('KBBQ_LOCAL_RANKS') or os.environ.get('LOCAL_WORLD_SIZE') or 1))
+    return dict(HOST_BINDING)
 
 
 def barrier():

@@ -1,0 +1,132 @@
+"""
+Rehearsals of the one-process-per-GPU mode with as many ranks as a one-GPU box allows: its process guard admits six
+processes on the card, one of which is this test runner, so FIVE ranks share the GPU here and talk over gloo
+(KBBQ_DIST_BACKEND=gloo); the 8-rank forms of the host logic run on the CPU (tests/test_parallel_gloo.py,
+tests/test_host_logic.py::test_every_rank_cuts_its_own_byte_range, tests/test_host_threads.py).  What runs here is the
+whole product path per rank -- own byte range, packer, K1, ONE allreduce of the count tables, replicated solve, K2,
+writer -- on the reference's goldens (BASELINE configs 1, 3 and 5's cuts), `kbbq benchmark -f`, the BAM-sourced tally
+and bench.py's own launcher.
+"""
+import glob
+import json
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+RANKS = 5
+
+
+@pytest.fixture(scope='module')
+def dev():
+    import torch
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from kbbq import _device
+    return _device
+
+
+def _run_ranks(world, argv, timeout=400, env=None, worker='dist_cli_worker.py'):
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, KBBQ_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', **(env or {}))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'tests', worker)] + argv
+    return subprocess.run(cmd, env=env, capture_output=True, timeout=timeout)
+
+
+def _usable_cpus():
+    from kbbq import _native as N
+    r = subprocess.run([sys.executable, '-c', 'import sys; sys.path.insert(0, %r); from kbbq import _native as N; print(N.load().kbbq_host_threads(1 << 40))'
+                        % os.path.join(ROOT, 'kbbq-py_amd')], capture_output=True, timeout=120,
+                       env={k: v for k, v in os.environ.items() if k not in ('LOCAL_WORLD_SIZE', 'KBBQ_LOCAL_RANKS', 'KBBQ_HOST_THREADS')})
+    return int(r.stdout.decode().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize('name', ['c1_10k_1rg', 'c3cut_2k_8rg', 'c5cut_2k_mixed'])
+def test_five_ranks_write_the_reference_output(dev, oracle, name, tmp_path):
+    """`kbbq recalibrate -f A B -o FILE` on 5 ranks: FILE.rank0000 ... rank0004 concatenated are the reference's bytes;
+    every rank cut its own byte range; every rank started 1 / 5 of the host threads."""
+    from test_gpu_parity import _files
+    info, _ = load_golden(name)
+    fa, fb = _files(oracle, info, tmp_path)
+    out = str(tmp_path / 'out.fq')
+    argv = ['recalibrate', '-f', fa, fb, '-o', out] + (['--infer-rg'] if info['case']['infer_rg'] else [])
+    r = _run_ranks(RANKS, argv, env={'KBBQ_TIMING': '1'})
+    err = r.stderr.decode()
+    assert r.returncode == 0, err[-3000:]
+    assert r.stdout == b''
+    parts = sorted(glob.glob(out + '.rank*'))
+    assert len(parts) == RANKS
+    text = b''.join(open(p, 'rb').read() for p in parts).decode()
+    assert len(text) == info['output_len'] and oracle.sha256(text) == info['output_sha256']
+    assert err.count('open+index+scan (own byte range)') == RANKS and 'open+index+scan (wait)' not in err
+    threads = [int(x) for x in re.findall(r'kbbq host: (\d+) host threads \(1 / %d of' % RANKS, err)]
+    assert len(threads) == RANKS and sum(threads) <= max(_usable_cpus(), RANKS), err[-1500:]
+
+
+def test_five_ranks_print_in_rank_order(dev, oracle, tmp_path):
+    """The same to a shared stdout (the ranks print in turn): BASELINE config 3's cut, 8 read groups."""
+    from test_gpu_parity import _files
+    info, _ = load_golden('c3cut_2k_8rg')
+    fa, fb = _files(oracle, info, tmp_path)
+    r = _run_ranks(RANKS, ['recalibrate', '-f', fa, fb, '--infer-rg'])
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    text = r.stdout.decode()
+    assert len(text) == info['output_len'] and oracle.sha256(text) == info['output_sha256']
+
+
+def test_five_ranks_print_the_reference_benchmark(dev, oracle, tmp_path):
+    """`kbbq benchmark -f` on 5 ranks (BASELINE config 5's benchmark half): the golden table, every rank flagging about a
+    fifth of the alignments, all of them together."""
+    import oracle_benchmark as OB
+    info, _ = load_golden('bench_a')
+    paths = OB.synth_truthset(str(tmp_path), **info['case'])
+    argv = ['benchmark', '-b', paths['sam'], '-r', paths['fa'], '-v', paths['vcf'], '-d', paths['bed'], '-l', 'lbl', '-f', paths['fq']]
+    r = _run_ranks(RANKS, argv, env={'KBBQ_TIMING': '1'})
+    err = r.stderr.decode()
+    assert r.returncode == 0, err[-3000:]
+    assert r.stdout.decode() == info['printed']['fastq']
+    seen = re.findall(r'rank (\d) of %d counts FASTQ reads \[\d+, \d+\) and flagged alignments \[\d+, \d+\): (\d+) of (\d+)' % RANKS, err)
+    assert sorted(x[0] for x in seen) == [str(i) for i in range(RANKS)], err[-1500:]
+    total = int(seen[0][2])
+    assert all(int(k) <= 0.45 * total for _, k, _ in seen) and sum(int(k) for _, k, _ in seen) >= total
+    # and without -f: the alignments themselves sharded
+    r = _run_ranks(RANKS, argv[:-2])
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert r.stdout.decode() == info['printed']['bam']
+
+
+def test_five_ranks_tally_alignments_like_one(dev, oracle, tmp_path):
+    """kbbq.gatk.bqsr.bam_to_bqsr_covariates on 5 ranks (the one-pass tally on shards of the alignments, one allreduce):
+    the nine vectors of the reference golden `bqsr_b`."""
+    from test_oracle_bqsr import VEC, _inputs
+    info, gold, paths = _inputs('bqsr_b', tmp_path, oracle)
+    out = str(tmp_path / 'vec.json')
+    r = _run_ranks(RANKS, [paths['sam'], paths['fa'], paths['vcf'], '1', out], worker='dist_api_worker.py')
+    assert r.returncode == 0, r.stderr.decode()[-6000:]
+    got = json.load(open(out))['vectors']
+    for k, g in zip(VEC, got):
+        assert np.array_equal(np.array(g, dtype=np.int64), gold[k]), k
+
+
+def test_bench_with_five_ranks_checks_every_rank(dev):
+    """`python bench.py --gpus 5` through its own launcher (gloo rehearsal on the shared GPU): one JSON line, every rank
+    verified its own batch and the line carries the AND, every rank reports its share of the host threads."""
+    env = dict(os.environ); env.pop('RANK', None); env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(RANKS), '--steps', '2', '--warmup', '1',
+                        '--reads', '200000'], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.split('\n') if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == RANKS and d['ranks_seen'] == RANKS and d['backend'] == 'gloo' and 'rehearsal' in d['data']
+    assert d['verified'] is True and d['verified_per_rank'] == [True] * RANKS
+    assert len(d['per_rank_ms_per_step']['ranks']) == RANKS
+    assert d['host_binding']['local_ranks'] == RANKS and d['host_binding']['host_threads'] >= 1
+    assert abs(d['value'] - RANKS * 200000 * 150 / (d['ms_per_step'] / 1e3)) / d['value'] < 1e-6

@@ -422,7 +422,7 @@ def test_every_rank_cuts_its_own_byte_range(oracle, tmp_path):
     oracle.write_fastq(fa, names, seq, qual, meta)
     oracle.write_fastq(fb, names, cseq, qual, meta)
     whole = fastx.pack_pair(fa, fb, True)
-    for world in (2, 3, 5):
+    for world in (2, 3, 5, 8):
         parts, errors = _ranks_in_threads(world, lambda r, g: fastx.pack_pair(fa, fb, True, shard=(r, world), gather=g))
         assert not any(errors), errors
         assert [p['first'] for p in parts] == [sum(q['n'] for q in parts[:i]) for i in range(world)]

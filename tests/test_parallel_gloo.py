@@ -1,5 +1,5 @@
 """
-Multi-process CPU test of the N > 1 host logic (world_size 2, gloo): shard ranges,
+Multi-process CPU test of the N > 1 host logic (world_size 2 and 8, gloo): shard ranges,
 first-appearance read-group merge, global max length and the sum-allreduce of the count
 tables.  K1 itself cannot run here (no GPU): each rank's tables come from the CPU oracle
 (tests may use it), which is exactly what K1 produces on the GPU box
@@ -67,9 +67,8 @@ def _worker(rank, world, port, name, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('name', ['c1_10k_1rg', 'c3cut_2k_8rg'])
-def test_sharded_tables_allreduce_to_reference(name):
-    world = 2
+@pytest.mark.parametrize('name,world', [('c1_10k_1rg', 2), ('c3cut_2k_8rg', 2), ('c3cut_2k_8rg', 8), ('c5cut_2k_mixed', 8)])
+def test_sharded_tables_allreduce_to_reference(name, world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -81,7 +80,7 @@ def test_sharded_tables_allreduce_to_reference(name):
         p.join(timeout=60)
         assert p.exitcode == 0
     info, _ = load_golden(name)
-    assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res)
+    assert sorted(r[0] for r in res) == list(range(world)) and all(r[1] for r in res)
     assert sum(r[2] for r in res) == info['case']['n']
 
 
