@@ -99,6 +99,7 @@ int kbbq_dev_free(kbbq_ctx* ctx, void* dptr);
 int kbbq_dev_zero(kbbq_ctx* ctx, void* dptr, size_t bytes);                       /* async */
 int kbbq_dev_upload(kbbq_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);   /* sync */
 int kbbq_dev_download(kbbq_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* sync */
+int kbbq_dev_mem_info(kbbq_ctx* ctx, size_t* free_bytes, size_t* total_bytes);          /* hipMemGetInfo: what the file path sizes its device budget with */
 /* the rest of what the file path needs to run WITHOUT torch (kbbq/_hipmem.py: the single-GPU command line never imports
  * it): page-locked host buffers for the ingest / egress slabs, copies enqueued on the context's stream (kind 1 host to
  * device, 2 device to host, 3 device to device; no synchronisation), events on that stream (when has a slab's upload
@@ -550,6 +551,25 @@ int         kbbq_fastq_name(const kbbq_fastq* f, int64_t i, const char** name, i
 int         kbbq_fastq_rg_count(const kbbq_fastq* f);
 const char* kbbq_fastq_rg_name(const kbbq_fastq* f, int i);
 int         kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* info5);
+/* ---- the same files read SEQUENTIALLY (csrc/fastq_stream.cpp): inputs that cannot be mapped or sought, inputs of any size ----
+ * The reference walks its inputs read by read in constant memory (recalibrate.py:56-57 zip(FastxFile(A), FastxFile(B)),
+ * :141-156 a second walk over A), so `-f <(zcat a.fq.gz) <(zcat b.fq.gz)` and files larger than memory work there.  A
+ * kbbq_fastq_stream hands out SEGMENTS -- whole records, each an ordinary kbbq_fastq over memory of its own (scan / meta /
+ * fill_rows / format work on it; close it with kbbq_fastq_close): the leading file about `max_bytes` per segment
+ * (records = 0), the following file exactly the leader's number of records (records > 0; fewer only when it ends first: zip()
+ * stops there).  *segment = NULL when the input has ended; *at_end = 1 when it ends behind this segment.  path: a regular
+ * file, a named pipe / process substitution, "-" = standard input; gzip bytes are refused (decompress in the pipe).
+ * kbbq_fastq_stream_tee: every byte handed out is also appended to `fd` -- the spool a pipe's file A is kept in for pass 2.
+ * kbbq_fastq_scan_next: kbbq_fastq_scan of one segment, with what the reference's walk carries from read to read handed
+ * over by the caller: the read groups met so far (kbbq_fastq_set_rg_names first; new ones are appended, first-appearance
+ * order over the whole input, recalibrate.py:59-64) and the longest read so far (recalibrate.py:89-101).                  */
+typedef struct kbbq_fastq_stream kbbq_fastq_stream;
+int         kbbq_fastq_stream_open(const char* path, kbbq_fastq_stream** out);
+int         kbbq_fastq_stream_is_regular(const kbbq_fastq_stream* s);
+int         kbbq_fastq_stream_tee(kbbq_fastq_stream* s, int fd);
+int         kbbq_fastq_stream_next(kbbq_fastq_stream* s, size_t max_bytes, int64_t records, kbbq_fastq** segment, int* at_end);
+int         kbbq_fastq_stream_close(kbbq_fastq_stream* s);
+int         kbbq_fastq_scan_next(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t prior_longest, int64_t* info5);
 /* kbbq_fastq_open of both files (b may be NULL) + kbbq_fastq_scan on the library's own threads; _begin returns at
  * once, _wait joins, hands over the readers and info5 and frees the job (call it exactly once).  File A's error is
  * reported before file B's.  Lets a Python caller set its device up while the files are being read. */

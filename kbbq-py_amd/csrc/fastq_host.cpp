@@ -14,6 +14,7 @@
 #include "../../include/kbbq_hip.h"
 #include "host_threads.h"
 #include "bam_host.h"
+#include "fastq_host.h"
 
 #include <algorithm>
 #include <atomic>
@@ -37,27 +38,6 @@
 
 extern "C" const char* kbbq_last_error(void);
 int kbbq_set_error_(int code, const char* msg);      // defined in kbbq_hip.hip
-
-// std::vector whose resize() leaves new elements uninitialised: the index arrays of a 50 M-read file are GBs that
-// the indexing threads overwrite anyway (and first-touch in parallel instead of in one zero-filling thread)
-template <typename T> struct raw_alloc : std::allocator<T> {
-    template <typename U> struct rebind { using other = raw_alloc<U>; };
-    template <typename U, typename... A> void construct(U* p, A&&... a)
-    {
-        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
-    }
-};
-template <typename T> using raw_vector = std::vector<T, raw_alloc<T>>;
-
-struct kbbq_fastq {
-    const uint8_t* buf = nullptr; size_t size = 0; bool mapped = false;
-    size_t range_end = 0;                  // end of the indexed byte range (the file size for a whole-file reader)
-    raw_vector<uint64_t> h0, s0, q0;       // start offsets of header / sequence / quality lines
-    raw_vector<uint32_t> hlen, slen;       // header line length (without '@', up to whitespace = name), sequence length
-    std::vector<std::string> rg_names;     // first-appearance order (filled by scan / fill with infer_rg)
-    std::vector<uint8_t> owned;            // the inflated text of a compressed file
-    ~kbbq_fastq() { if (mapped && buf) munmap((void*)buf, size); }
-};
 
 static unsigned nthreads_for(size_t work) { return kbbq_threads_for(work); }
 
@@ -84,6 +64,84 @@ template <typename F> static void parallel_for(int64_t n, unsigned nt, F f)
         if (lo < hi) th.emplace_back([=]() { f(lo, hi); });
     }
     for (auto& t : th) t.join();
+}
+
+int kbbq_fastq_index_range_(kbbq_fastq* f, size_t r0, size_t r1)
+{
+    // Line index, in parallel and without a merged list of line ends: (1) every thread collects the '\n' offsets of
+    // its byte range; (2) a prefix sum of the counts numbers the lines; (3) every thread turns ITS line ends into
+    // record fields -- line g is field g % 4 of record g / 4, and starts after the previous line end, which is the
+    // previous entry of the same list or the last entry of an earlier thread's.
+    const unsigned nt = nthreads_for(r1 - r0);
+    std::vector<raw_vector<uint64_t>> parts(nt);
+    const size_t per = (r1 - r0 + nt - 1) / nt;
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) {
+            const size_t lo = std::min(r1, r0 + t * per), hi = std::min(r1, lo + per);
+            th.emplace_back([f, lo, hi, &parts, t]() {
+                auto& v = parts[t];
+                v.reserve((hi - lo) / 64 + 16);
+                newline_offsets(f->buf, lo, hi, v);
+            });
+        }
+        for (auto& t : th) t.join();
+    }
+    if (r1 == f->size && r1 > r0 && f->buf[f->size - 1] != '\n') parts[nt - 1].push_back(f->size);   // last line without '\n'
+    std::vector<uint64_t> base(nt + 1, 0), before(nt, 0);      // first line number of a part; line end before its first
+    {
+        uint64_t last_end = (uint64_t)r0 - 1;                   // "line end" before the range (before offset 0: -1)
+        for (unsigned t = 0; t < nt; ++t) {
+            base[t + 1] = base[t] + parts[t].size();
+            before[t] = last_end;
+            if (!parts[t].empty()) last_end = parts[t].back();
+        }
+    }
+    const uint64_t nlines = base[nt];
+    if (nlines % 4 != 0) return 4;
+    const int64_t n = (int64_t)(nlines / 4);
+    f->range_end = r1;
+    f->h0.resize(n); f->s0.resize(n); f->q0.resize(n); f->hlen.resize(n); f->slen.resize(n);
+    raw_vector<uint32_t> qlen((size_t)n);
+    std::atomic<int> bad(0);
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) {
+            if (parts[t].empty()) continue;
+            th.emplace_back([f, t, &parts, &base, &before, &qlen, &bad]() {
+                const auto& v = parts[t];
+                uint64_t start = before[t] + 1;                  // (uint64_t)-1 + 1 == 0 for the file's first line
+                for (size_t j = 0; j < v.size(); ++j) {
+                    const uint64_t g = base[t] + j, i = g >> 2;
+                    uint64_t end = v[j];
+                    if (end > start && f->buf[end - 1] == '\r') --end;
+                    switch (g & 3) {
+                    case 0: {
+                        if (end <= start || f->buf[start] != '@') { bad = 1; break; }
+                        uint64_t ne = start + 1;                 // name: up to the first whitespace
+                        while (ne < end && f->buf[ne] != ' ' && f->buf[ne] != '\t') ++ne;
+                        f->h0[i] = start + 1; f->hlen[i] = (uint32_t)(ne - start - 1);
+                        break;
+                    }
+                    case 1:
+                        if (end - start > 65535) { bad = 3; f->s0[i] = start; f->slen[i] = 0; break; }
+                        f->s0[i] = start; f->slen[i] = (uint32_t)(end - start);
+                        break;
+                    case 2: break;                               // the '+' line
+                    default:
+                        f->q0[i] = start; qlen[i] = (uint32_t)std::min<uint64_t>(end - start, 0xFFFFFFFFu);
+                    }
+                    start = v[j] + 1;
+                }
+            });
+        }
+        for (auto& t : th) t.join();
+    }
+    if (!bad.load())
+        parallel_for(n, nt, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) if (qlen[(size_t)i] != f->slen[i]) { bad = 2; break; }
+        });
+    return bad.load();
 }
 
 extern "C" {
@@ -128,83 +186,12 @@ static int open_impl(const char* path, int64_t range_lo, int64_t range_hi, kbbq_
     if ((r0 > 0 && f->buf[r0 - 1] != '\n') || (r1 < f->size && r1 > r0 && f->buf[r1 - 1] != '\n')) {
         delete f; return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": the byte range does not start / end at a line end").c_str());
     }
-    // Line index, in parallel and without a merged list of line ends: (1) every thread collects the '\n' offsets of
-    // its byte range; (2) a prefix sum of the counts numbers the lines; (3) every thread turns ITS line ends into
-    // record fields -- line g is field g % 4 of record g / 4, and starts after the previous line end, which is the
-    // previous entry of the same list or the last entry of an earlier thread's.
-    const unsigned nt = nthreads_for(r1 - r0);
-    std::vector<raw_vector<uint64_t>> parts(nt);
-    const size_t per = (r1 - r0 + nt - 1) / nt;
-    {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t) {
-            const size_t lo = std::min(r1, r0 + t * per), hi = std::min(r1, lo + per);
-            th.emplace_back([f, lo, hi, &parts, t]() {
-                auto& v = parts[t];
-                v.reserve((hi - lo) / 64 + 16);
-                newline_offsets(f->buf, lo, hi, v);
-            });
-        }
-        for (auto& t : th) t.join();
-    }
-    if (r1 == f->size && r1 > r0 && f->buf[f->size - 1] != '\n') parts[nt - 1].push_back(f->size);   // last line without '\n'
-    std::vector<uint64_t> base(nt + 1, 0), before(nt, 0);      // first line number of a part; line end before its first
-    {
-        uint64_t last_end = (uint64_t)r0 - 1;                   // "line end" before the range (before offset 0: -1)
-        for (unsigned t = 0; t < nt; ++t) {
-            base[t + 1] = base[t] + parts[t].size();
-            before[t] = last_end;
-            if (!parts[t].empty()) last_end = parts[t].back();
-        }
-    }
-    const uint64_t nlines = base[nt];
-    if (nlines % 4 != 0) { delete f; return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": not a 4-line-per-record FASTQ file").c_str()); }
-    const int64_t n = (int64_t)(nlines / 4);
-    f->range_end = r1;
-    f->h0.resize(n); f->s0.resize(n); f->q0.resize(n); f->hlen.resize(n); f->slen.resize(n);
-    raw_vector<uint32_t> qlen((size_t)n);
-    std::atomic<int> bad(0);
-    {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t) {
-            if (parts[t].empty()) continue;
-            th.emplace_back([f, t, &parts, &base, &before, &qlen, &bad]() {
-                const auto& v = parts[t];
-                uint64_t start = before[t] + 1;                  // (uint64_t)-1 + 1 == 0 for the file's first line
-                for (size_t j = 0; j < v.size(); ++j) {
-                    const uint64_t g = base[t] + j, i = g >> 2;
-                    uint64_t end = v[j];
-                    if (end > start && f->buf[end - 1] == '\r') --end;
-                    switch (g & 3) {
-                    case 0: {
-                        if (end <= start || f->buf[start] != '@') { bad = 1; break; }
-                        uint64_t ne = start + 1;                 // name: up to the first whitespace
-                        while (ne < end && f->buf[ne] != ' ' && f->buf[ne] != '\t') ++ne;
-                        f->h0[i] = start + 1; f->hlen[i] = (uint32_t)(ne - start - 1);
-                        break;
-                    }
-                    case 1:
-                        if (end - start > 65535) { bad = 3; f->s0[i] = start; f->slen[i] = 0; break; }
-                        f->s0[i] = start; f->slen[i] = (uint32_t)(end - start);
-                        break;
-                    case 2: break;                               // the '+' line
-                    default:
-                        f->q0[i] = start; qlen[i] = (uint32_t)std::min<uint64_t>(end - start, 0xFFFFFFFFu);
-                    }
-                    start = v[j] + 1;
-                }
-            });
-        }
-        for (auto& t : th) t.join();
-    }
-    if (!bad.load())
-        parallel_for(n, nt, [&](int64_t lo, int64_t hi) {
-            for (int64_t i = lo; i < hi; ++i) if (qlen[(size_t)i] != f->slen[i]) { bad = 2; break; }
-        });
-    if (bad.load()) {
-        const int b = bad.load(); delete f;
-        return kbbq_set_error_(KBBQ_E_ARG, b == 1 ? "record header does not start with @"
-                                          : b == 2 ? "sequence and quality lengths differ" : "read longer than 65535 bases");
+    const int bad = kbbq_fastq_index_range_(f, r0, r1);
+    if (bad) {
+        delete f;
+        return kbbq_set_error_(KBBQ_E_ARG, bad == 4 ? (std::string(path) + ": not a 4-line-per-record FASTQ file").c_str()
+                                          : bad == 1 ? "record header does not start with @"
+                                          : bad == 2 ? "sequence and quality lengths differ" : "read longer than 65535 bases");
     }
     *out = f;
     return KBBQ_OK;
@@ -390,7 +377,22 @@ extern "C" {
 // [2] R, [3] error kind (0 none, 1 RG IndexError, 2 RG AssertionError, 3 name prefix, 4 length
 // mismatch, 5 shorter than the running maximum), [4] error index.  b may be NULL (single file:
 // kinds 3-5 are not checked -- pass 2 of the reference accepts any lengths).
-int kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* info)
+static int scan_impl(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, bool keep_prior, uint32_t prior_longest, int64_t* info);
+int kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* info) { return scan_impl(a, b, infer_rg, false, 0, info); }
+
+// The scan of ONE SEGMENT of a pair that is being read piece by piece (fastq_stream.cpp): what the reference's single walk
+// over the reads carries from read to read is carried from segment to segment by the caller -- the read groups met so far
+// (installed with kbbq_fastq_set_rg_names before the call: new ones are appended, ids stay first-appearance order over the
+// whole file, recalibrate.py:59-64) and the longest read so far (`prior_longest`: a read shorter than it is the IndexError of
+// recalibrate.py:89-101 even when it is the longest of its own segment).  info as kbbq_fastq_scan, indices relative to the
+// segment; [1] is the longest USABLE read of this segment only, [2] the number of read groups including the prior ones.
+int kbbq_fastq_scan_next(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t prior_longest, int64_t* info)
+{
+    if (prior_longest < 0 || prior_longest > 65535) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_scan_next: bad prior_longest");
+    return scan_impl(a, b, infer_rg, true, (uint32_t)prior_longest, info);
+}
+
+static int scan_impl(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, bool keep_prior, uint32_t prior_longest, int64_t* info)
 {
     if (!a || !info) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_scan: NULL argument");
     int64_t n = (int64_t)a->h0.size();
@@ -446,7 +448,7 @@ int kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* i
         }
     });
     if (b) {
-        std::vector<uint32_t> before((size_t)nchunks, 0);      // longest read of all earlier chunks
+        std::vector<uint32_t> before((size_t)nchunks, prior_longest);      // longest read of all earlier chunks (and segments)
         for (int64_t c = 1; c < nchunks; ++c) before[(size_t)c] = std::max(before[(size_t)c - 1], ch[(size_t)c - 1].longest);
         over_chunks([&](Chunk& c) {
             uint32_t runmax = before[(size_t)(&c - ch.data())];
@@ -462,7 +464,8 @@ int kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* i
     auto consider = [&](int64_t idx, int kind) {         // lowest index wins; kinds are in check order
         if (idx >= 0 && (err_idx < 0 || idx < err_idx || (idx == err_idx && kind < err_kind))) { err_idx = idx; err_kind = kind; }
     };
-    a->rg_names.clear();
+    const std::vector<std::string> prior = keep_prior ? a->rg_names : std::vector<std::string>();
+    a->rg_names = prior;
     auto add_rgs = [](std::vector<std::string>& to, const std::vector<std::string>& from) {
         for (const auto& s : from) if (std::find(to.begin(), to.end(), s) == to.end()) to.push_back(s);
     };
@@ -471,13 +474,13 @@ int kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* i
             add_rgs(a->rg_names, c.rgs);
             if (c.rg_err >= 0) { consider(c.rg_err, c.rg_kind); break; }      // the reference never looks further
         }
-    } else if (n > 0) a->rg_names.emplace_back("0");
+    } else if (n > 0 && a->rg_names.empty()) a->rg_names.emplace_back("0");
     for (const auto& c : ch) if (c.pair_err >= 0) { consider(c.pair_err, c.pair_kind); break; }
     int64_t usable = n;
     if (err_idx >= 0) usable = err_idx + (err_kind == 5 ? 1 : 0);
     // longest read and read groups among the usable reads only
     uint32_t S = 0;
-    std::vector<std::string> seen;
+    std::vector<std::string> seen = infer_rg ? prior : std::vector<std::string>();
     for (const auto& c : ch) {
         if (c.lo >= usable) break;
         if (c.hi <= usable) {
@@ -488,7 +491,7 @@ int kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t* i
             if (infer_rg) { std::vector<std::string> part; rgs_of(c.lo, usable, part, nullptr, nullptr); add_rgs(seen, part); }
         }
     }
-    const int R = usable > 0 ? (infer_rg ? (int)seen.size() : 1) : 0;
+    const int R = (usable > 0 || !prior.empty()) ? (infer_rg ? (int)seen.size() : 1) : 0;
     if (R > 32767) return kbbq_set_error_(KBBQ_E_ARG, "more than 32767 read groups: the sidecar word holds 15 bits of read-group id");
     info[0] = usable; info[1] = S; info[2] = R; info[3] = err_kind; info[4] = err_idx;
     return KBBQ_OK;

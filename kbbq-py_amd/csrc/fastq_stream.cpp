@@ -1,0 +1,251 @@
+// fastq_stream.cpp -- a FASTQ file read SEQUENTIALLY, segment by segment (no GPU code).
+//
+// The reference walks its two input files read by read in constant memory (recalibrate.py:56-57 zip(FastxFile, FastxFile),
+// :141-156), so it takes inputs of any size and inputs that cannot be mapped or sought -- `-f <(zcat a.fq.gz) <(zcat b.fq.gz)`.
+// The mapped reader of fastq_host.cpp indexes a whole file (or a rank's byte range of it).  This reader hands out SEGMENTS: a
+// few hundred MB of whole records at a time, each an ordinary kbbq_fastq over memory of its own, indexed by the same code
+// (kbbq_fastq_index_range_), so that scan / fill / format work on it unchanged; what the reference's walk carries from read to
+// read -- read groups met so far, the longest read so far, the record number -- the caller carries from segment to segment
+// (kbbq_fastq_scan_next).  File A leads (segments of about max_bytes), file B follows with the same NUMBER of records per
+// segment; a shorter file B ends pass 1 where zip() would.  Pass 2 needs file A a second time: a regular file is
+// simply read again, a pipe is copied to a spool file as it is read (kbbq_fastq_stream_tee) and pass 2 reads the spool.
+#include "../../include/kbbq_hip.h"
+#include "fastq_host.h"
+#include "host_threads.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+int kbbq_set_error_(int code, const char* msg);      // defined in kbbq_hip.hip
+
+struct kbbq_fastq_stream {
+    int fd = -1; bool own_fd = false;
+    bool regular = false; int64_t size = -1;          // regular files: size known, positioned parallel reads
+    int64_t pos = 0;                                   // bytes consumed from the descriptor
+    bool eof = false;
+    raw_vector<uint8_t> carry;                         // read but not handed out yet (a partial record; records beyond a follower's count)
+    int tee_fd = -1;                                   // every byte handed out is also written here (the spool of a pipe)
+    int64_t records = 0, bytes = 0;                    // handed out so far
+    std::string path;
+    ~kbbq_fastq_stream() { if (own_fd && fd >= 0) close(fd); }
+};
+
+namespace {
+
+template <typename F> void over_threads(size_t n, unsigned nt, F f)
+{
+    if (nt <= 1 || n < ((size_t)1 << 20)) { f(0u, (size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
+        th.emplace_back([=]() { f(t, lo, hi); });
+    }
+    for (auto& t : th) t.join();
+}
+
+size_t count_newlines(const uint8_t* p, size_t n)
+{
+    size_t c = 0;
+    for (size_t i = 0; i < n; ++i) c += (p[i] == '\n');          // vectorised by the compiler
+    return c;
+}
+
+// number of '\n' in buf[0, n), per-thread counts in `parts` (for kth_newline)
+size_t count_lines(const uint8_t* buf, size_t n, std::vector<size_t>& parts, std::vector<size_t>& starts)
+{
+    const unsigned nt = kbbq_threads_for(n);
+    parts.assign(nt, 0); starts.assign(nt + 1, n);
+    over_threads(n, nt, [&](unsigned t, size_t lo, size_t hi) { parts[t] = count_newlines(buf + lo, hi - lo); starts[t] = lo; });
+    if (nt <= 1 || n < ((size_t)1 << 20)) { starts[0] = 0; for (unsigned t = 1; t <= nt; ++t) starts[t] = n; }
+    size_t total = 0;
+    for (size_t c : parts) total += c;
+    return total;
+}
+
+// offset just behind the k-th '\n' (k >= 1, k <= the number counted) of buf
+size_t behind_kth_newline(const uint8_t* buf, size_t n, size_t k, const std::vector<size_t>& parts, const std::vector<size_t>& starts)
+{
+    size_t before = 0;
+    for (size_t t = 0; t < parts.size(); ++t) {
+        if (before + parts[t] >= k) {
+            const uint8_t* p = buf + starts[t]; const uint8_t* e = buf + (t + 1 < starts.size() ? std::max(starts[t + 1], starts[t]) : n);
+            if (t + 1 == parts.size()) e = buf + n;
+            size_t need = k - before;
+            while (p < e) {
+                const uint8_t* q = (const uint8_t*)memchr(p, '\n', (size_t)(e - p));
+                if (!q) break;
+                if (--need == 0) return (size_t)(q - buf) + 1;
+                p = q + 1;
+            }
+            return n;                                            // cannot happen: the counts said it is here
+        }
+        before += parts[t];
+    }
+    return n;
+}
+
+// read up to `want` bytes at the stream's position into dst; returns the bytes read (< want only at the end of the input)
+int64_t read_some(kbbq_fastq_stream* s, uint8_t* dst, size_t want)
+{
+    if (s->eof || want == 0) return 0;
+    if (s->regular) {
+        const size_t have = (size_t)std::max<int64_t>(0, s->size - s->pos);
+        const size_t take = std::min(want, have);
+        std::atomic<int> bad(0);
+        const int64_t base = s->pos;
+        over_threads(take, kbbq_threads_for(take / 4), [&](unsigned, size_t lo, size_t hi) {
+            size_t at = lo;
+            while (at < hi) {
+                const ssize_t k = pread(s->fd, dst + at, hi - at, (off_t)(base + (int64_t)at));
+                if (k < 0 && errno == EINTR) continue;
+                if (k <= 0) { bad = 1; return; }
+                at += (size_t)k;
+            }
+        });
+        if (bad.load()) return -1;
+        s->pos += (int64_t)take;
+        if (s->pos >= s->size) s->eof = true;
+        return (int64_t)take;
+    }
+    size_t got = 0;
+    while (got < want) {
+        const ssize_t k = read(s->fd, dst + got, want - got);
+        if (k < 0 && errno == EINTR) continue;
+        if (k < 0) return -1;
+        if (k == 0) { s->eof = true; break; }
+        got += (size_t)k;
+    }
+    s->pos += (int64_t)got;
+    return (int64_t)got;
+}
+
+bool write_all(int fd, const uint8_t* p, size_t n)
+{
+    while (n) {
+        const ssize_t k = write(fd, p, n);
+        if (k < 0 && errno == EINTR) continue;
+        if (k <= 0) return false;
+        p += k; n -= (size_t)k;
+    }
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+// path: a regular file, a named pipe / process substitution (/dev/fd/N), a character device, or "-" for standard input
+int kbbq_fastq_stream_open(const char* path, kbbq_fastq_stream** out)
+{
+    if (!path || !out) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_stream_open: NULL argument");
+    *out = nullptr;
+    kbbq_fastq_stream* s = new kbbq_fastq_stream();
+    s->path = path;
+    if (!strcmp(path, "-")) s->fd = 0;
+    else { s->fd = open(path, O_RDONLY); s->own_fd = true; }
+    if (s->fd < 0) { delete s; return kbbq_set_error_(KBBQ_E_ARG, (std::string("cannot open ") + path).c_str()); }
+    struct stat st;
+    if (fstat(s->fd, &st) != 0) { delete s; return kbbq_set_error_(KBBQ_E_ARG, "fstat failed"); }
+    s->regular = S_ISREG(st.st_mode);
+    if (s->regular) { s->size = (int64_t)st.st_size; s->eof = s->size == 0; }
+#ifdef F_SETPIPE_SZ
+    else if (S_ISFIFO(st.st_mode)) (void)fcntl(s->fd, F_SETPIPE_SZ, 1 << 20);      // 64 KB by default: fewer wake-ups per GB
+#endif
+    *out = s;
+    return KBBQ_OK;
+}
+
+int kbbq_fastq_stream_is_regular(const kbbq_fastq_stream* s) { return s && s->regular ? 1 : 0; }
+
+// every byte handed out from now on is appended to `fd` (the caller's spool file; not closed here); -1 stops it
+int kbbq_fastq_stream_tee(kbbq_fastq_stream* s, int fd)
+{
+    if (!s) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_stream_tee: NULL stream");
+    s->tee_fd = fd;
+    return KBBQ_OK;
+}
+
+// The next segment: whole records only.
+//   records == 0  (the leading file): about max_bytes of text (at least one record, however long);
+//   records  > 0  (the following file): exactly that many records, fewer only when the input ends first.
+// *segment: a reader over memory of its own (close it with kbbq_fastq_close), NULL when the input has ended and nothing is
+// left; *at_end: 1 when the input has ended behind this segment.  Gzip-compressed bytes are refused (pipe them through zcat).
+int kbbq_fastq_stream_next(kbbq_fastq_stream* s, size_t max_bytes, int64_t records, kbbq_fastq** segment, int* at_end)
+{
+    if (!s || !segment || records < 0) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_stream_next: bad argument");
+    *segment = nullptr;
+    if (at_end) *at_end = 0;
+    max_bytes = std::max<size_t>(max_bytes, 1 << 16);
+    kbbq_fastq* f = new kbbq_fastq();
+    raw_vector<uint8_t>& buf = f->text;
+    size_t have = s->carry.size();
+    size_t cap = std::max(max_bytes, have) + (1 << 16);
+    buf.resize(cap);
+    if (have) memcpy(buf.data(), s->carry.data(), have);
+    s->carry.clear();
+    const size_t target = (size_t)records * 4;
+    size_t cut = 0;
+    std::vector<size_t> parts, starts;
+    auto behind = [&](size_t lines, size_t nlines) {                            // offset behind `lines` whole lines
+        return lines == 0 ? (size_t)0 : (lines <= nlines ? behind_kth_newline(buf.data(), have, lines, parts, starts) : have);
+    };
+    for (;;) {
+        if (!s->eof && have < cap) {
+            const int64_t got = read_some(s, buf.data() + have, cap - have);
+            if (got < 0) { delete f; return kbbq_set_error_(KBBQ_E_ARG, (s->path + ": read failed").c_str()); }
+            have += (size_t)got;
+        }
+        if (s->bytes == 0 && have >= 2 && buf[0] == 0x1f && buf[1] == 0x8b) {
+            delete f;
+            return kbbq_set_error_(KBBQ_E_ARG, (s->path + ": gzip-compressed bytes in a sequentially read input -- decompress them in the pipe, e.g. <(zcat file.fq.gz)").c_str());
+        }
+        const size_t nlines = count_lines(buf.data(), have, parts, starts);
+        // at the end of the input the last line needs no line end (as in the mapped reader)
+        const size_t whole = nlines + ((s->eof && have > 0 && buf[have - 1] != '\n') ? 1 : 0);
+        if (target && whole >= target) { cut = behind(target, nlines); break; }               // the follower's count is there
+        if (s->eof) {
+            // whatever is there: whole records only, and nothing may be left behind them (the mapped reader refuses such a file too)
+            if (whole & 3) { delete f; return kbbq_set_error_(KBBQ_E_ARG, (s->path + ": not a 4-line-per-record FASTQ file").c_str()); }
+            cut = have;
+            break;
+        }
+        if (!target && have >= max_bytes && nlines >= 4) { cut = behind(nlines & ~(size_t)3, nlines); break; }
+        cap = have + std::max<size_t>(have / 4, 1 << 20);                      // not enough yet (a follower's longer records, one huge record): read more
+        buf.resize(cap);
+    }
+    if (cut < have) { s->carry.resize(have - cut); memcpy(s->carry.data(), buf.data() + cut, have - cut); }
+    if (at_end) *at_end = (s->eof && s->carry.empty()) ? 1 : 0;
+    if (cut == 0) { delete f; return KBBQ_OK; }                                // the input has ended: no segment
+    buf.resize(cut);
+    f->buf = buf.data(); f->size = cut; f->mapped = false;
+    const int bad = kbbq_fastq_index_range_(f, 0, cut);
+    if (bad) {
+        delete f;
+        return kbbq_set_error_(KBBQ_E_ARG, bad == 4 ? (s->path + ": not a 4-line-per-record FASTQ file").c_str()
+                                          : bad == 1 ? "record header does not start with @"
+                                          : bad == 2 ? "sequence and quality lengths differ" : "read longer than 65535 bases");
+    }
+    if (s->tee_fd >= 0 && !write_all(s->tee_fd, buf.data(), cut)) {
+        delete f;
+        return kbbq_set_error_(KBBQ_E_ARG, (s->path + ": writing the spool file failed (KBBQ_SPOOL_DIR selects another directory)").c_str());
+    }
+    s->records += (int64_t)f->h0.size(); s->bytes += (int64_t)cut;
+    *segment = f;
+    return KBBQ_OK;
+}
+
+int kbbq_fastq_stream_close(kbbq_fastq_stream* s) { delete s; return KBBQ_OK; }
+
+} // extern "C"

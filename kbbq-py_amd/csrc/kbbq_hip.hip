@@ -294,6 +294,17 @@ int kbbq_dev_download(kbbq_ctx* c, void* dst, const void* src, size_t bytes)
     return KBBQ_OK;
 }
 
+int kbbq_dev_mem_info(kbbq_ctx* c, size_t* free_bytes, size_t* total_bytes)
+{
+    if (!c) return fail(KBBQ_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return KBBQ_OK;
+}
+
 int kbbq_host_alloc(size_t bytes, void** hptr)
 {
     if (!hptr) return fail(KBBQ_E_ARG, "kbbq_host_alloc: NULL argument");

@@ -50,6 +50,7 @@ PROTOTYPES = {
     'kbbq_dev_zero': (_i, [_vp, _vp, _sz]),
     'kbbq_dev_upload': (_i, [_vp, _vp, _vp, _sz]),
     'kbbq_dev_download': (_i, [_vp, _vp, _vp, _sz]),
+    'kbbq_dev_mem_info': (_i, [_vp, _c.POINTER(_sz), _c.POINTER(_sz)]),
     'kbbq_host_alloc': (_i, [_sz, _c.POINTER(_vp)]),
     'kbbq_host_free': (_i, [_vp]),
     'kbbq_dev_copy_async': (_i, [_vp, _vp, _vp, _sz, _i]),
@@ -133,6 +134,12 @@ PROTOTYPES = {
     'kbbq_fastq_rg_count': (_i, [_vp]),
     'kbbq_fastq_rg_name': (_c.c_char_p, [_vp, _i]),
     'kbbq_fastq_scan': (_i, [_vp, _vp, _i, _vp]),
+    'kbbq_fastq_scan_next': (_i, [_vp, _vp, _i, _i64, _vp]),
+    'kbbq_fastq_stream_open': (_i, [_c.c_char_p, _c.POINTER(_vp)]),
+    'kbbq_fastq_stream_is_regular': (_i, [_vp]),
+    'kbbq_fastq_stream_tee': (_i, [_vp, _i]),
+    'kbbq_fastq_stream_next': (_i, [_vp, _sz, _i64, _c.POINTER(_vp), _c.POINTER(_i)]),
+    'kbbq_fastq_stream_close': (_i, [_vp]),
     'kbbq_fastq_pair_begin': (_i, [_c.c_char_p, _c.c_char_p, _i, _c.POINTER(_vp)]),
     'kbbq_fastq_pair_wait': (_i, [_vp, _c.POINTER(_vp), _c.POINTER(_vp), _vp]),
     'kbbq_fastq_lengths': (_i, [_vp, _i64, _i64, _vp]),

@@ -300,6 +300,16 @@ class NativeFastq:
         lib = _N.load()
         return [lib.kbbq_fastq_rg_name(self._h, i).decode('ascii') for i in range(lib.kbbq_fastq_rg_count(self._h))]
 
+    def scan_next(self, other, infer_rg_flag, rg_names, prior_longest):
+        """scan() of one segment of a sequentially read input: `rg_names` are the read groups of the segments before it
+        (new ones are appended: rg_names() afterwards), prior_longest their longest read (kbbq_fastq_scan_next)."""
+        blob = b''.join(str(x).encode('ascii') + b'\0' for x in rg_names)
+        _N.check(_N.load().kbbq_fastq_set_rg_names(self._h, blob, len(rg_names)))
+        info = np.zeros(5, dtype=np.int64)
+        _N.check(_N.load().kbbq_fastq_scan_next(self._h, other._h if other is not None else None, 1 if infer_rg_flag else 0,
+                                                int(prior_longest), _N.ptr(info)))
+        return [int(x) for x in info]
+
     def scan(self, other, infer_rg_flag):
         info = np.zeros(5, dtype=np.int64)
         _N.check(_N.load().kbbq_fastq_scan(self._h, other._h if other is not None else None,
@@ -401,6 +411,55 @@ class NativeFastq:
     def format(self, first, n, newqual):
         """The same as bytes."""
         return self.format_array(first, n, newqual).tobytes()
+
+
+class FastqStream:
+    """A FASTQ input read sequentially, segment by segment (kbbq_fastq_stream_*: csrc/fastq_stream.cpp) -- a regular file, a
+    named pipe / process substitution, or '-' for standard input.  next() returns (NativeFastq over the segment's own
+    memory or None at the end, at_end); the segment's `first` / `total` number its records file-wide as far as known."""
+
+    def __init__(self, path):
+        self._h = _ct.c_void_p()
+        self.path = str(path)
+        _N.check(_N.load().kbbq_fastq_stream_open(self.path.encode(), _ct.byref(self._h)))
+        self.regular = bool(_N.load().kbbq_fastq_stream_is_regular(self._h))
+        self.records = 0                     # handed out so far
+
+    def tee(self, fd):
+        _N.check(_N.load().kbbq_fastq_stream_tee(self._h, int(fd)))
+
+    def next(self, max_bytes, records=0):
+        seg, end = _ct.c_void_p(), _ct.c_int(0)
+        _N.check(_N.load().kbbq_fastq_stream_next(self._h, int(max_bytes), int(records), _ct.byref(seg), _ct.byref(end)))
+        if not seg.value:
+            return None, True
+        f = NativeFastq(None, _handle=seg)
+        f.first, f.total = self.records, self.records + f.n
+        self.records += f.n
+        return f, bool(end.value)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            _N.load().kbbq_fastq_stream_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def is_sequential_input(path):
+    """True for an input that cannot be mapped and indexed as a whole: standard input, a pipe, a character device."""
+    import os
+    import stat
+    if str(path) == '-':
+        return True
+    try:
+        return not stat.S_ISREG(os.stat(str(path)).st_mode)
+    except OSError:
+        return False
 
 
 _SCAN_ERRORS = {

@@ -4,7 +4,7 @@
 # timed-out step ends the job: no further GPU step is started after a kill).
 #   tests[=EXPR]      pytest -m gpu (optionally -k EXPR)
 #   file=PATH[::K]    pytest -m gpu of one test file (optionally -k K)
-#   ranks             the 5-rank rehearsals (tests/test_gpu_ranks.py)
+#   ranks             the 4-rank rehearsals (tests/test_gpu_ranks.py)
 #   bench[=ARGS]      python bench.py (default: the driver's form, --steps 20 --warmup 5)
 #   benchq            python bench.py --no-extra --cpu-sample 0 --steps 10 --warmup 3
 #   hostentry         scripts/time_host_entry.py (kbbq_accumulate / kbbq_apply on host buffers, PCIe included)
@@ -34,8 +34,9 @@ for step in "$@"; do
     bench)     run bench 900 python bench.py ${arg:---steps 20 --warmup 5}; grep '^{' gpurun_out/bench_$TAG.log | tail -1 > gpurun_out/bench_$TAG.json ;;
     benchq)    run benchq 600 python bench.py --no-extra --cpu-sample 0 --steps 10 --warmup 3; grep '^{' gpurun_out/benchq_$TAG.log | tail -1 > gpurun_out/benchq_$TAG.json ;;
     hostentry) run hostentry 400 python scripts/time_host_entry.py ;;
-    e2e)       run e2e 600 python tests/tools/e2e_cli.py ${arg:-8000000} ;;
-    fuzz)      run fuzz_kernels $((arg + 120)) python tests/tools/fuzz_gpu.py $arg && run fuzz_aligned $((arg + 120)) python tests/tools/fuzz_gpu_aligned.py $arg && run fuzz_cli $((arg + 120)) python tests/tools/fuzz_gpu_cli.py $arg ;;
+    e2e)       run e2e 600 python tests/tools/e2e_cli.py --reads ${arg:-8000000} ;;
+    fuzz)      seed=$(( $(date +%s) % 100000 ))
+               run fuzz_kernels $((arg + 240)) python tests/tools/fuzz_gpu.py --seconds $arg --seed $seed && run fuzz_aligned $((arg + 240)) python tests/tools/fuzz_gpu_aligned.py --seconds $arg --seed $seed && run fuzz_cli $((arg + 240)) python tests/tools/fuzz_gpu_cli.py --seconds $arg --seed $seed ;;
     py)        s=${arg%%::*}; a=""; [[ "$arg" == *::* ]] && a=${arg#*::}
                run py_$(basename $s .py) 900 python $s $a ;;
     prof)      n=${arg%%::*}; c=${arg#*::}
