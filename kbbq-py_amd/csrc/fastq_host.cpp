@@ -57,13 +57,7 @@ static void newline_offsets(const uint8_t* buf, size_t lo, size_t hi, raw_vector
 template <typename F> static void parallel_for(int64_t n, unsigned nt, F f)
 {
     if (nt <= 1 || n < 4096) { f(0, n); return; }
-    std::vector<std::thread> th;
-    const int64_t per = (n + nt - 1) / nt;
-    for (unsigned t = 0; t < nt; ++t) {
-        const int64_t lo = std::min<int64_t>(n, t * per), hi = std::min<int64_t>(n, lo + per);
-        if (lo < hi) th.emplace_back([=]() { f(lo, hi); });
-    }
-    for (auto& t : th) t.join();
+    kbbq_parallel_parts((size_t)n, nt, [&](unsigned, size_t lo, size_t hi) { f((int64_t)lo, (int64_t)hi); });     // parked workers (host_threads.h)
 }
 
 int kbbq_fastq_index_range_(kbbq_fastq* f, size_t r0, size_t r1)
@@ -75,18 +69,12 @@ int kbbq_fastq_index_range_(kbbq_fastq* f, size_t r0, size_t r1)
     const unsigned nt = nthreads_for(r1 - r0);
     std::vector<raw_vector<uint64_t>> parts(nt);
     const size_t per = (r1 - r0 + nt - 1) / nt;
-    {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t) {
-            const size_t lo = std::min(r1, r0 + t * per), hi = std::min(r1, lo + per);
-            th.emplace_back([f, lo, hi, &parts, t]() {
-                auto& v = parts[t];
-                v.reserve((hi - lo) / 64 + 16);
-                newline_offsets(f->buf, lo, hi, v);
-            });
-        }
-        for (auto& t : th) t.join();
-    }
+    kbbq_parallel(nt, [&](unsigned t) {
+        const size_t lo = std::min(r1, r0 + t * per), hi = std::min(r1, lo + per);
+        auto& v = parts[t];
+        v.reserve((hi - lo) / 64 + 16);
+        newline_offsets(f->buf, lo, hi, v);
+    });
     if (r1 == f->size && r1 > r0 && f->buf[f->size - 1] != '\n') parts[nt - 1].push_back(f->size);   // last line without '\n'
     std::vector<uint64_t> base(nt + 1, 0), before(nt, 0);      // first line number of a part; line end before its first
     {
@@ -105,10 +93,9 @@ int kbbq_fastq_index_range_(kbbq_fastq* f, size_t r0, size_t r1)
     raw_vector<uint32_t> qlen((size_t)n);
     std::atomic<int> bad(0);
     {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t) {
-            if (parts[t].empty()) continue;
-            th.emplace_back([f, t, &parts, &base, &before, &qlen, &bad]() {
+        kbbq_parallel(nt, [&](unsigned t) {
+            {
+                if (parts[t].empty()) return;
                 const auto& v = parts[t];
                 uint64_t start = before[t] + 1;                  // (uint64_t)-1 + 1 == 0 for the file's first line
                 for (size_t j = 0; j < v.size(); ++j) {
@@ -133,9 +120,8 @@ int kbbq_fastq_index_range_(kbbq_fastq* f, size_t r0, size_t r1)
                     }
                     start = v[j] + 1;
                 }
-            });
-        }
-        for (auto& t : th) t.join();
+            }
+        });
     }
     if (!bad.load())
         parallel_for(n, nt, [&](int64_t lo, int64_t hi) {
@@ -418,9 +404,7 @@ static int scan_impl(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, bool keep
         std::atomic<int64_t> next(0);
         auto run = [&]() { for (int64_t c; (c = next.fetch_add(1)) < nchunks;) body(ch[(size_t)c]); };
         if (nt <= 1) { run(); return; }
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t) th.emplace_back(run);
-        for (auto& t : th) t.join();
+        kbbq_parallel(nt, [&](unsigned) { run(); });
     };
     auto rgs_of = [&](int64_t lo, int64_t hi, std::vector<std::string>& out, int64_t* err, int* kind) {
         const char* last = nullptr; int lastlen = -1;          // consecutive reads mostly share a read group
@@ -726,12 +710,10 @@ int kbbq_group_rows_host(const uint32_t* meta, int64_t nrows, int pairs, int R, 
     std::atomic<int> bad(0);
     auto key = [&](int64_t i) { return (int)((meta[pairs ? 2 * i : i] >> 16) & 0x7FFFu); };
     auto over = [&](auto body) {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t) {
+        kbbq_parallel(nt, [&](unsigned t) {
             const int64_t lo = std::min<int64_t>(nrows, (int64_t)t * per), hi = std::min<int64_t>(nrows, lo + per);
-            if (nt == 1) body(t, lo, hi); else th.emplace_back([=]() { body(t, lo, hi); });
-        }
-        for (auto& t : th) t.join();
+            body(t, lo, hi);
+        });
     };
     over([&](unsigned t, int64_t lo, int64_t hi) {
         auto& c = cnt[t];

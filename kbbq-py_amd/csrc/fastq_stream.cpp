@@ -46,13 +46,11 @@ namespace {
 template <typename F> void over_threads(size_t n, unsigned nt, F f)
 {
     if (nt <= 1 || n < ((size_t)1 << 20)) { f(0u, (size_t)0, n); return; }
-    std::vector<std::thread> th;
     const size_t per = (n + nt - 1) / nt;
-    for (unsigned t = 0; t < nt; ++t) {
+    kbbq_parallel(nt, [&](unsigned t) {
         const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
-        th.emplace_back([=]() { f(t, lo, hi); });
-    }
-    for (auto& t : th) t.join();
+        f(t, lo, hi);
+    });
 }
 
 size_t count_newlines(const uint8_t* p, size_t n)

@@ -1922,13 +1922,11 @@ static void threaded_copy(void* dst, const void* src, size_t bytes)
 {
     const unsigned nt = kbbq_threads_for(bytes / 4);
     if (nt <= 1 || bytes < ((size_t)4 << 20)) { memcpy(dst, src, bytes); return; }
-    std::vector<std::thread> th;
     const size_t per = ((bytes + nt - 1) / nt + 4095) & ~(size_t)4095;
-    for (unsigned t = 0; t < nt; ++t) {
+    kbbq_parallel(nt, [&](unsigned t) {
         const size_t lo = std::min(bytes, (size_t)t * per), hi = std::min(bytes, lo + per);
-        if (lo < hi) th.emplace_back([=]() { memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
-    }
-    for (auto& t : th) t.join();
+        if (lo < hi) memcpy((char*)dst + lo, (const char*)src + lo, hi - lo);
+    });
 }
 
 // Every exit of a pipelined run that leaves before its last slab -- a launch or a copy failed -- waits for what is still in

@@ -46,6 +46,37 @@ def _torch():
     return _backend
 
 
+def parse_bytes(text):
+    """'256M', '1.5G', '64k', '1000000' -> bytes."""
+    t = str(text).strip()
+    mult = {'k': 1 << 10, 'm': 1 << 20, 'g': 1 << 30, 't': 1 << 40}.get(t[-1:].lower())
+    if t[-2:].lower() in ('kb', 'mb', 'gb', 'tb'):
+        t, mult = t[:-1], {'k': 1 << 10, 'm': 1 << 20, 'g': 1 << 30, 't': 1 << 40}[t[-2].lower()]
+    return int(float(t[:-1]) * mult) if mult else int(float(t))
+
+
+def device_budget():
+    """Device memory the file path may hold for reads at any one time: KBBQ_DEVICE_BUDGET (bytes, or with a K / M / G
+    suffix), else 60 % of what is free on the device now.  A shard whose resident form needs more is streamed
+    (kbbq/_stream.py): slabs of rows sized to this budget go through K1 (pass 1) and K2 (pass 2) and are dropped."""
+    env = os.environ.get('KBBQ_DEVICE_BUDGET')
+    if env:
+        return max(parse_bytes(env), 1 << 20)
+    torch = _torch()
+    free, _ = torch.cuda.mem_get_info()
+    return int(free * 0.6)
+
+
+def memory_peak(reset=False):
+    """Largest number of bytes of device memory in use by tensors since the last reset (torch's allocator, or
+    kbbq/_hipmem.py's accounting of kbbq_dev_alloc)."""
+    torch = _torch()
+    if reset:
+        torch.cuda.reset_peak_memory_stats()
+        return 0
+    return int(torch.cuda.max_memory_allocated())
+
+
 def synchronize():
     """Wait for everything enqueued on the current device (stage timing)."""
     if _backend is not None:
@@ -140,6 +171,7 @@ class Tables:
 
 
 _pinned = {}
+_pinned_lock = __import__('threading').RLock()      # the streaming path's producer and the egress pipeline's copy stage both ask for buffers
 
 
 def pinned(tag, index, nbytes):
@@ -148,15 +180,16 @@ def pinned(tag, index, nbytes):
     are allocated once and shared by index; `tag` separates users whose buffers are in use at the same time."""
     torch = _torch()
     key = (tag, index)
-    buf = _pinned.get(key)
-    if buf is None or buf.shape[0] < nbytes:
-        for other, cand in list(_pinned.items()):                # a free buffer of another tag that is large enough
-            if other[0] == '' and cand.shape[0] >= nbytes:
-                buf = _pinned.pop(other)
-                break
-        else:
-            buf = torch.empty(int(nbytes), dtype=torch.uint8, pin_memory=True)
-        _pinned[key] = buf
+    with _pinned_lock:
+        buf = _pinned.get(key)
+        if buf is None or buf.shape[0] < nbytes:
+            for other, cand in list(_pinned.items()):                # a free buffer of another tag that is large enough
+                if other[0] == '' and cand.shape[0] >= nbytes:
+                    buf = _pinned.pop(other)
+                    break
+            else:
+                buf = torch.empty(int(nbytes), dtype=torch.uint8, pin_memory=True)
+            _pinned[key] = buf
     return buf
 
 
@@ -165,9 +198,10 @@ _released = [0]
 
 def release_pinned(tag):
     """The buffers of `tag` become available to other users (kept allocated)."""
-    for key in [k for k in _pinned if k[0] == tag]:
-        _released[0] += 1
-        _pinned[('', _released[0])] = _pinned.pop(key)
+    with _pinned_lock:
+        for key in [k for k in _pinned if k[0] == tag]:
+            _released[0] += 1
+            _pinned[('', _released[0])] = _pinned.pop(key)
 
 
 class ReadBatch:
@@ -213,7 +247,7 @@ class ReadBatch:
         return b
 
     @classmethod
-    def from_reader(cls, text, other, infer_rg_flag, first, n, pitch, slab=1 << 17, device=None):
+    def from_reader(cls, text, other, infer_rg_flag, first, n, pitch, slab=1 << 17, device=None, keep_pinned=False):
         """Reads [first, first + n) of a fastx.NativeFastq (and their corrections from `other`, or None) straight onto
         the device: the C++ packer fills page-locked slabs (all host threads) while the copy engine uploads the
         previous ones -- no host copy of the planes is ever materialised."""
@@ -243,7 +277,8 @@ class ReadBatch:
                 events[slot].record()
             for e in events.values():
                 e.synchronize()
-        release_pinned('ingest')
+        if not keep_pinned:                  # (the streaming path fills slab after slab: it releases them once, at the end)
+            release_pinned('ingest')
         b.h2d_bytes = n * (planes * pitch + 4)
         return b
 
@@ -467,7 +502,8 @@ def lay_out(batch, R, S=None, packed=True, pairs=None, stats=None):
     return laid
 
 
-def laid_from_reader(text, other, infer_rg_flag, first, n, pitch, R, packed=True, pairs=None, slab=1 << 17, device=None):
+def laid_from_reader(text, other, infer_rg_flag, first, n, pitch, R, packed=True, pairs=None, slab=1 << 17, device=None, pair_S=None,
+                     keep_pinned=False):
     """Reads [first, first + n) of a fastx.NativeFastq (and their corrections from `other`, or None) onto the device IN
     THE LAYOUT lay_out() would give them -- written by the C++ packer itself (kbbq_fastq_fill_rows): mate-pair rows, 4-bit
     sequence planes, rows gathered by read-group segment, decided from the sidecar statistics of the text (kbbq_fastq_meta)
@@ -480,6 +516,8 @@ def laid_from_reader(text, other, infer_rg_flag, first, n, pitch, R, packed=True
         return None
     meta, st = text.meta(infer_rg_flag, first, n)
     S_ = st['longest']
+    if pair_S is not None and S_ != pair_S and pairs is None:
+        pairs = False                        # two reads to a row need count tables / a LUT of exactly 2 x THESE reads' length (a slab of a band)
     flags = layout_flags(st, n, pitch, packed, pairs)
     two = bool(flags & N.ROWS_PAIRS)
     nrows = (n + 1) // 2 if two else n
@@ -534,7 +572,8 @@ def laid_from_reader(text, other, infer_rg_flag, first, n, pitch, R, packed=True
                 events[slot].record()
             for e in events.values():
                 e.synchronize()
-        release_pinned('ingest')
+        if not keep_pinned:
+            release_pinned('ingest')
         if not foreign:
             break
         flags &= ~N.ROWS_NIBBLES                                  # a base outside ACGTN: character planes keep the exact semantics

@@ -77,11 +77,12 @@ class Slots:
         return b
 
 
-def _slabs(bands, outs, step):
+def _slabs(produced, step):
     """(serial number, band, its device plane of new qualities, first read, reads) for slabs of `step` reads (even, so
-    that a slab of mate-pair rows starts at a first mate)."""
+    that a slab of mate-pair rows starts at a first mate).  produced: (band, plane) pairs -- a list, or a generator that
+    makes the planes as it is asked for them (the streaming file path: kbbq/_stream.py)."""
     k = 0
-    for band, out in zip(bands, outs):
+    for band, out in produced:
         for first in range(0, band['n'], step):
             yield k, band, out, first, min(step, band['n'] - first)
             k += 1
@@ -101,19 +102,26 @@ def emit_records(text, base, bands, outs, slab=1 << 18, sink=None):
     they are, kbbq_fastq_format_rows) -- to sys.stdout, rendered by the C++ writer in slabs.  A binary stdout gets the
     bytes through the three-stage pipeline above (copy off the device into page-locked buffers | rendering into re-used
     buffers | write(2)); a text-only stdout (StringIO) gets print(), like the reference."""
+    emit_produced(text, base, zip(bands, outs), max([band['pitch'] for band in bands] + [16]), slab, sink)
+
+
+def emit_produced(text, base, produced, widest, slab=1 << 18, sink=None):
+    """emit_records for (band, plane) pairs that are PRODUCED while the earlier ones are being copied, rendered and written
+    (a generator: it runs on the pipeline's feeding thread): the streaming file path's pass 2, fill | H2D | K2 | D2H |
+    format | write.  A band may carry its own reader (band['text']: a segment of a sequentially read input) and its own
+    `base`; widest: the largest row pitch any band will have."""
     sys.stdout.flush()
     raw = sink if sink is not None else getattr(sys.stdout, 'buffer', None)      # sink: a binary file of the caller's
     if raw is None:
-        for _, band, out, first, m in _slabs(bands, outs, 1 << 20):
+        for _, band, out, first, m in _slabs(produced, 1 << 20):
             r0, r1 = _rows_of(band, first, m)
             newq = out[r0:r1].cpu().numpy()
-            print(text.format_rows_array(base + band['first'] + first, m, newq, band.get('out_flags', 0),
-                                         band.get('out_S2', 0)).tobytes().decode('latin-1'), end='')
+            print(band.get('text', text).format_rows_array(band.get('base', base) + band['first'] + first, m, newq, band.get('out_flags', 0),
+                                                           band.get('out_S2', 0)).tobytes().decode('latin-1'), end='')
         sys.stdout.flush()
         return
     from . import _device as dev
     torch = dev._torch()
-    widest = max([band['pitch'] for band in bands] + [16])
     made = [0]
 
     def page_locked(nbytes):
@@ -129,20 +137,23 @@ def emit_records(text, base, bands, outs, slab=1 << 18, sink=None):
         with stage('D2H'), torch.cuda.device(out.device):           # a new thread starts on device 0
             host = staging.get(k, (r1 - r0) * width)[:(r1 - r0) * width].view(r1 - r0, width)
             host.copy_(out[r0:r1], non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-        return k, base + band['first'] + first, m, host.numpy(), band.get('out_flags', 0), band.get('out_S2', 0)
+            done = torch.cuda.Event()                                # this copy only: the producer may have enqueued the next
+            done.record()                                            # slab's uploads and kernels behind it meanwhile
+            done.synchronize()
+        return (k, band.get('text', text), band.get('base', base) + band['first'] + first, m, host.numpy(), band.get('out_flags', 0),
+                band.get('out_S2', 0))
 
     def render(item):
-        k, first, m, newq, flags, S2 = item
+        k, reader, first, m, newq, flags, S2 = item
         with stage('format'):
-            return text.format_rows_array(first, m, newq, flags, S2, out=lambda nbytes: rendered.get(k, nbytes))
+            return reader.format_rows_array(first, m, newq, flags, S2, out=lambda nbytes: rendered.get(k, nbytes))
 
     def write(buf):
         with stage('write'):
             raw.write(memoryview(buf))
 
     try:
-        pipeline(_slabs(bands, outs, slab), fetch, render, write)
+        pipeline(_slabs(produced, slab), fetch, render, write)
     finally:
         dev.release_pinned('egress')
     raw.flush()

@@ -75,20 +75,79 @@ def _ctx(index):
     return _device.context(index)
 
 
+class _Pool:
+    """Accounting of the device memory this module holds, and -- once a reserve limit is set (the streaming file path does:
+    kbbq/_stream.py) -- a free list: a released allocation is kept and handed to the next request of about its size instead
+    of going back to the runtime (hipFree waits for the device, hipMalloc of a 100 MB slab takes a fraction of a millisecond:
+    a path that allocates and frees a slab per step pays both per step).  All work of this module is enqueued on ONE
+    stream, so a block released by one step and reused by the next is ordered behind the kernels that still read it."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.live = self.peak = self.reserved = self.peak_reserved = 0
+        self.limit = None                    # bytes this module may hold (live + kept); None: nothing is kept
+        self.kept = []                       # (nbytes, ptr, index)
+
+    def take(self, index, nbytes):
+        nbytes = int(nbytes)
+        with self.lock:
+            best = None
+            for k, (size, ptr, idx) in enumerate(self.kept):
+                if idx == index and nbytes <= size <= nbytes + (nbytes >> 2) + 4096 and (best is None or size < self.kept[best][0]):
+                    best = k
+            if best is not None:
+                size, ptr, _ = self.kept.pop(best)
+                self._count(size, 0)
+                return ptr, size
+            if self.limit is not None and self.kept and self.reserved + nbytes > self.limit:
+                self._release_kept()
+        p = ctypes.c_void_p()
+        N.check(N.load().kbbq_dev_alloc(_ctx(index).handle, nbytes, ctypes.byref(p)))
+        with self.lock:
+            self._count(nbytes, nbytes)
+        return p.value, nbytes
+
+    def give(self, index, ptr, size):
+        with self.lock:
+            self.live -= size
+            if self.limit is not None and size >= (1 << 20) and self.reserved <= self.limit:
+                self.kept.append((size, ptr, index))
+                return
+            self.reserved -= size
+        N.load().kbbq_dev_free(_ctx(index).handle, ctypes.c_void_p(ptr))
+
+    def _count(self, live, reserved):
+        self.live += live
+        self.reserved += reserved
+        self.peak = max(self.peak, self.live)
+        self.peak_reserved = max(self.peak_reserved, self.reserved)
+
+    def _release_kept(self):                 # lock held
+        for size, ptr, idx in self.kept:
+            N.load().kbbq_dev_free(_ctx(idx).handle, ctypes.c_void_p(ptr))
+            self.reserved -= size
+        self.kept = []
+
+    def empty_cache(self):
+        with self.lock:
+            self._release_kept()
+
+
+_pool = _Pool()
+
+
 class _DeviceMemory:
-    """One kbbq_dev_alloc allocation, freed with the last tensor that views it."""
+    """One device allocation (kbbq_dev_alloc, or a kept one of the pool), released with the last tensor that views it."""
 
     def __init__(self, index, nbytes):
         self.index = index
-        p = ctypes.c_void_p()
-        N.check(N.load().kbbq_dev_alloc(_ctx(index).handle, int(nbytes), ctypes.byref(p)))
-        self.ptr = p.value
+        self.ptr, self.size = _pool.take(index, max(int(nbytes), 16))
 
     def __del__(self):
         try:
             if self.ptr:
-                N.load().kbbq_dev_free(_ctx(self.index).handle, ctypes.c_void_p(self.ptr))
-                self.ptr = None
+                ptr, self.ptr = self.ptr, None
+                _pool.give(self.index, ptr, self.size)
         except Exception:                    # interpreter shutdown: the process's memory goes with it
             pass
 
@@ -320,6 +379,42 @@ class _Cuda:
         return n.value
 
     @staticmethod
+    def mem_get_info(index=None):
+        """(free, total) bytes of the device, as torch.cuda.mem_get_info."""
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        N.check(N.load().kbbq_dev_mem_info(_ctx(_current[0] if index is None else getattr(index, 'index', index)).handle,
+                                           ctypes.byref(f), ctypes.byref(t)))
+        return f.value, t.value
+
+    @staticmethod
+    def max_memory_allocated(index=None):
+        return _pool.peak
+
+    @staticmethod
+    def max_memory_reserved(index=None):
+        return _pool.peak_reserved
+
+    @staticmethod
+    def memory_allocated(index=None):
+        return _pool.live
+
+    @staticmethod
+    def reset_peak_memory_stats(index=None):
+        _pool.peak, _pool.peak_reserved = _pool.live, _pool.reserved
+
+    @staticmethod
+    def empty_cache():
+        _pool.empty_cache()
+
+    @staticmethod
+    def set_reserve_limit(nbytes):
+        """From now on released device allocations are kept for reuse while the module holds no more than `nbytes` (None:
+        back to releasing everything at once)."""
+        _pool.limit = None if nbytes is None else int(nbytes)
+        if nbytes is None:
+            _pool.empty_cache()
+
+    @staticmethod
     def current_device():
         return _current[0]
 
@@ -347,9 +442,6 @@ class _Cuda:
     def synchronize(index=None):
         _ctx(_current[0] if index is None else getattr(index, 'index', index)).sync()
 
-    @staticmethod
-    def empty_cache():
-        pass
 
 
 cuda = _Cuda()

@@ -538,8 +538,14 @@ def band_rows(band):
         A, B, infer_rg_flag, first = band['source']
         if B is not None and (getattr(B, '_closing', False) or B._h is None):
             B = None                                              # the corrected file has been closed: pass 2 does not need it
-        band['batch'] = dev.ReadBatch.from_reader(A, B, infer_rg_flag, first, band['n'], band['pitch'])
+        band['batch'] = dev.ReadBatch.from_reader(A, B, infer_rg_flag, first, band['n'], band['pitch'], keep_pinned=band.get('keep_pinned', False))
     return band['batch']
+
+
+def _too_large(n, S, budget):
+    """Would n reads of up to S bases, resident on the device (three input planes, the output plane, sidecars), need more
+    than `budget` bytes?  (kbbq/_stream.py resident_bytes)"""
+    return int(n) * (4 * pitch_for(S) + 4) > int(budget)
 
 
 def _shard(n, shard):
@@ -690,7 +696,7 @@ def local_ranges(path_a, path_b, infer_rg_flag, rank, world, gather):
     return A, B, [usable, S, R, err[1] if err else 0, err[0] if err else -1]
 
 
-def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None, to_device=False, exchange=None, gather=None):
+def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None, to_device=False, exchange=None, gather=None, budget=None):
     """Pass-1 input (recalibrate.py:56-57) through the C++ packer; same dictionary as pack_pair_py
     except that `text` is the NativeFastq of file A and `names` is filled lazily by callers.
     shard = (rank, world): the rank packs only its own records [first, first + n); `total` is the global number of
@@ -700,7 +706,9 @@ def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None,
     their shard (uncompressed files; compressed ones fall back to everybody reading everything).
     bands=True: instead of one set of planes at the widest pitch, `bands` holds the reads packed by length band
     (length_bands), each at its own pitch.  scan: a PairScan of the same arguments started earlier.  to_device (with
-    bands): the bands are filled straight onto the device (_fill_bands)."""
+    bands): the bands are filled straight onto the device (_fill_bands) -- unless `budget` (bytes of device memory) is given
+    and the shard's resident form would need more: then nothing is filled, `bands` is empty and `streamed` names the readers
+    and the records for kbbq/_stream.py, which walks them slab by slab in either pass."""
     from ._trace import stage
     rank, world = shard if shard is not None else (0, 1)
     planned = exchange is not None and world > 1
@@ -765,6 +773,9 @@ def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None,
     keep = False
     try:
         with stage('fill'):
+            if bands and to_device and budget is not None and hi > lo and _too_large(hi - lo, S, budget):
+                keep = True
+                return dict(common, other=B, bands=[], streamed=dict(A=A, B=B, infer_rg=infer_rg_flag, lo=lo, hi=hi, budget=int(budget)))
             if bands:
                 filled = _fill_bands(A, B, infer_rg_flag, lo, hi, to_device, R, S)
                 keep = to_device             # only once the bands exist (a fill that raises must not leak B's mapping: ADVICE r3); a
@@ -777,7 +788,7 @@ def pack_pair(path_a, path_b, infer_rg_flag, shard=None, bands=False, scan=None,
             close_later(B)                   # file B is not needed after the fill: unmap it off the critical path
 
 
-def pack_single(text, infer_rg_flag, shard=None, bands=False, to_device=False):
+def pack_single(text, infer_rg_flag, shard=None, bands=False, to_device=False, budget=None):
     """Pass-2 input: every read of file A with its own first-appearance RG map
     (recalibrate.py:141-148); shard = (rank, world) as in pack_pair."""
     total, S, R, kind, idx = text.scan(None, infer_rg_flag)
@@ -788,6 +799,8 @@ def pack_single(text, infer_rg_flag, shard=None, bands=False, to_device=False):
     rgs = text.rg_names()
     common = dict(n=hi - lo, first=lo, total=total, pitch=pitch, S=S, R=R,
                   rg_to_int={(nm if infer_rg_flag else 0): i for i, nm in enumerate(rgs)})
+    if bands and to_device and budget is not None and hi > lo and _too_large(hi - lo, S, budget):
+        return dict(common, bands=[], streamed=dict(A=text, B=None, infer_rg=infer_rg_flag, lo=lo, hi=hi, budget=int(budget)))
     if bands:
         return dict(common, bands=_fill_bands(text, None, infer_rg_flag, lo, hi, to_device, R, S))
     seq, _, qual, meta = text.fill(None, infer_rg_flag, hi - lo, pitch, first=lo)

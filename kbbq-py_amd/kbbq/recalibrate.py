@@ -27,6 +27,7 @@ from . import compare_reads as utils        # noqa: F401  (module attribute of t
 from . import fastx
 from . import _device as dev
 from . import _solve
+from . import _stream
 from . import parallel
 from ._trace import stage
 from .gatk import applybqsr
@@ -59,6 +60,13 @@ def _tally_local(packed, minscore, maxscore):
     R, S = max(packed['R'], 0), packed['S']
     if R == 0 or S == 0:
         return None
+    if packed.get('streamed'):
+        # a shard larger than the device budget: nothing is resident, the reads go through K1 slab by slab (kbbq/_stream.py)
+        st = packed['streamed']
+        st['peak'] = _stream.Peak(st['budget'])
+        tables = dev.Tables(R, 2 * S)
+        _stream.tally_range(st['A'], st['B'], st['infer_rg'], st['lo'], st['hi'], tables, minscore, st['budget'])
+        return tables
     tables = dev.Tables(R, 2 * S)
 
     def tally_band(band, laid):
@@ -143,7 +151,7 @@ def _pack_and_tally(fastq, infer_rg, minscore, maxscore):
     try:
         packed = fastx.pack_pair(fastq[0], fastq[1], infer_rg, shard=(rank, world) if world > 1 else None, bands=True,
                                  scan=scan, to_device=True, exchange=parallel.broadcast_object if world > 1 else None,
-                                 gather=parallel.all_gather_object if world > 1 else None)
+                                 gather=parallel.all_gather_object if world > 1 else None, budget=dev.device_budget())
     except Exception as e:                   # noqa: BLE001 -- one rank's failure (its shard unreadable, out of memory) stops them all
         failure = e
     parallel.raise_first_error(failure, 0)
@@ -172,7 +180,18 @@ def fastq_to_covariate_arrays(fastq, infer_rg=False, minscore=6, maxscore=42):
     """Tally errors and observations of the (uncorrected, corrected) FASTQ pair by read
     group, reported quality, cycle and dinucleotide.  Returns the reference's 9-tuple:
     meanq, rg_errs, rg_total, q_errs, q_total, pos_errs, pos_total, dinuc_errs, dinuc_total."""
-    packed, tables = _pack_and_tally(fastq, infer_rg, minscore, maxscore)
+    if any(fastx.is_sequential_input(p) for p in fastq) or os.environ.get('KBBQ_SEQUENTIAL'):
+        if maxscore != 42:
+            raise ValueError('the Q axis of the device tables is fixed at 43 (maxscore = 42)')
+        run = _Sequential(fastq, infer_rg)
+        try:
+            _warm_up()
+            tables = run.pass1(minscore)
+        finally:
+            run.close()
+        packed = dict(R=len(run.rgs) if run.usable else 0, S=run.longest)
+    else:
+        packed, tables = _pack_and_tally(fastq, infer_rg, minscore, maxscore)
     if tables is None:
         z = lambda *s: np.zeros(s, dtype=np.int64)
         R, S = packed['R'], packed['S']
@@ -229,6 +248,8 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None, output=None):
     ranks every rank writes ITS records to `output`.rankNNNN at the same time (the files, concatenated in rank order,
     are the single-process output) -- ranks sharing one stdout can only write in turn."""
     world, rank = parallel.world_rank()
+    if any(fastx.is_sequential_input(p) for p in fastq) or os.environ.get('KBBQ_SEQUENTIAL'):
+        return _recalibrate_sequential(fastq, infer_rg, gatkreport, output)
     shard = (rank, world) if world > 1 else None
     packed, single = None, None
     if gatkreport is not None and os.path.exists(gatkreport):
@@ -237,7 +258,7 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None, output=None):
         text = scan.result()[0]
         if text.n == 0:
             return
-        single = fastx.pack_single(text, infer_rg, shard, bands=True, to_device=True)
+        single = fastx.pack_single(text, infer_rg, shard, bands=True, to_device=True, budget=dev.device_budget())
         tables = load_model(gatkreport, single['rg_to_int'])
     else:
         packed, tables = _pack_and_tally(fastq, infer_rg, 6, 42)
@@ -263,7 +284,10 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None, output=None):
         if single is None:
             if text.n != text.total:
                 text = fastx.NativeFastq(fastq[0])                 # a shard's reader: pass 2 needs all of file A
-            single = fastx.pack_single(text, infer_rg, shard, bands=True, to_device=True)
+            single = fastx.pack_single(text, infer_rg, shard, bands=True, to_device=True, budget=dev.device_budget())
+
+    if single.get('streamed'):
+        return _emit_streamed(text, single, lut, shape, output, world, rank)
 
     if single['R'] != R:
         # pass 2 met read groups the model does not have (recalibrate.py:143-151: an IndexError at the first such read) or
@@ -272,22 +296,7 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None, output=None):
             band['laid'] = None
 
     def apply_band(band):
-        """New qualities of a band: in the band's own layout (mate-pair rows stay mate-pair rows, stored in input order
-        -- the writer reads them as they are) or, when the layout's kernel cannot serve the LUT or the rows, one read
-        per row from the checked kernel."""
-        laid, out = band.get('laid'), None
-        band['out_flags'], band['out_S2'] = 0, 0
-        if laid is not None:
-            try:
-                out = dev.apply(laid, lut, shape, restore_order=True)      # grouped rows: stored straight back in input order
-                if isinstance(laid, dev.PairBatch):
-                    band['out_flags'], band['out_S2'] = dev.N.ROWS_PAIRS, 2 * laid.S
-            except dev.N.LutNeedsCheckedApply:
-                out = None                   # a LUT the fast kernel cannot serve: the checked row-per-read kernel
-        if out is None:
-            band['out_flags'], band['out_S2'] = 0, 0
-            out = dev.apply(fastx.band_rows(band), lut, shape)
-        return out
+        return _stream.apply_band(band, lut, shape)
 
     def apply_shard():
         merged = {}
@@ -331,6 +340,265 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None, output=None):
     else:
         with open(output if world == 1 else '%s.rank%04d' % (output, rank), 'wb') as sink:
             _egress.emit_records(text, single['first'], single['bands'], outs, sink=sink)
+
+
+def _prefetched(items, depth=1):
+    """Iterate `items` (a generator whose steps spend their time in C calls that release the interpreter lock: reading and
+    indexing the next segment of an input) on a helper thread, `depth` items ahead of the consumer."""
+    import queue
+    import threading
+    q, end = queue.Queue(depth), object()
+    stop = threading.Event()
+
+    def run():
+        try:
+            for it in items:
+                if stop.is_set():
+                    break
+                q.put((it, None))
+        except BaseException as e:           # noqa: BLE001 -- re-raised by the consumer
+            q.put((None, e))
+            return
+        q.put((end, None))
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    try:
+        while True:
+            it, exc = q.get()
+            if exc is not None:
+                raise exc
+            if it is end:
+                return
+            yield it
+    finally:
+        stop.set()
+        while th.is_alive():                 # let a producer blocked on the full queue see the stop
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                th.join(0.01)
+
+
+SEGMENT_BYTES = 256 << 20                    # text of file A per segment of a sequentially read input (KBBQ_SEGMENT_BYTES)
+
+
+def _segment_bytes():
+    env = os.environ.get('KBBQ_SEGMENT_BYTES')
+    return max(dev.parse_bytes(env), 1 << 16) if env else SEGMENT_BYTES
+
+
+def _pair_segments(sa, sb, seg_bytes):
+    """(segment of file A, segment of file B holding the same number of records -- fewer, or None, once file B has ended)
+    until file A ends; without sb: (segment of A, None)."""
+    b_ended = sb is None
+    while True:
+        a, _ = sa.next(seg_bytes)
+        if a is None:
+            return
+        b = None
+        if not b_ended:
+            b, _ = sb.next(len_bytes(a) + (1 << 16), a.n)
+            if b is None or b.n < a.n:
+                b_ended = True
+        yield a, b
+
+
+def len_bytes(reader):
+    """Bytes of text a segment holds (what its follower is asked for first)."""
+    return max(reader.record_offset(reader.first + reader.n) - reader.record_offset(reader.first), 1 << 16) if reader.n else 1 << 16
+
+
+def _grown(tables, R, S2):
+    """`tables` at (at least) R read groups and S2 cycle columns: the reference appends zeros at the END of either axis when
+    a longer read or a new read group arrives (recalibrate.py:66-87), so every count keeps its absolute index."""
+    if tables is not None and tables.R >= R and tables.S2 >= S2:
+        return tables
+    if tables is None:
+        return dev.Tables(R, S2)
+    R, S2 = max(R, tables.R), max(S2, tables.S2)
+    old = tables.to_host()
+    new = [np.zeros((R, 43, S2), dtype=np.int64), np.zeros((R, 43, S2), dtype=np.int64),
+           np.zeros((R, 43, 16), dtype=np.int64), np.zeros((R, 43, 16), dtype=np.int64)]
+    for o, w in zip(old, new):
+        w[:o.shape[0], :, :o.shape[2]] = o
+    return dev.Tables.from_host(*new)
+
+
+class _Sequential:
+    """The two passes over inputs that are READ SEQUENTIALLY (fastx.FastqStream): pipes, process substitutions, standard
+    input -- and regular files when KBBQ_SEQUENTIAL is set: no mapping, no whole-file index, host memory a few segments
+    whatever the input's size.  What the reference's walk carries from read to read (recalibrate.py:59-101: read groups in
+    first-appearance order, the longest read so far, the growing count arrays) is carried from segment to segment; the
+    first offending read stops the walk where the reference stops.  File A is needed twice: a regular file is read again,
+    anything else is copied to a spool file while pass 1 reads it (KBBQ_SPOOL_DIR, default the temporary directory)."""
+
+    def __init__(self, fastq, infer_rg):
+        world, _ = parallel.world_rank()
+        if world > 1:
+            raise ValueError('inputs that are read sequentially (pipes, standard input) need a single process: the ranks of a '
+                             'multi-GPU run cut their byte ranges out of regular files')
+        self.fastq, self.infer_rg = fastq, infer_rg
+        self.spool = None
+        self.rgs, self.longest, self.total_a, self.usable = [], 0, 0, 0
+
+    def rg_to_int(self):
+        return {(nm if self.infer_rg else 0): i for i, nm in enumerate(self.rgs)}
+
+    def close(self):
+        if getattr(self, 'peak', None) is not None:
+            self.peak.close()
+            self.peak = None
+        if self.spool is not None:
+            try:
+                os.unlink(self.spool)
+            except OSError:
+                pass
+            self.spool = None
+
+    def _open_a(self):
+        sa = fastx.FastqStream(self.fastq[0])
+        fd = None
+        if not sa.regular:
+            import tempfile
+            fd, self.spool = tempfile.mkstemp(prefix='kbbq-spool-', suffix='.fq', dir=os.environ.get('KBBQ_SPOOL_DIR') or None)
+            sa.tee(fd)
+        return sa, fd
+
+    def pass1(self, minscore=6, tally=True):
+        """Count tables of the pair (None when no read was tallied); tally=False: file A alone, read groups and the spool
+        only (a model file replaces pass 1)."""
+        sa, fd = self._open_a()
+        sb = fastx.FastqStream(self.fastq[1]) if tally else None
+        budget = dev.device_budget()
+        self.peak = _stream.Peak(budget)
+        tables, b_ended = None, False
+        segments = _prefetched(_pair_segments(sa, sb, _segment_bytes()))
+        try:
+            for a, b in segments:
+                self.total_a += a.n
+                if tally and b is None:
+                    b_ended = True                               # file B ended at the last segment's end
+                if b_ended:
+                    if sa.regular:
+                        break                                    # zip() has stopped (H6) and file A can be read again
+                    continue                                     # ... a pipe is drained into the spool for pass 2
+                with stage('scan'):
+                    usable, S_seg, R, kind, idx = a.scan_next(b, self.infer_rg, self.rgs, self.longest)
+                self.rgs = a.rg_names()
+                self.longest = max(self.longest, S_seg)
+                if tally and usable > 0:
+                    tables = _grown(tables, R, 2 * self.longest)
+                    try:
+                        _stream.tally_range(a, b, self.infer_rg, a.first, a.first + usable, tables, minscore, budget)
+                    except (IndexError, TypeError) as e:
+                        if hasattr(e, 'read_index'):
+                            e.read_index = a.first + max(e.read_index, 0)
+                        raise
+                self.usable += usable
+                if kind:
+                    raise fastx._SCAN_ERRORS[kind](a.first + idx)
+                if tally and (b is None or b.n < a.n):
+                    b_ended = True
+        finally:
+            segments.close()                                     # joins the reading thread before the streams go
+            if fd is not None:
+                os.close(fd)
+            sa.close()
+            if sb is not None:
+                sb.close()
+        return tables
+
+    def pass2(self, lut, shape, output):
+        """Every read of file A (its own first-appearance read groups, recalibrate.py:141-148) through K2 and the writer."""
+        from . import _egress
+        torch = dev._torch()
+        device = torch.cuda.current_device()
+        budget = dev.device_budget()
+        sa = fastx.FastqStream(self.spool or self.fastq[0])
+        peak = self.peak = getattr(self, 'peak', None) or _stream.Peak(budget)
+        infer_rg = self.infer_rg
+        segments = _prefetched(_pair_segments(sa, None, _segment_bytes()))
+
+        def produced():
+            rgs = []
+            for a, _ in segments:
+                with stage('scan'):
+                    _, _, _, kind, idx = a.scan_next(None, infer_rg, rgs, 0)
+                if kind:
+                    raise fastx._SCAN_ERRORS[kind](a.first + idx)
+                rgs = a.rg_names()
+                try:
+                    yield from _stream.produce_range(a, infer_rg, a.first, a.first + a.n, lut, shape, budget, origin=a.first,
+                                                     extra=dict(text=a, base=a.first), device=device)
+                except _stream.REFUSALS as e:
+                    if hasattr(e, 'read_index'):
+                        e.read_index = a.first + max(e.read_index, 0)
+                    raise
+        try:
+            widest = fastx.pitch_for(max(self.longest, 1)) * 2 + 16
+            if output is None:
+                _egress.emit_produced(None, 0, produced(), widest)
+            else:
+                with open(output, 'wb') as sink:
+                    _egress.emit_produced(None, 0, produced(), widest, sink=sink)
+            LAST_RUN.clear()
+            LAST_RUN['bands'] = []
+            LAST_RUN['streamed'] = dict(peak.report(), reads=self.total_a, sequential=True, spooled=self.spool is not None,
+                                        tables_bytes=8 * int(dev.N.load().kbbq_tables_count(shape[0], shape[2])), lut_bytes=int(lut.numel()))
+        finally:
+            try:
+                segments.close()                                 # joins the reading thread before the stream goes
+            except ValueError:                                   # (still running on the pipeline's thread: cannot happen once it has joined)
+                pass
+            sa.close()
+
+
+def _recalibrate_sequential(fastq, infer_rg, gatkreport, output):
+    """recalibrate_fastq for inputs that are read sequentially: same results, same errors at the same reads."""
+    run = _Sequential(fastq, infer_rg)
+    try:
+        _warm_up()
+        load = gatkreport is not None and os.path.exists(gatkreport)
+        tables = run.pass1(tally=not load)
+        if run.total_a == 0:
+            return
+        if load:
+            tables = load_model(gatkreport, run.rg_to_int())
+        elif tables is None:
+            raise IndexError('index 0 is out of bounds for axis 0 with size 0')   # no read was tallied
+        elif gatkreport is not None:
+            save_model(tables, run.rg_to_int(), gatkreport)
+        with stage('solve', sync=True):
+            lut, shape = dev.solve_lut(tables)
+        run.pass2(lut, shape, output)
+    finally:
+        run.close()
+
+
+def _emit_streamed(text, single, lut, shape, output, world, rank):
+    """Pass 2 of a shard that is not resident (kbbq/_stream.py): file A's reads are filled again slab by slab and go through
+    K2 while the slabs before them are copied back, rendered and written -- fill | H2D | K2 | D2H | format | write.  The
+    ranks do not agree on a first error beforehand as the resident pass 2 does: an error stops the rank that meets it where
+    it stands, after the records before the offending slab have been written (the reference prints up to the offending read)."""
+    from . import _egress
+    st = single['streamed']
+    torch = dev._torch()
+    device = torch.cuda.current_device()
+    peak = st.get('peak') or _stream.Peak(st['budget'])
+    try:
+        produced = _stream.produce_range(st['A'], st['infer_rg'], st['lo'], st['hi'], lut, shape, st['budget'], device=device)
+        widest = fastx.pitch_for(single['S']) * 2 + 16
+        if output is None:
+            parallel.in_rank_order(lambda: _egress.emit_produced(text, single['first'], produced, widest))
+        else:
+            with open(output if world == 1 else '%s.rank%04d' % (output, rank), 'wb') as sink:
+                _egress.emit_produced(text, single['first'], produced, widest, sink=sink)
+        LAST_RUN.clear()
+        LAST_RUN['bands'] = []
+        LAST_RUN['streamed'] = dict(peak.report(), reads=st['hi'] - st['lo'],
+                                    tables_bytes=8 * int(dev.N.load().kbbq_tables_count(shape[0], shape[2])), lut_bytes=int(lut.numel()))
+    finally:
+        peak.close()
 
 
 def recalibrate_bam(bam, use_oq=False, set_oq=False):

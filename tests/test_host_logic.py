@@ -833,3 +833,105 @@ def test_hipmem_host_tensors_behave_like_the_torch_subset_they_replace():
     with pytest.raises(ValueError):
         H.from_numpy(a[:, ::2])
     assert H._device_of('cuda:3') == H.Device('cuda', 3) and H._device_of(None) == H.CPU
+
+
+def test_sequential_reader_hands_out_whole_records(oracle, tmp_path):
+    """fastx.FastqStream (csrc/fastq_stream.cpp): segments of whole records from a regular file and from a named pipe, a
+    follower with the leader's record counts, a spool that receives what was handed out; the incremental scan carries read
+    groups and the longest read from segment to segment and finds what the whole-file scan finds."""
+    import threading
+    n = 3001
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 3, 36, 200, 4)
+    order = np.argsort(meta & 0xFFFF, kind='stable')
+    seq, cseq, qual, meta = seq[order], cseq[order], qual[order], meta[order]
+    names = oracle.synth_names(0, n, 4, with_rg=True)
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, [x + '_c' for x in names], cseq, qual, meta)
+    whole = open(fa, 'rb').read()
+    A, B = fastx.NativeFastq(fa), fastx.NativeFastq(fb)
+    want = A.scan(B, True)
+    for max_bytes in (1 << 16, 200000, 1 << 30):
+        s, t = fastx.FastqStream(fa), fastx.FastqStream(fb)
+        assert s.regular
+        got, rgs, longest, nseg = b'', [], 0, 0
+        while True:
+            a, end = s.next(max_bytes)
+            if a is None:
+                break
+            b, _ = t.next(max_bytes, a.n)
+            assert b.n == a.n and b.first == a.first
+            info = a.scan_next(b, True, rgs, longest)
+            assert info[0] == a.n and info[3] == 0
+            rgs, longest = a.rg_names(), max(longest, info[1])
+            _, _, ql, _ = a.fill(None, True, a.n, 208, first=a.first)
+            got += a.format(a.first, a.n, ql)
+            nseg += 1
+        assert got == whole and rgs == A.rg_names() and longest == want[1] and len(rgs) == want[2]
+        assert nseg == (1 if max_bytes > len(whole) else -(-len(whole) // max_bytes)) or nseg >= len(whole) // (max_bytes + 70000)
+    # the first offender of a later segment: a read shorter than the longest read of the segments before it
+    lines = whole.split(b'\n')
+    k = 2500
+    lines[4 * k + 1] = lines[4 * k + 1][:20]; lines[4 * k + 3] = lines[4 * k + 3][:20]
+    bad = str(tmp_path / 'bad.fq')
+    open(bad, 'wb').write(b'\n'.join(lines))
+    linesb = open(fb, 'rb').read().split(b'\n')
+    linesb[4 * k + 1] = linesb[4 * k + 1][:20]; linesb[4 * k + 3] = linesb[4 * k + 3][:20]
+    badb = str(tmp_path / 'badb.fq')
+    open(badb, 'wb').write(b'\n'.join(linesb))
+    s, t = fastx.FastqStream(bad), fastx.FastqStream(badb)
+    rgs, longest, found = [], 0, None
+    while found is None:
+        a, _ = s.next(100000)
+        b, _ = t.next(100000, a.n)
+        info = a.scan_next(b, True, rgs, longest)
+        rgs, longest = a.rg_names(), max(longest, info[1])
+        if info[3]:
+            found = (info[3], a.first + info[4], info[0])
+    assert found[0] == 5 and found[1] == k and fastx.NativeFastq(bad).scan(fastx.NativeFastq(badb), True)[3:] == [5, k]
+    # a named pipe: not regular, read once, teed into a spool
+    fifo = str(tmp_path / 'fifo')
+    os.mkfifo(fifo)
+    th = threading.Thread(target=lambda: open(fifo, 'wb').write(whole))
+    th.start()
+    s = fastx.FastqStream(fifo)
+    assert not s.regular and fastx.is_sequential_input(fifo) and not fastx.is_sequential_input(fa) and fastx.is_sequential_input('-')
+    spool = os.open(str(tmp_path / 'spool'), os.O_RDWR | os.O_CREAT)
+    s.tee(spool)
+    total = 0
+    while True:
+        a, _ = s.next(150000)
+        if a is None:
+            break
+        total += a.n
+    th.join(); os.close(spool)
+    assert total == n and open(str(tmp_path / 'spool'), 'rb').read() == whole
+    # ends: no last newline, CRLF, an input that stops inside a record, nothing at all, a shorter follower, gzip bytes
+    for text, count in ((whole[:-1], n), (whole.replace(b'\n', b'\r\n'), n), (b'', 0)):
+        p = str(tmp_path / 'x.fq'); open(p, 'wb').write(text)
+        s, total = fastx.FastqStream(p), 0
+        while True:
+            a, _ = s.next(90000)
+            if a is None:
+                break
+            assert a.name(a.first) == names[a.first]
+            total += a.n
+        assert total == count
+    p = str(tmp_path / 'y.fq'); open(p, 'wb').write(b'\n'.join(whole.split(b'\n')[:4 * 100 + 2]) + b'\n')
+    s = fastx.FastqStream(p)
+    with pytest.raises(ValueError):
+        while s.next(1 << 30)[0] is not None:
+            pass
+    p = str(tmp_path / 'z.fq'); open(p, 'wb').write(b'\n'.join(open(fb, 'rb').read().split(b'\n')[:4 * 700]) + b'\n')
+    s, t, na, nb = fastx.FastqStream(fa), fastx.FastqStream(p), 0, 0
+    while True:
+        a, _ = s.next(120000)
+        if a is None:
+            break
+        b, _ = t.next(120000, a.n)
+        na, nb = na + a.n, nb + (b.n if b is not None else 0)
+    assert (na, nb) == (n, 700)
+    import gzip
+    p = str(tmp_path / 'g.fq.gz'); gzip.open(p, 'wb').write(whole)
+    with pytest.raises(ValueError, match='zcat'):
+        fastx.FastqStream(p).next(1 << 20)
