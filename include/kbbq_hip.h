@@ -568,6 +568,7 @@ int         kbbq_fastq_stream_open(const char* path, kbbq_fastq_stream** out);
 int         kbbq_fastq_stream_is_regular(const kbbq_fastq_stream* s);
 int         kbbq_fastq_stream_tee(kbbq_fastq_stream* s, int fd);
 int         kbbq_fastq_stream_next(kbbq_fastq_stream* s, size_t max_bytes, int64_t records, kbbq_fastq** segment, int* at_end);
+int         kbbq_fastq_stream_prefetch(kbbq_fastq_stream* s, size_t bytes);   /* read ahead until `bytes` wait in the stream (another thread, while the leading file is read) */
 int         kbbq_fastq_stream_close(kbbq_fastq_stream* s);
 int         kbbq_fastq_scan_next(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, int64_t prior_longest, int64_t* info5);
 /* kbbq_fastq_open of both files (b may be NULL) + kbbq_fastq_scan on the library's own threads; _begin returns at

@@ -175,6 +175,22 @@ int kbbq_fastq_stream_tee(kbbq_fastq_stream* s, int fd)
     return KBBQ_OK;
 }
 
+// Read ahead of the next kbbq_fastq_stream_next until `bytes` bytes wait in the stream: what a caller runs on a second thread
+// for the FOLLOWING file while the leading file's segment is being read -- two pipes fed by two decompressors are then
+// drained at the same time instead of one after the other.  Not to be called while a _next of the same stream runs.
+int kbbq_fastq_stream_prefetch(kbbq_fastq_stream* s, size_t bytes)
+{
+    if (!s) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_stream_prefetch: NULL stream");
+    const size_t have = s->carry.size();
+    if (s->eof || bytes <= have) return KBBQ_OK;
+    bytes -= have;
+    s->carry.resize(have + bytes);
+    const int64_t got = read_some(s, s->carry.data() + have, bytes);
+    s->carry.resize(have + (size_t)std::max<int64_t>(got, 0));
+    if (got < 0) return kbbq_set_error_(KBBQ_E_ARG, (s->path + ": read failed").c_str());
+    return KBBQ_OK;
+}
+
 // The next segment: whole records only.
 //   records == 0  (the leading file): about max_bytes of text (at least one record, however long);
 //   records  > 0  (the following file): exactly that many records, fewer only when the input ends first.

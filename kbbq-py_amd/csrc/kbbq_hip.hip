@@ -137,7 +137,8 @@ int kbbq_ctx_create(int device, kbbq_ctx** out)
 #undef KBBQ_KM_ATTR
     (void)hipFuncSetAttribute((const void*)(k2v3_apply<false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k2v3_apply<true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
-    (void)hipFuncSetAttribute((const void*)k2t_apply, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)k2t_apply<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    (void)hipFuncSetAttribute((const void*)k2t_apply<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2t_bands, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k1v3_aligned<false, K1V3_DNREP>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)(k1v3_aligned<true, K1V3_DNREP>), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
@@ -605,6 +606,10 @@ static int narrowed_row_lut(kbbq_ctx* c, const void* d_lut_blob, int R, int Qt, 
     return Sb;
 }
 
+static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta,
+                      int64_t nrows, int pitch, int pairs, int R, int S2, int minscore, const void* d_lut_blob,
+                      const void* d_pair_lut, const int64_t* d_seg, uint8_t* d_out, int nib = 0, const int64_t* d_perm = nullptr);
+
 int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta,
                    int64_t nreads, int pitch, int R, int Qt, int S2, int minscore,
                    const void* d_lut, int mode, uint8_t* d_out)
@@ -625,6 +630,19 @@ int kbbq_apply_dev(kbbq_ctx* c, const uint8_t* d_seq, const uint8_t* d_qual, con
     // the LUT of the columns rows of this pitch can reach (narrowed_row_lut): a band of short reads under wide tables
     const int Sb0 = (getenv("KBBQ_K2_ROWLUT") && !strcmp(getenv("KBBQ_K2_ROWLUT"), "0")) ? S2 : std::min(pitch, S2);
     const size_t full_bytes = (size_t)R * (33 + Qt) * full_lut_row_bytes(Sb0);
+    if (mode == KBBQ_APPLY_FAST && R == 1 && Qt == KQ && !(S2 & 1) && S2 <= 65534 && !(force && !strcmp(force, "v1"))) {
+        // one read group, rows as a caller holds them (one character row per read): the short-lived kernel (kbbq_k2_tile.h) when
+        // apply_rows' conditions for it hold -- it falls through to the persistent kernel itself otherwise.  What it cannot serve
+        // (a foreign letter, q > 42, a read longer than the LUT) it reports as KBBQ_E_LUT: the caller's KBBQ_APPLY_CHECKED run
+        // decides, as for a LUT that is not range-safe.
+        const char* tile = getenv("KBBQ_K2_TILE");
+        const char* tile_chars = getenv("KBBQ_K2_TILE_CHARS");
+        const int cpr = pitch / 16;
+        const size_t rg_bytes = (size_t)(33 + KQ) * full_lut_row_bytes(Sb0);
+        if (!(tile && !strcmp(tile, "0")) && !(tile_chars && !strcmp(tile_chars, "0")) && cpr >= 2 && cpr <= 4096
+            && rg_bytes <= (size_t)(getenv("KBBQ_K2_TILE_LUT_KB") ? atoi(getenv("KBBQ_K2_TILE_LUT_KB")) : 52) << 10)
+            return apply_rows(c, "kbbq_apply_dev", d_seq, d_qual, d_meta, nreads, pitch, 0, R, S2, minscore, d_lut, nullptr, nullptr, d_out, 0, nullptr);
+    }
     if (mode == KBBQ_APPLY_FAST && full_bytes <= (size_t)c->lds_bytes && !(force && !strcmp(force, "v1"))) {
         K2v3Params q;
         q.seq = d_seq; q.qual = d_qual; q.meta = d_meta; q.nreads = nreads; q.pitch = pitch;
@@ -1102,7 +1120,7 @@ int kbbq_pair_lut_rows_dev(kbbq_ctx* c, const void* d_lut_blob, int R, int S2, i
 // K2 (table-driven kernel) on one-read-per-row or mate-pair rows, optionally grouped by read group
 static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_meta,
                       int64_t nrows, int pitch, int pairs, int R, int S2, int minscore, const void* d_lut_blob,
-                      const void* d_pair_lut, const int64_t* d_seg, uint8_t* d_out, int nib = 0, const int64_t* d_perm = nullptr)
+                      const void* d_pair_lut, const int64_t* d_seg, uint8_t* d_out, int nib, const int64_t* d_perm)
 {
     int rc = check_planes(who, nrows, pitch, d_seq, d_qual, d_out);
     if (rc) return rc;
@@ -1149,7 +1167,10 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
     const char* tile = getenv("KBBQ_K2_TILE");
     // (one read per row: while two workgroups' copies of the narrowed LUT fit a CU -- rows of up to ~300 bases; measured up to
     //  there, scripts/gpu_tilekb.sh: config 5's K2 0.651 -> 0.687 of roofline going from a 32 KB to a 52 KB limit)
-    if (!(tile && !strcmp(tile, "0")) && nib && (R == 1 || d_seg) && q.cpr >= 2 && q.cpr <= 4096
+    // character planes (round 4; KBBQ_K2_TILE_CHARS=0: the persistent kernel as before): the same kernel with 16-byte sequence loads
+    const char* tile_chars = getenv("KBBQ_K2_TILE_CHARS");
+    const bool planes_ok = nib || !(tile_chars && !strcmp(tile_chars, "0"));
+    if (!(tile && !strcmp(tile, "0")) && planes_ok && (R == 1 || d_seg) && q.cpr >= 2 && q.cpr <= 4096
         && (pairs ? rg_bytes * 3 <= (size_t)c->lds_bytes : rg_bytes <= (size_t)(getenv("KBBQ_K2_TILE_LUT_KB") ? atoi(getenv("KBBQ_K2_TILE_LUT_KB")) : 52) << 10)) {
         K2tParams t;
         t.seq = d_seq; t.qual = d_qual; t.meta = d_meta; t.nchunks = nrows * q.cpr; t.cpr = q.cpr; t.cpr_magic = q.cpr_magic;
@@ -1183,7 +1204,8 @@ static int apply_rows(kbbq_ctx* c, const char* who, const uint8_t* d_seq, const 
         }
         {
             Timed tm(c, 1);
-            hipLaunchKernelGGL(k2t_apply, dim3((unsigned)gt), dim3(K2T_THREADS), (size_t)t.lut_bytes, c->stream, t);
+            if (nib) hipLaunchKernelGGL(k2t_apply<true>, dim3((unsigned)gt), dim3(K2T_THREADS), (size_t)t.lut_bytes, c->stream, t);
+            else hipLaunchKernelGGL(k2t_apply<false>, dim3((unsigned)gt), dim3(K2T_THREADS), (size_t)t.lut_bytes, c->stream, t);
         }
         HIPCHK(hipGetLastError());
         return KBBQ_OK;

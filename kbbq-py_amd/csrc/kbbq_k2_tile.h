@@ -90,6 +90,12 @@ __global__ __launch_bounds__(256) void k2t_order(K2tOrderParams p)
 
 // the kernel's body for workgroup `bx` of the batch `p` describes (k2t_apply: blockIdx.x; k2t_bands: the workgroup's
 // number within its length band)
+// NIB = false (round 4): CHARACTER planes -- what rows a caller already holds on the device get (kbbq_apply_dev, one read group)
+// and what a batch with a letter outside ACGTN keeps; 16 bytes of sequence per chunk instead of 8, decoded with decode4x as in
+// k2v3_apply.  The kernel still only REPORTS what it cannot serve (a foreign letter included: the reference's TypeError is
+// decided by the checked kernel the caller runs next), so the persistent kernel remains the form that handles such chunks in
+// place -- rows of several read groups that are not grouped take it, as before.
+template <bool NIB>
 __device__ __forceinline__ void k2t_body(const K2tParams& p, u32* lds, const int bx, const int ntiles)
 {
     const int lane = lane_id();
@@ -124,23 +130,37 @@ __device__ __forceinline__ void k2t_body(const K2tParams& p, u32* lds, const int
     const long long row0 = base_c / p.cpr;
     const u32 rem0 = (u32)(base_c - row0 * p.cpr);
     // 1. the wave's data loads, all of them, before anything else (clamped at the end of the planes: re-read the last chunk)
-    u32 sq[K2T_STEPS][2], ql[K2T_STEPS][4], mk[K2T_STEPS];
+    u32 sq[K2T_STEPS][NIB ? 2 : 4], ql[K2T_STEPS][4], mk[K2T_STEPS];
     long long cidx[K2T_STEPS];
 #pragma unroll
     for (int s = 0; s < K2T_STEPS; ++s) {
         const long long c = base + 64 * s + lane;
         const long long cc = c < chunk_hi ? c : chunk_hi - 1;
         cidx[s] = c;
-        const uint2 sv = *reinterpret_cast<const uint2*>(p.seq + 8 * cc);
+        if constexpr (NIB) {
+            const uint2 sv = *reinterpret_cast<const uint2*>(p.seq + 8 * cc);
+            sq[s][0] = sv.x; sq[s][1] = sv.y;
+        } else {
+            const uint4 sv = *reinterpret_cast<const uint4*>(p.seq + 16 * cc);
+            sq[s][0] = sv.x; sq[s][1] = sv.y; sq[s][2] = sv.z; sq[s][3] = sv.w;
+        }
         const uint4 qv = *reinterpret_cast<const uint4*>(p.qual + 16 * cc);
-        sq[s][0] = sv.x; sq[s][1] = sv.y;
         ql[s][0] = qv.x; ql[s][1] = qv.y; ql[s][2] = qv.z; ql[s][3] = qv.w;
         const u32 rel = rem0 + (u32)(cc - base_c);                    // < cpr + 64 * K2T_STEPS
         mk[s] = p.meta[row0 + __umulhi(rel, p.cpr_magic)];
     }
     // the base before the wave's first chunk (its last nibble), for the context of the first base
     const long long c0 = base < chunk_hi ? base : chunk_hi - 1;
-    const u32 before = c0 > 0 ? (u32)p.seq[8 * c0 - 1] >> 4 : 4u;
+    u32 before = 4u;
+    if (c0 > 0) {
+        if constexpr (NIB) before = (u32)p.seq[8 * c0 - 1] >> 4;
+        else {                                                                  // the character's code (A0 T1 G2 C3, anything else 4:
+            u32 cd, cd5, expect;                                                // a foreign letter is reported by the lane that owns it)
+            const u32 ch4 = (u32)p.seq[16 * c0 - 1] * 0x01010101u;
+            decode4x(ch4, cd, cd5, expect);
+            before = expect == ch4 ? (cd & 0xFFu) : 4u;
+        }
+    }
     // 2. the LUT (L2-resident after the first workgroups), then one barrier
     {
         const uint4* src = reinterpret_cast<const uint4*>(p.lut + (size_t)g * (size_t)(33 + p.Qt) * p.rb);
@@ -161,12 +181,19 @@ __device__ __forceinline__ void k2t_body(const K2tParams& p, u32* lds, const int
         const int j = (int)(rel - drow * (u32)p.cpr);
         const int len = (int)(mk[s] & 0xFFFFu);
         const int nb = act0 ? len - 16 * j : 0;
-        u32 code[4], code5[4], hiq = 0u;
-        code[0] = nib_lo(sq[s][0]); code[1] = nib_hi(sq[s][0]); code[2] = nib_lo(sq[s][1]); code[3] = nib_hi(sq[s][1]);
-        const u32 badbits = nib_invalid(sq[s][0]) | nib_invalid(sq[s][1]);
+        u32 code[4], code5[4], hiq = 0u, badbits = 0u;
+        if constexpr (NIB) {
+            code[0] = nib_lo(sq[s][0]); code[1] = nib_hi(sq[s][0]); code[2] = nib_lo(sq[s][1]); code[3] = nib_hi(sq[s][1]);
+            badbits = nib_invalid(sq[s][0]) | nib_invalid(sq[s][1]);
+        }
 #pragma unroll
         for (int wd = 0; wd < 4; ++wd) {
-            code5[wd] = (code[wd] << 2) + code[wd];
+            if constexpr (NIB) code5[wd] = (code[wd] << 2) + code[wd];
+            else {
+                u32 expect;
+                decode4x(sq[s][wd], code[wd], code5[wd], expect);
+                badbits |= expect ^ sq[s][wd];                                   // a letter outside ACGTN (padding is N by the layout contract)
+            }
             hiq |= ((ql[s][wd] & 0x7F7F7F7Fu) + hi_add) | ql[s][wd];
         }
         hiq &= 0x80808080u;
@@ -211,10 +238,11 @@ __device__ __forceinline__ void k2t_body(const K2tParams& p, u32* lds, const int
     }
 }
 
+template <bool NIB = true>
 __global__ __launch_bounds__(K2T_THREADS) void k2t_apply(K2tParams p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
-    k2t_body(p, lds, (int)blockIdx.x, (int)gridDim.x);
+    k2t_body<NIB>(p, lds, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ONE launch over all length bands of a mixed-length input (k1v3_bands' counterpart): workgroup blockIdx.x belongs to the
@@ -232,5 +260,5 @@ __global__ __launch_bounds__(K2T_THREADS) void k2t_bands(K2tBandsParams t)
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     int lo = 0, hi = t.nbands;                                      // largest b with wg_start[b] <= blockIdx.x
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (t.wg_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
-    k2t_body(t.band[lo], lds, (int)blockIdx.x - t.wg_start[lo], t.wg_start[lo + 1] - t.wg_start[lo]);
+    k2t_body<true>(t.band[lo], lds, (int)blockIdx.x - t.wg_start[lo], t.wg_start[lo + 1] - t.wg_start[lo]);
 }

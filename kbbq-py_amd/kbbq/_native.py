@@ -139,6 +139,7 @@ PROTOTYPES = {
     'kbbq_fastq_stream_is_regular': (_i, [_vp]),
     'kbbq_fastq_stream_tee': (_i, [_vp, _i]),
     'kbbq_fastq_stream_next': (_i, [_vp, _sz, _i64, _c.POINTER(_vp), _c.POINTER(_i)]),
+    'kbbq_fastq_stream_prefetch': (_i, [_vp, _sz]),
     'kbbq_fastq_stream_close': (_i, [_vp]),
     'kbbq_fastq_pair_begin': (_i, [_c.c_char_p, _c.c_char_p, _i, _c.POINTER(_vp)]),
     'kbbq_fastq_pair_wait': (_i, [_vp, _c.POINTER(_vp), _c.POINTER(_vp), _vp]),

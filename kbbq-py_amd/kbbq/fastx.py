@@ -428,6 +428,10 @@ class FastqStream:
     def tee(self, fd):
         _N.check(_N.load().kbbq_fastq_stream_tee(self._h, int(fd)))
 
+    def prefetch(self, nbytes):
+        """Read up to nbytes ahead of the next next() (on another thread, while the other file's segment is being read)."""
+        _N.check(_N.load().kbbq_fastq_stream_prefetch(self._h, int(nbytes)))
+
     def next(self, max_bytes, records=0):
         seg, end = _ct.c_void_p(), _ct.c_int(0)
         _N.check(_N.load().kbbq_fastq_stream_next(self._h, int(max_bytes), int(records), _ct.byref(seg), _ct.byref(end)))

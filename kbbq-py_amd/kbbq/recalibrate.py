@@ -390,9 +390,18 @@ def _segment_bytes():
 def _pair_segments(sa, sb, seg_bytes):
     """(segment of file A, segment of file B holding the same number of records -- fewer, or None, once file B has ended)
     until file A ends; without sb: (segment of A, None)."""
+    import threading
     b_ended = sb is None
     while True:
-        a, _ = sa.next(seg_bytes)
+        ahead = None
+        if not b_ended:                      # both inputs are drained at the same time (two pipes fed by two decompressors)
+            ahead = threading.Thread(target=_quietly, args=(sb.prefetch, seg_bytes), daemon=True)
+            ahead.start()
+        try:
+            a, _ = sa.next(seg_bytes)
+        finally:
+            if ahead is not None:
+                ahead.join()
         if a is None:
             return
         b = None
@@ -401,6 +410,14 @@ def _pair_segments(sa, sb, seg_bytes):
             if b is None or b.n < a.n:
                 b_ended = True
         yield a, b
+
+
+def _quietly(fn, *args):
+    """fn(*args) on a helper thread: a failure is left for the main call on the same stream to meet and report."""
+    try:
+        fn(*args)
+    except Exception:                        # noqa: BLE001
+        pass
 
 
 def len_bytes(reader):

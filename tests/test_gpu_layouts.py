@@ -245,6 +245,52 @@ def test_short_lived_k2_equals_the_persistent_k2(dev, n, R, monkeypatch):
         del got, want
 
 
+@pytest.mark.parametrize('n,S,R,lay', [(26_000_000, 150, 1, 'rows'), (6002, 150, 1, 'rows'), (130, 100, 1, 'rows'), (20_000, 75, 1, 'rows'),
+                                       (8000, 150, 3, 'grouped'), (6000, 150, 1, 'pairs'), (6000, 100, 4, 'pairs+grouped'), (5000, 250, 1, 'rows')])
+def test_short_lived_k2_on_character_planes(dev, oracle, n, S, R, lay, monkeypatch):
+    """Round 4: the short-lived K2 on CHARACTER planes (k2t_apply<false>: rows as a caller holds them -- kbbq_apply_dev with one
+    read group --, character rows grouped by read group, character mate-pair rows) against the persistent kernel
+    (KBBQ_K2_TILE_CHARS=0) on the same batch: identical bytes, also through the permutation; at 26 M reads chunk numbers
+    pass 2^28.  What it cannot serve it reports, and the checked kernel then decides as the reference does: a foreign letter
+    is the TypeError, a quality above 42 the IndexError."""
+    import torch
+    b = dev.ReadBatch.synthetic(0, n, n, seed=23, len_lo=S, len_hi=S, nrg=R)
+    t = dev.Tables(R, 2 * S)
+    dev.accumulate(b, t)
+    lut, shape = dev.solve_lut(t)
+    src = b
+    if 'pairs' in lay:
+        src = dev.PairBatch.from_reads(b)
+    if 'grouped' in lay:
+        src = dev.group_by_rg(src, R)
+    ctx = dev.context()
+    for restore in ((False, True) if src.seg is not None else (False,)):
+        monkeypatch.setenv('KBBQ_K2_TILE_CHARS', '0')
+        want = dev.apply(src, lut, shape, restore_order=restore)
+        monkeypatch.delenv('KBBQ_K2_TILE_CHARS')
+        got = dev.apply(src, lut, shape, restore_order=restore)
+        assert torch.equal(got, want), (lay, restore)
+        del got, want
+    if n > 1_000_000 or lay != 'rows':
+        return
+    # against the oracle, and the error cases through the path a caller takes (apply on plain rows)
+    seq, cseq, qual, meta = _host(b, n)
+    _, ref = _oracle_run(oracle, seq, cseq, qual, meta, R, S)
+    got = dev.apply(b, lut, shape)[:n].cpu().numpy()
+    assert np.array_equal(got[:, :S].astype(np.int32) - 33, ref[:, :S])
+    k = n // 2
+    bad = dev.ReadBatch.from_host(seq.copy(), qual.copy(), meta, cseq=cseq)
+    row = seq[k].copy(); row[7] = ord('x')
+    bad.seq[k] = torch.from_numpy(row).cuda()
+    with pytest.raises(TypeError):
+        dev.apply(bad, lut, shape)
+    bad = dev.ReadBatch.from_host(seq.copy(), qual.copy(), meta, cseq=cseq)
+    row = qual[k].copy(); row[9] = 33 + 43
+    bad.qual[k] = torch.from_numpy(row).cuda()
+    with pytest.raises(IndexError):
+        dev.apply(bad, lut, shape)
+
+
 @pytest.mark.parametrize('lo,hi,R,packed', [(36, 48, 1, True), (20, 64, 3, True), (100, 150, 1, True), (161, 200, 2, False),
                                             (1, 16, 1, True), (250, 300, 1, False), (161, 208, 2, True), (257, 300, 1, True)])
 def test_apply_with_the_lut_narrowed_to_the_rows_pitch(dev, oracle, lo, hi, R, packed, monkeypatch):

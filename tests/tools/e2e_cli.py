@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 ap = argparse.ArgumentParser(); ap.add_argument('--reads', type=int, default=4_000_000); ap.add_argument('--dir', default='/tmp')
 ap.add_argument('--reps', type=int, default=2); ap.add_argument('--keep', action='store_true')
+ap.add_argument('--modes', default='resident', help='comma-separated: resident, budget=SIZE (KBBQ_DEVICE_BUDGET), sequential (KBBQ_SEQUENTIAL=1), '
+                                                     'pipes (-f <(cat A) <(cat B))')
 a = ap.parse_args()
 import numpy as np, oracle as O
 n = a.reads
@@ -23,20 +25,37 @@ with open(fa, 'wb') as A, open(fb, 'wb') as B:
             rec[:, 14:164] = plane[:, :150]; rec[:, 164] = 10; rec[:, 165] = ord('+'); rec[:, 166] = 10
             rec[:, 167:317] = qual[:, :150]; rec[:, 317] = 10
             rec.tofile(f)
-env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, 'kbbq-py_amd'), KBBQ_TIMING='1')
-for rep in range(a.reps):
-    t0 = time.perf_counter()
-    with open(fo, 'wb') as out:
-        subprocess.run([sys.executable, '-m', 'kbbq.main', 'recalibrate', '-f', fa, fb], env=env, stdout=out, check=True)
-    dt = time.perf_counter() - t0
-    print('rep %d: %d reads, %.3f s wall incl. interpreter start = %.2f Gbases/s; output %d bytes'
-          % (rep, n, dt, n * 150 / dt / 1e9, os.path.getsize(fo)), flush=True)
 import hashlib
-h = hashlib.sha256()
-with open(fo, 'rb') as f:
-    for blk in iter(lambda: f.read(1 << 24), b''):
-        h.update(blk)
-print('output sha256', h.hexdigest()[:16])
+def sha(path):
+    h = hashlib.sha256()
+    with open(path, 'rb') as f:
+        for blk in iter(lambda: f.read(1 << 24), b''):
+            h.update(blk)
+    return h.hexdigest()[:16]
+base_env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, 'kbbq-py_amd'), KBBQ_TIMING='1')
+shas = {}
+for mode in a.modes.split(','):
+    env = dict(base_env)
+    cmd = [sys.executable, '-m', 'kbbq.main', 'recalibrate', '-f', fa, fb]
+    shell = False
+    if mode.startswith('budget='):
+        env['KBBQ_DEVICE_BUDGET'] = mode.split('=', 1)[1]
+    elif mode == 'sequential':
+        env['KBBQ_SEQUENTIAL'] = '1'
+    elif mode == 'pipes':
+        cmd, shell = '%s -m kbbq.main recalibrate -f <(cat %s) <(cat %s)' % (sys.executable, fa, fb), True
+    for rep in range(a.reps):
+        if os.path.exists(fo):
+            os.remove(fo)                    # a fresh output file: truncating 2.5 GB of page cache is the kernel's 0.4 s, not the command's
+        t0 = time.perf_counter()
+        with open(fo, 'wb') as out:
+            subprocess.run(cmd, env=env, stdout=out, check=True, shell=shell, executable='/bin/bash' if shell else None)
+        dt = time.perf_counter() - t0
+        print('%s rep %d: %d reads, %.3f s wall incl. interpreter start = %.2f Gbases/s; output %d bytes'
+              % (mode, rep, n, dt, n * 150 / dt / 1e9, os.path.getsize(fo)), flush=True)
+    shas[mode] = sha(fo)
+    print('%s output sha256 %s' % (mode, shas[mode]), flush=True)
+print('all modes wrote the same bytes:', len(set(shas.values())) == 1)
 for p in (fa, fb, fo):
     if not a.keep:
         os.remove(p)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised campaign of the whole file path: random FASTQ pairs (uniform and ragged-but-sorted lengths, 1..6 read
-groups with and without --infer-rg, corrected file sometimes shorter, sometimes gzip-compressed) through
+groups with and without --infer-rg, corrected file sometimes shorter, sometimes gzip-compressed; resident, streamed within a
+small device budget, or read sequentially like a pipe) through
 kbbq.recalibrate.recalibrate_fastq (C++ reader, slab-wise fill, K1 / K3 / K2 in whatever layouts the path picks, output
 pipeline) against the CPU oracle's text.  Exit code 1 on any difference.  Test infrastructure (uses oracle/)."""
 import argparse, gzip, os, shutil, sys, tempfile, time
@@ -63,6 +64,17 @@ while time.time() < t_end:
         except Exception as e:                                        # noqa: BLE001 -- the oracle refuses: not a case for this campaign
             skipped += 1
             continue
+        # how the path walks the reads: resident (everything on the device between the passes), streamed within a small device
+        # budget (kbbq/_stream.py), or read sequentially like a pipe (fastx.FastqStream; compressed files cannot be)
+        mode = str(rng.choice(['resident', 'budget', 'sequential'] if ga == fa else ['resident', 'budget']))
+        for k in ('KBBQ_DEVICE_BUDGET', 'KBBQ_SEQUENTIAL', 'KBBQ_SEGMENT_BYTES'):
+            os.environ.pop(k, None)
+        if mode != 'resident':
+            os.environ['KBBQ_DEVICE_BUDGET'] = str(int(rng.choice([1 << 20, 3 << 20, 16 << 20])))
+        if mode == 'sequential':
+            os.environ['KBBQ_SEQUENTIAL'] = '1'
+            os.environ['KBBQ_SEGMENT_BYTES'] = str(int(rng.choice([1 << 16, 300000, 1 << 22])))
+        info['mode'] = mode
         got = product(ga, gb, infer, os.path.join(tmp, 'out.fq'))
         if got == want and cases % 8 == 0:
             # the command line as its own process: no torch (kbbq/_hipmem.py), output with -o
