@@ -3,6 +3,7 @@
 // sanitizer on this pool; the host side can, and it is the part that parses untrusted text.
 #include "../../include/kbbq_hip.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -118,9 +119,58 @@ static int run_sam(const char* path)
     return 0;
 }
 
+// the sequential reader (fastq_stream.cpp): file A leads in segments of `seg` bytes, file B follows record for record; every
+// segment is scanned with the state of the ones before it, filled, formatted and closed
+static int run_stream(const char* pa, const char* pb, int infer, size_t seg)
+{
+    kbbq_fastq_stream *sa = nullptr, *sb = nullptr;
+    int rc = kbbq_fastq_stream_open(pa, &sa);
+    if (rc) { printf("stream open A rc=%d (%s)\n", rc, g_err.c_str()); return 0; }
+    if (pb) { rc = kbbq_fastq_stream_open(pb, &sb); if (rc) { printf("stream open B rc=%d (%s)\n", rc, g_err.c_str()); kbbq_fastq_stream_close(sa); return 0; } }
+    std::string rgs; int nrg = 0; int64_t longest = 0, total = 0, segs = 0, usable_all = 0; bool b_ended = pb == nullptr;
+    for (;;) {
+        kbbq_fastq *a = nullptr, *b = nullptr; int end = 0;
+        if (sb && !b_ended) (void)kbbq_fastq_stream_prefetch(sb, seg);
+        rc = kbbq_fastq_stream_next(sa, seg, 0, &a, &end);
+        if (rc) { printf("stream next A rc=%d (%s)\n", rc, g_err.c_str()); break; }
+        if (!a) break;
+        const int64_t n = kbbq_fastq_count(a);
+        if (sb && !b_ended) {
+            rc = kbbq_fastq_stream_next(sb, seg, n, &b, nullptr);
+            if (rc) { printf("stream next B rc=%d (%s)\n", rc, g_err.c_str()); kbbq_fastq_close(a); break; }
+            if (!b || kbbq_fastq_count(b) < n) b_ended = true;
+        }
+        (void)kbbq_fastq_set_rg_names(a, rgs.data(), nrg);
+        int64_t info[5] = {0, 0, 0, 0, 0};
+        rc = kbbq_fastq_scan_next(a, (pb && b) ? b : nullptr, infer, longest, info);
+        if (rc) { printf("stream scan rc=%d (%s)\n", rc, g_err.c_str()); kbbq_fastq_close(a); if (b) kbbq_fastq_close(b); break; }
+        rgs.clear(); nrg = kbbq_fastq_rg_count(a);
+        for (int i = 0; i < nrg; ++i) { rgs += kbbq_fastq_rg_name(a, i); rgs.push_back('\0'); }
+        longest = std::max<int64_t>(longest, info[1]);
+        const int64_t m = info[0];
+        const int pitch = (int)std::max<int64_t>(16, (info[1] + 15) / 16 * 16);
+        std::vector<uint8_t> seq((size_t)m * pitch + 1), cseq((size_t)m * pitch + 1), qual((size_t)m * pitch + 1);
+        std::vector<uint32_t> meta((size_t)m + 1);
+        rc = kbbq_fastq_fill_range(a, (pb && b) ? b : nullptr, infer, 0, m, pitch, seq.data(), (pb && b) ? cseq.data() : nullptr, qual.data(), meta.data());
+        const int64_t need = -kbbq_fastq_format(a, 0, m, pitch, qual.data(), nullptr, 0);
+        std::vector<char> out((size_t)need + 1);
+        const int64_t got = kbbq_fastq_format(a, 0, m, pitch, qual.data(), out.data(), need);
+        if (rc || got != need) printf("stream fill rc=%d bytes=%lld/%lld\n", rc, (long long)got, (long long)need);
+        total += n; usable_all += m; ++segs;
+        kbbq_fastq_close(a); if (b) kbbq_fastq_close(b);
+        if (info[3]) { printf("stream first offender kind=%lld at %lld\n", (long long)info[3], (long long)(total - n + info[4])); break; }
+        if (end) break;
+    }
+    printf("stream records=%lld usable=%lld segments=%lld S=%lld R=%d\n", (long long)total, (long long)usable_all, (long long)segs, (long long)longest, nrg);
+    kbbq_fastq_stream_close(sa); if (sb) kbbq_fastq_stream_close(sb);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) return 2;
+    if (!strcmp(argv[1], "stream")) return run_stream(argv[2], argc > 3 && strcmp(argv[3], "-") ? argv[3] : nullptr, argc > 4 ? atoi(argv[4]) : 0,
+                                                      argc > 5 ? (size_t)atoll(argv[5]) : (size_t)1 << 16);
     if (!strcmp(argv[1], "sam")) return run_sam(argv[2]);
     if (!strcmp(argv[1], "pair")) return run_pair(argv[2], argc > 3 && strcmp(argv[3], "-") ? argv[3] : nullptr, argc > 4 ? atoi(argv[4]) : 0);
     if (!strcmp(argv[1], "combiln")) {

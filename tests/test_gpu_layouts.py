@@ -280,7 +280,8 @@ def test_short_lived_k2_on_character_planes(dev, oracle, n, S, R, lay, monkeypat
     assert np.array_equal(got[:, :S].astype(np.int32) - 33, ref[:, :S])
     k = n // 2
     bad = dev.ReadBatch.from_host(seq.copy(), qual.copy(), meta, cseq=cseq)
-    row = seq[k].copy(); row[7] = ord('x')
+    at = int(np.flatnonzero(qual[k, 1:S] >= 33 + 6)[0]) + 1                 # a looked-up position (compare_reads.py:288-292: q[i] >= minscore)
+    row = seq[k].copy(); row[at] = ord('x')
     bad.seq[k] = torch.from_numpy(row).cuda()
     with pytest.raises(TypeError):
         dev.apply(bad, lut, shape)

@@ -17,8 +17,8 @@ def harness(tmp_path_factory):
     csrc = os.path.join(ROOT, 'kbbq-py_amd', 'csrc')
     cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-pthread',
            '-o', exe, os.path.join(ROOT, 'tests', 'native', 'host_sanitize.cpp'),
-           os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'solve_host.cpp'), os.path.join(csrc, 'sam_host.cpp'),
-           os.path.join(csrc, 'bam_host.cpp'), '-lz']
+           os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'fastq_stream.cpp'), os.path.join(csrc, 'solve_host.cpp'),
+           os.path.join(csrc, 'sam_host.cpp'), os.path.join(csrc, 'bam_host.cpp'), '-lz']
     subprocess.check_call(cmd)
 
     def run(*args):
@@ -52,6 +52,13 @@ def test_wellformed_pairs(harness, oracle, tmp_path):
     assert 'job rc=0 n=%d' % n in out and out.split('job ')[1].split('\n')[0].split(' ', 1)[1].startswith(out.split('scan ')[1].split('\n')[0].split(' ', 1)[1])
     out = harness('pair', fa, '-', '0')
     assert 'scan rc=0' in out
+    # the sequential reader over the same pair, in segments of 64 KB and of everything at once: the same file-wide facts
+    want = out_pair = harness('pair', fa, fb, '1')
+    S = int(want.split('scan rc=0 n=%d S=' % n)[1].split()[0])
+    for seg in ('65536', '300000', '1000000000'):
+        out = harness('stream', fa, fb, '1', seg)
+        assert 'stream records=%d usable=%d' % (n, n) in out and ' S=%d R=3' % S in out and 'offender' not in out, out
+    assert 'stream records=%d' % n in harness('stream', fa, '-', '0', '70000')
 
 
 def test_malformed_inputs_do_not_touch_memory_they_do_not_own(harness, tmp_path):
@@ -77,6 +84,9 @@ def test_malformed_inputs_do_not_touch_memory_they_do_not_own(harness, tmp_path)
             harness('pair', p, '-', infer)
             harness('pair', p, good, infer)
             harness('pair', good, p, infer)
+            harness('stream', p, '-', infer, '65536')
+            harness('stream', p, good, infer, '65536')
+            harness('stream', good, p, infer, '65536')
     harness('pair', str(tmp_path / 'does_not_exist.fq'), '-', '0')
     # gzip input, intact / truncated / garbage after the magic
     import gzip
@@ -88,6 +98,14 @@ def test_malformed_inputs_do_not_touch_memory_they_do_not_own(harness, tmp_path)
     raw = open(gz, 'rb').read()
     harness('pair', _write(tmp_path / 'cut.fq.gz', raw[:len(raw) // 2], 'wb'), '-', '0')
     harness('pair', _write(tmp_path / 'junk.fq.gz', b'\x1f\x8b' + b'\x00' * 50, 'wb'), '-', '0')
+    assert 'zcat' in harness('stream', str(gz), '-', '0')          # compressed bytes in a sequentially read input: refused with advice
+    # many records in small segments, a follower that ends early, a follower whose records are longer than the leader's
+    many = _write(tmp_path / 'many.fq', ''.join('@r%d/1_RG:Z:g%d\n%s\n+\n%s\n' % (i, i % 5, 'ACGT' * (5 + i // 3000), 'IIII' * (5 + i // 3000)) for i in range(20000)))
+    longer = _write(tmp_path / 'longer.fq', ''.join('@r%d/1_RG:Z:g%d and a long comment %s\n%s\n+\n%s\n' % (i, i % 5, 'x' * 200, 'ACGT' * (5 + i // 3000), 'IIII' * (5 + i // 3000)) for i in range(20000)))
+    assert 'stream records=20000 usable=20000' in harness('stream', many, longer, '1', '65536')
+    short = _write(tmp_path / 'short.fq', ''.join('@r%d/1_RG:Z:g%d\n%s\n+\n%s\n' % (i, i % 5, 'ACGT' * (5 + i // 3000), 'IIII' * (5 + i // 3000)) for i in range(7777)))
+    out = harness('stream', many, short, '1', '65536')
+    assert 'stream records=20000' in out or 'usable=7777' in out
 
 
 def test_gammaln_pool(harness):
@@ -148,8 +166,8 @@ def test_threaded_readers_under_thread_sanitizer(tmp_path, oracle):
     csrc = os.path.join(ROOT, 'kbbq-py_amd', 'csrc')
     cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=thread', '-pthread', '-o', exe,
            os.path.join(ROOT, 'tests', 'native', 'host_sanitize.cpp'),
-           os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'solve_host.cpp'), os.path.join(csrc, 'sam_host.cpp'),
-           os.path.join(csrc, 'bam_host.cpp'), '-lz']
+           os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'fastq_stream.cpp'), os.path.join(csrc, 'solve_host.cpp'),
+           os.path.join(csrc, 'sam_host.cpp'), os.path.join(csrc, 'bam_host.cpp'), '-lz']
     if subprocess.run(cmd, capture_output=True).returncode != 0:
         pytest.skip('this g++ cannot link -fsanitize=thread')
     n = 20000
@@ -163,7 +181,7 @@ def test_threaded_readers_under_thread_sanitizer(tmp_path, oracle):
     import bamwriter
     bam = bamwriter.write_bam(tmp_path / 't.bam', open(sam).read())
     env = dict(os.environ, KBBQ_HOST_THREADS='6', KBBQ_SCAN_CHUNK='501', TSAN_OPTIONS='halt_on_error=0')
-    for args in (['pair', fa, fb, '1'], ['pair', fa, '-', '0'], ['combiln'], ['sam', sam], ['sam', bam]):
+    for args in (['pair', fa, fb, '1'], ['pair', fa, '-', '0'], ['stream', fa, fb, '1', '2000000'], ['combiln'], ['sam', sam], ['sam', bam]):
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=env)
         assert 'ThreadSanitizer' not in r.stderr, r.stderr[-3000:]
         assert r.returncode == 0, (args, r.returncode, r.stderr[-2000:])
