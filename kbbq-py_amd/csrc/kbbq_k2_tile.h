@@ -144,7 +144,18 @@ __device__ __forceinline__ void k2t_body(const K2tParams& p, u32* lds, const int
             const uint4 sv = *reinterpret_cast<const uint4*>(p.seq + 16 * cc);
             sq[s][0] = sv.x; sq[s][1] = sv.y; sq[s][2] = sv.z; sq[s][3] = sv.w;
         }
+#ifdef KBBQ_Q6_PROBE
+        // TIMING ONLY (wrong results): what would K2 gain from qualities packed 16 to 12 bytes?  The loads and the unpacking work of
+        // such a plane (three words of 6-bit fields + the fourth word's fields in their spare bit pairs), on whatever bytes lie there
+        uint4 qv;
+        {
+            const uint3 q3 = *reinterpret_cast<const uint3*>(p.qual + 12 * cc);
+            qv.x = (q3.x & 0x1F1F1F1Fu) + 0x27272727u; qv.y = (q3.y & 0x1F1F1F1Fu) + 0x27272727u; qv.z = (q3.z & 0x1F1F1F1Fu) + 0x27272727u;
+            qv.w = (((q3.x >> 6) & 0x03030303u) | ((q3.y >> 4) & 0x0C0C0C0Cu) | ((q3.z >> 2) & 0x10101010u)) + 0x27272727u;
+        }
+#else
         const uint4 qv = *reinterpret_cast<const uint4*>(p.qual + 16 * cc);
+#endif
         ql[s][0] = qv.x; ql[s][1] = qv.y; ql[s][2] = qv.z; ql[s][3] = qv.w;
         const u32 rel = rem0 + (u32)(cc - base_c);                    // < cpr + 64 * K2T_STEPS
         mk[s] = p.meta[row0 + __umulhi(rel, p.cpr_magic)];

@@ -383,7 +383,16 @@ __device__ __forceinline__ void k1v3_body(const K1v3Params& p, u32* lds, const i
                     ch.s[0] = sv.x; ch.s[1] = sv.y; ch.s[2] = sv.z; ch.s[3] = sv.w;
                     ch.c[0] = cv.x; ch.c[1] = cv.y; ch.c[2] = cv.z; ch.c[3] = cv.w;
                 }
+#ifdef KBBQ_Q6_PROBE
+                uint4 qv;                                            // TIMING ONLY (wrong results): see kbbq_k2_tile.h
+                {
+                    const uint3 q3 = *reinterpret_cast<const uint3*>(bqual + ((rowoff >> 2) * 3u));
+                    qv.x = (q3.x & 0x1F1F1F1Fu) + 0x27272727u; qv.y = (q3.y & 0x1F1F1F1Fu) + 0x27272727u; qv.z = (q3.z & 0x1F1F1F1Fu) + 0x27272727u;
+                    qv.w = (((q3.x >> 6) & 0x03030303u) | ((q3.y >> 4) & 0x0C0C0C0Cu) | ((q3.z >> 2) & 0x10101010u)) + 0x27272727u;
+                }
+#else
                 const uint4 qv = *reinterpret_cast<const uint4*>(bqual + rowoff);
+#endif
                 ch.q[0] = qv.x; ch.q[1] = qv.y; ch.q[2] = qv.z; ch.q[3] = qv.w;
             };
             auto process = [&](const K1Chunk& ch) {

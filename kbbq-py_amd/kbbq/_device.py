@@ -95,9 +95,19 @@ def warm_up(device=0):
         batch = ReadBatch.synthetic(0, 128, 128, seed=1)
         tables = Tables(1, 2 * 150)
         accumulate(batch, tables)
-        lut, shape = solve_lut(tables)            # also proves (once per process) the device's gammaln against the host's
-        apply(batch, lut, shape).cpu()
-        torch.cuda.synchronize()
+        if torch.__name__ != 'torch' and device not in _logtabs and not os.environ.get('KBBQ_HOST_SOLVE'):
+            # the command line without torch: the proof of the device's gammaln against the host's (1.3 M arguments, ~40 ms) is not
+            # needed before the first solve -- it runs on a thread of its own while the packer fills and uploads the reads
+            # (device_logtab() joins it); the first launches above have loaded the library's code object
+            import threading
+            job = threading.Thread(target=_prove_logtab, args=(device,), daemon=True)
+            _logtab_jobs[device] = job
+            job.start()
+            torch.cuda.synchronize()
+        else:
+            lut, shape = solve_lut(tables)        # also proves (once per process) the device's gammaln against the host's
+            apply(batch, lut, shape).cpu()
+            torch.cuda.synchronize()
     _warm = True
 
 
@@ -840,6 +850,16 @@ def delta_q(prior_q, numerrs, numtotal):
 
 
 _logtabs = {}            # device index -> the host libm's log() constants on the device, or None (host pass in use)
+_logtab_jobs = {}        # device index -> the thread that is establishing _logtabs[device] (warm_up)
+
+
+def _prove_logtab(device):
+    try:
+        torch = _torch()
+        with torch.cuda.device(device):
+            _logtab_check(device)
+    except Exception:                        # noqa: BLE001 -- no proof: the solve keeps its host pass
+        _logtabs[device] = None
 _solve_bufs = {}
 
 
@@ -861,8 +881,18 @@ def device_logtab(device=None):
     torch = _torch()
     if device is None:
         device = torch.cuda.current_device()
+    job = _logtab_jobs.pop(device, None)
+    if job is not None:                      # started by warm_up(): wait for its verdict
+        job.join()
     if device in _logtabs:
         return _logtabs[device]
+    return _logtab_check(device)
+
+
+def _logtab_check(device):
+    """The check itself (device_logtab's docstring); records and returns its verdict."""
+    import os
+    torch = _torch()
     tab = None
     if not os.environ.get('KBBQ_HOST_SOLVE'):
         lib = N.load()

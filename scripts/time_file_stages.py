@@ -7,7 +7,13 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'kbbq-py_amd'))
 import numpy as np
-import torch
+NATIVE = '--native' in sys.argv          # device memory from the library's own C ABI (kbbq/_hipmem.py), as the command line without torch
+if NATIVE:
+    sys.argv.remove('--native')
+    from kbbq import _device as dev
+    dev.use_native_memory()
+else:
+    import torch
 from kbbq import _device as dev, recalibrate, _trace
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
 tmp = os.environ.get('TMPDIR', '/tmp')
@@ -53,11 +59,17 @@ def run(label, env, reps=3):
             else:
                 os.environ[k] = v
     wall, st = best
+    if NATIVE:
+        label += ' [native memory]'
     print('%-34s wall %.3f s = %.2f Gbases/s   %s' % (label, wall, n * 150 / wall / 1e9, '  '.join('%s %.3f' % kv for kv in st.items())), flush=True)
     return wall
 
 
 try:
+    if NATIVE:
+        for rep in range(3):             # every repetition on its own line: is `apply` (40 ms in the command line) a first-call cost?
+            run('repetition %d' % rep, {}, reps=1)
+        raise SystemExit(0)
     base = run('16 threads (default)', {})
     for t in ('8', '4'):
         run('%s threads' % t, {'KBBQ_HOST_THREADS': t})
