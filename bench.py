@@ -636,17 +636,62 @@ def extra_file_path(torch, dev, n=8_000_000):
             os.close(fd)
             os.close(saved)
         size = os.path.getsize(fo)
+        bands = list(recalibrate.LAST_RUN.get('bands', []))
+        # the same files in constant device memory (kbbq/_stream.py: 256 MB of slabs instead of the whole shard) and through two
+        # pipes (`-f <(cat A) <(cat B)`: sequential segments, file A spooled for pass 2) -- round 4; the bytes are compared
+        import hashlib
+
+        def digest(path):
+            h = hashlib.sha256()
+            with open(path, 'rb') as fh:
+                for blk in iter(lambda: fh.read(1 << 24), b''):
+                    h.update(blk)
+            return h.hexdigest()
+        want = digest(fo)
+        other = {}
+        for key, env, pipes in (('streamed_256M', {'KBBQ_DEVICE_BUDGET': '256M'}, False), ('pipes', {}, True)):
+            os.remove(fo)
+            saved_env = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            feeders, inputs = [], [fa, fb]
+            try:
+                if pipes:
+                    inputs = [os.path.join(tmp, 'kbbq_bench_%d_fifo_%s' % (os.getpid(), x)) for x in 'ab']
+                    for src, fifo in zip((fa, fb), inputs):
+                        os.mkfifo(fifo)
+                        feeders.append(subprocess.Popen('cat %s > %s' % (src, fifo), shell=True))
+                _trace.collect(True)
+                t0 = time.perf_counter()
+                recalibrate.recalibrate_fastq(inputs, output=fo)
+                w = time.perf_counter() - t0
+                other[key] = {'wall_s': w, 'value': n * READ_LEN / w, 'unit': 'bases/s', 'stages_s': _trace.collect(False),
+                              'same_bytes_as_resident': digest(fo) == want, 'run': dict(recalibrate.LAST_RUN.get('streamed') or {})}
+            except Exception as e:                # noqa: BLE001
+                _trace.collect(False)
+                other[key] = {'error': '%s: %s' % (type(e).__name__, e)}
+            finally:
+                for f in feeders:
+                    f.wait()
+                for k, v in saved_env.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+                if pipes:
+                    for fifo in inputs:
+                        if os.path.exists(fifo):
+                            os.remove(fifo)
     finally:
         for p in (fa, fb, fo):
             if os.path.exists(p):
                 os.remove(p)
     bases = n * READ_LEN
-    bands = list(recalibrate.LAST_RUN.get('bands', []))
     return {'workload': '%d synthetic 2x150 bp reads as two FASTQ files (%.1f GB each) -> recalibrated FASTQ file (%.1f GB), '
                         'in-process, device warm' % (n, n * 318 / 1e9, size / 1e9),
             'value': bases / wall, 'unit': 'bases/s', 'wall_s': wall, 'stages_s': stages, 'bands': bands,
             'h2d_bytes_per_base': sum(b['h2d_bytes'] for b in bands) / bases if bands else None,
-            'input_written_in_s': write_s}
+            'input_written_in_s': write_s,
+            'streamed_within_256MB_of_device_memory': other.get('streamed_256M'), 'through_two_pipes': other.get('pipes')}
 
 
 def build_extra(torch, dev, parallel, args, headline_layout):

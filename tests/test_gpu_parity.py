@@ -760,6 +760,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields(dev):
     # the file path uploads the layout of the headline, written by the packer: 2 B/base, no layout pass, no unpack
     assert 'layout' not in extra['file_path']['stages_s'] and 2.0 <= extra['file_path']['h2d_bytes_per_base'] < 2.1
     assert all('mate-pair rows' in b['layout'] and '4-bit' in b['layout'] and 'kbbq_fastq_fill_rows' in b['written_by'] for b in extra['file_path']['bands'])
+    # round 4: the same files within 256 MB of device memory and through two pipes -- the same bytes
+    st, pp = extra['file_path']['streamed_within_256MB_of_device_memory'], extra['file_path']['through_two_pipes']
+    assert st['same_bytes_as_resident'] is True and pp['same_bytes_as_resident'] is True, (st, pp)
+    assert pp['run']['sequential'] and pp['run']['spooled'] and st['value'] > 1e6
     assert extra['config3_8rg']['verified'] is True and extra['single_end_150']['verified'] is True
     assert extra['from_input_order_rows']['ms_per_step'] == extra['layout_reads']['ms_per_step']
 
