@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/pmc_traffic.json from FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc, one counter per pass, scripts/gpu_pmc_r2.sh):
+"""profiles/pmc_traffic.json from FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc, one counter per pass, scripts/gpu_job.sh pmc):
 HBM bytes per base of K1 / K2 for every device layout, keyed to the kernel source they were taken on (bench.py prints
 `traffic` only when its own kernel_source_sha matches)."""
 import collections, csv, glob, json, os, sys
@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import bench
 root, reads, readlen = sys.argv[1], int(sys.argv[2]), 150
 bases = reads * readlen
-out = {'_comment': 'HBM bytes per base from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scripts/gpu_pmc_r2.sh), %d reads x %d bp '
+out = {'_comment': 'HBM bytes per base from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scripts/gpu_job.sh pmc), %d reads x %d bp '
                    'per launch; FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of coalesced streaming reads at 64 bytes, '
                    'MI355X_MICROARCH.md HBM section); both counters are in KiB.  Layout keys: bench.py layout_key().' % (reads, readlen),
        'kernel_source_sha': bench.kernel_source_sha(), 'bases_per_launch_measured': bases}

@@ -19,7 +19,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
 tmp = os.environ.get('TMPDIR', '/tmp')
 fa, fb, fo = (os.path.join(tmp, 'kbbq_stages_%d_%s.fq' % (os.getpid(), x)) for x in 'abo')
 batch = dev.ReadBatch.synthetic(0, n, n, seed=1)
-seq, cseq, qual = (getattr(batch, p)[:n, :150].cpu().numpy() for p in ('seq', 'cseq', 'qual'))
+seq, cseq, qual = (getattr(batch, p).cpu().numpy()[:n, :150] for p in ('seq', 'cseq', 'qual'))
 del batch
 for path, plane in ((fa, seq), (fb, cseq)):
     rec = np.empty((n, 318), dtype=np.uint8)
