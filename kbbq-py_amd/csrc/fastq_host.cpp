@@ -60,6 +60,52 @@ template <typename F> static void parallel_for(int64_t n, unsigned nt, F f)
     kbbq_parallel_parts((size_t)n, nt, [&](unsigned, size_t lo, size_t hi) { f((int64_t)lo, (int64_t)hi); });     // parked workers (host_threads.h)
 }
 
+// A FASTQ file whose sequences and qualities run over several lines, as kseq (pysam.FastxFile) reads it: a record starts at a line
+// beginning with '@' (name up to the first whitespace, the rest is the comment); sequence lines follow until a line that begins with
+// '+'; quality lines follow until they hold at least as many characters as the sequence -- exactly as many, or the file is refused.
+// Only printable characters of a sequence / quality line count.  `out` receives the same records four lines each.  False when the
+// text is not such a file (no record at all, a record without '+' line, qualities of another length).
+static bool unwrap_fastq(const uint8_t* buf, size_t size, std::vector<uint8_t>& out)
+{
+    out.clear();
+    out.reserve(size + 16);
+    size_t at = 0, records = 0;
+    auto line_end = [&](size_t from) { const void* q = memchr(buf + from, '\n', size - from); return q ? (size_t)((const uint8_t*)q - buf) : size; };
+    auto graph = [](uint8_t c) { return c > 32 && c < 127; };
+    while (at < size) {
+        while (at < size && (buf[at] == '\n' || buf[at] == '\r')) ++at;              // blank lines between records
+        if (at >= size) break;
+        if (buf[at] != '@') return false;
+        size_t e = line_end(at);
+        size_t he = e; while (he > at && buf[he - 1] == '\r') --he;
+        out.insert(out.end(), buf + at, buf + he); out.push_back('\n');
+        at = e < size ? e + 1 : size;
+        const size_t seq_at = out.size();
+        bool plus = false;
+        while (at < size) {                                                           // sequence lines up to the '+' line
+            if (buf[at] == '+') { plus = true; break; }
+            e = line_end(at);
+            for (size_t i = at; i < e; ++i) if (graph(buf[i])) out.push_back(buf[i]);
+            at = e < size ? e + 1 : size;
+        }
+        if (!plus) return false;
+        const size_t seqlen = out.size() - seq_at;
+        if (seqlen > 65535) return false;
+        at = line_end(at); at = at < size ? at + 1 : size;                            // the rest of the '+' line is ignored
+        out.push_back('\n'); out.push_back('+'); out.push_back('\n');
+        const size_t q_at = out.size();
+        while (at < size && out.size() - q_at < seqlen) {                             // quality lines until the sequence's length is reached
+            e = line_end(at);
+            for (size_t i = at; i < e; ++i) if (graph(buf[i])) out.push_back(buf[i]);
+            at = e < size ? e + 1 : size;
+        }
+        if (out.size() - q_at != seqlen) return false;
+        out.push_back('\n');
+        ++records;
+    }
+    return records > 0;
+}
+
 int kbbq_fastq_index_range_(kbbq_fastq* f, size_t r0, size_t r1)
 {
     // Line index, in parallel and without a merged list of line ends: (1) every thread collects the '\n' offsets of
@@ -172,7 +218,19 @@ static int open_impl(const char* path, int64_t range_lo, int64_t range_hi, kbbq_
     if ((r0 > 0 && f->buf[r0 - 1] != '\n') || (r1 < f->size && r1 > r0 && f->buf[r1 - 1] != '\n')) {
         delete f; return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": the byte range does not start / end at a line end").c_str());
     }
-    const int bad = kbbq_fastq_index_range_(f, r0, r1);
+    int bad = kbbq_fastq_index_range_(f, r0, r1);
+    if (bad && bad != 3 && whole) {
+        // not four lines per record: a WRAPPED file (sequence and quality over several lines each), which pysam's reader -- kseq --
+        // accepts (recalibrate.py:56)?  Unwrap it into memory of our own and index that; anything kseq would not take keeps the error.
+        std::vector<uint8_t> flat;
+        if (unwrap_fastq(f->buf, f->size, flat)) {
+            if (f->mapped && f->buf) munmap((void*)f->buf, f->size);
+            f->owned.swap(flat);
+            f->buf = f->owned.data(); f->size = f->owned.size(); f->mapped = false;
+            f->h0.clear(); f->s0.clear(); f->q0.clear(); f->hlen.clear(); f->slen.clear();
+            bad = kbbq_fastq_index_range_(f, 0, f->size);
+        }
+    }
     if (bad) {
         delete f;
         return kbbq_set_error_(KBBQ_E_ARG, bad == 4 ? (std::string(path) + ": not a 4-line-per-record FASTQ file").c_str()

@@ -219,3 +219,16 @@ def test_two_ranks_stream_their_shards(dev, oracle, tmp_path):
     # sequentially read inputs cannot be cut into byte ranges: refused, not mis-read
     r = _run_ranks(2, ['recalibrate', '-f', fa, fb], env={'KBBQ_SEQUENTIAL': '1'})
     assert r.returncode != 0 and b'single process' in r.stderr
+
+
+def test_wrapped_fastq_through_the_command_line(dev, oracle, tmp_path):
+    """A FASTQ pair whose sequence and quality lines are wrapped at 70 characters (kseq / pysam.FastxFile reads such files,
+    recalibrate.py:56): the command line prints the golden, records four lines each as the reference prints them."""
+    from test_host_logic import _wrapped
+    info, _ = load_golden('c1_10k_1rg')
+    fa, fb = _files(oracle, info, tmp_path)
+    wa, wb = str(tmp_path / 'wa.fq'), str(tmp_path / 'wb.fq')
+    _wrapped(fa, wa, 70, plus_name=True); _wrapped(fb, wb, 70)
+    r = _cli([sys.executable, '-m', 'kbbq.main', 'recalibrate', '-f', wa, wb])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert len(r.stdout) == info['output_len'] and oracle.sha256(r.stdout) == info['output_sha256']

@@ -935,3 +935,44 @@ def test_sequential_reader_hands_out_whole_records(oracle, tmp_path):
     p = str(tmp_path / 'g.fq.gz'); gzip.open(p, 'wb').write(whole)
     with pytest.raises(ValueError, match='zcat'):
         fastx.FastqStream(p).next(1 << 20)
+
+
+def _wrapped(path_in, path_out, width, plus_name=False):
+    """The same records with sequence and quality lines wrapped at `width` characters (and the name repeated on the '+' line)."""
+    recs = open(path_in).read().split('\n')
+    out = []
+    for i in range(0, len(recs) - 3, 4):
+        h, s_, _, q = recs[i:i + 4]
+        out.append(h)
+        out += [s_[k:k + width] for k in range(0, max(len(s_), 1), width)]
+        out.append('+' + (h[1:] if plus_name else ''))
+        out += [q[k:k + width] for k in range(0, max(len(q), 1), width)]
+    open(path_out, 'w').write('\n'.join(out) + '\n')
+
+
+def test_wrapped_fastq_reads_like_four_line_fastq(oracle, tmp_path):
+    """Sequence and quality over several lines each (what kseq / pysam.FastxFile accepts, recalibrate.py:56): the mapped reader
+    unwraps such a file and packs the same planes, sidecars and names as from the four-line file -- quality lines that begin
+    with '@' or '+' included; what kseq refuses stays refused with the four-line reader's message."""
+    n = 2000
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 6, 36, 150, 3)
+    order = np.argsort(meta & 0xFFFF, kind='stable')
+    seq, cseq, qual, meta = seq[order], cseq[order], qual[order], meta[order]
+    qual[5, 0] = ord('@'); qual[6, 0] = ord('+'); qual[7, 60] = ord('@')          # '@' = Q31, '+' = Q10: legal qualities at line starts
+    names = oracle.synth_names(0, n, 3, with_rg=True)
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    oracle.write_fastq(fb, names, cseq, qual, meta)
+    want = fastx.pack_pair(fa, fb, True)
+    for width, plus_name in ((60, False), (7, True), (1000, True)):
+        wa, wb = str(tmp_path / ('wa%d.fq' % width)), str(tmp_path / ('wb%d.fq' % width))
+        _wrapped(fa, wa, width, plus_name); _wrapped(fb, wb, width, plus_name)
+        got = fastx.pack_pair(wa, wb, True)
+        assert (got['n'], got['S'], got['R'], got['rg_to_int']) == (want['n'], want['S'], want['R'], want['rg_to_int'])
+        for k in ('seq', 'cseq', 'qual', 'meta'):
+            assert np.array_equal(got[k], want[k]), (width, k)
+        assert got['text'].format(0, n, got['qual']) == open(fa, 'rb').read()             # records leave as four lines
+    for text in ('@r1\nACGT\nAC\n+\nIIII\n', '@r1\nACGT\nACGT\n', '@r1\nAC\nGT\n+\nIIIII\nI\n', 'x\n@r1\nAC\nGT\n+\nII\nII\n'):
+        p = str(tmp_path / 'bad.fq'); open(p, 'w').write(text)
+        with pytest.raises(ValueError):
+            fastx.NativeFastq(p)

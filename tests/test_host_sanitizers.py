@@ -76,6 +76,13 @@ def test_malformed_inputs_do_not_touch_memory_they_do_not_own(harness, tmp_path)
         'rg_not_rg': '@r1/1_XX:Z:a\nACGT\n+\nIIII\n',
         'binary': '@r\x00\x01\nAC\xff\xfe\n+\n\x00\x7f\x80\xff\n',
         'huge_name': '@' + 'n' * 100000 + '_RG:Z:' + 'g' * 70000 + '\nACGT\n+\nIIII\n',
+        # wrapped records (the unwrapping pass of the mapped reader), good and bad
+        'wrapped': '@r1/1_RG:Z:a c\nACGT\nAC\n+r1\nII\nIIII\n@r2/2_RG:Z:a\nACGTAC\n+\n@IIII\nI\n',
+        'wrapped_short_quality': '@r1\nACGT\nACGT\n+\nIIII\nII\n',
+        'wrapped_no_plus': '@r1\nACGT\nACGT\nACGT\n',
+        'wrapped_long_quality': '@r1\nAC\nGT\n+\nIIIII\nIII\n',
+        'wrapped_ends_in_sequence': '@r1\nACGT\nAC\n+\nIIIIII\n@r2\nAC',
+        'wrapped_crlf': '@r1\r\nACGT\r\nAC\r\n+\r\nIII\r\nIII\r\n',
     }
     good = _write(tmp_path / 'good.fq', '@r1/1_RG:Z:a\nACGT\n+\nIIII\n@r2/2_RG:Z:a\nACGT\n+\nIIII\n')
     for name, text in cases.items():
