@@ -513,7 +513,7 @@ def lay_out(batch, R, S=None, packed=True, pairs=None, stats=None):
 
 
 def laid_from_reader(text, other, infer_rg_flag, first, n, pitch, R, packed=True, pairs=None, slab=1 << 17, device=None, pair_S=None,
-                     keep_pinned=False):
+                     keep_pinned=False, with_out=False):
     """Reads [first, first + n) of a fastx.NativeFastq (and their corrections from `other`, or None) onto the device IN
     THE LAYOUT lay_out() would give them -- written by the C++ packer itself (kbbq_fastq_fill_rows): mate-pair rows, 4-bit
     sequence planes, rows gathered by read-group segment, decided from the sidecar statistics of the text (kbbq_fastq_meta)
@@ -546,6 +546,8 @@ def laid_from_reader(text, other, infer_rg_flag, first, n, pitch, R, packed=True
             laid.read_pitch, laid.twins = pitch, bool(flags & N.ROWS_TWINS)
         else:
             laid = ReadBatch(n, pitch, with_corrected=other is not None, device=device, nib=nib)
+        if with_out:                         # the output plane's first-use wipe passes behind the fill (_take_out_plane)
+            laid.out_plane = torch.empty_like(laid.qual)
         dp = laid.pitch
         sp = dp // 2 if nib else dp
         nseq = 2 if other is not None else 1
@@ -684,6 +686,18 @@ def _band_array(items, outs=None, pluts=None, restore_order=False):
     return arr
 
 
+def _take_out_plane(batch):
+    """The plane K2 writes a batch's new qualities into: the one the file path allocated beside the input planes while the packer
+    was still filling them (laid_from_reader: device memory is wiped by the driver before its first use -- 1.2 GB at ~30 GB/s is
+    the 40 ms the command line's first apply used to wait -- and that wait now passes behind the host's fill), else a fresh one."""
+    torch = _torch()
+    out = getattr(batch, 'out_plane', None)
+    if out is not None:
+        batch.out_plane = None               # handed over once: the egress pipeline releases it slab by slab
+        return out
+    return torch.empty_like(batch.qual)
+
+
 def accumulate_bands(items, tables, minscore=MINSCORE, check=True, dinuc_minscore=None):
     """K1 over ALL length bands of a mixed-length input in one launch (kbbq_accumulate_bands_dev: every band on its share of
     the workgroups, with its own pitch and LDS geometry), adding into `tables`.  items: [(batch, s_band, s_min)] as
@@ -716,7 +730,7 @@ def apply_bands(items, lut_dev, shape, outs=None, minscore=MINSCORE, check=True,
     ctx = context(dev_.index)
     lib = N.load()
     if outs is None:
-        outs = [torch.empty_like(b.qual) for b, _, _ in items]
+        outs = [_take_out_plane(b) for b, _, _ in items]
     pluts = []
     for batch, _, _ in items:
         plut = None
@@ -764,7 +778,7 @@ def apply(batch, lut_dev, shape, out=None, minscore=MINSCORE, check=True, restor
     R, Qt, S2, mode = shape
     ctx = context(batch.seq.device.index)
     if out is None:
-        out = torch.empty_like(batch.qual)
+        out = _take_out_plane(batch)
     pairs = isinstance(batch, PairBatch)
     grouped = batch.seg is not None
     if pairs or grouped or batch.nib:

@@ -525,7 +525,8 @@ def _fill_bands(A, B, infer_rg_flag, lo, hi, to_device=False, R=1, S=None):
             band['source'] = (A, B, infer_rg_flag, lo + b_lo)
             band['batch'] = None
             band['laid'] = dev.laid_from_reader(A, B, infer_rg_flag, lo + b_lo, b_hi - b_lo, pitch, max(R, 1),
-                                                packed=longest <= dev.PACKED_READS, pairs=None if S in (None, longest) else False)
+                                                packed=longest <= dev.PACKED_READS, pairs=None if S in (None, longest) else False,
+                                                with_out=True)
             if band['laid'] is None:
                 band_rows(band)
         else:

@@ -13,6 +13,7 @@
 #   py=SCRIPT[::ARGS] python SCRIPT ARGS  (timing scripts under scripts/ and tests/tools/)
 #   prof=NAME::CMD    rocprofv3 --kernel-trace --stats of CMD (a python command line), summary copied to gpurun_out/prof_NAME_TAG/
 #   pmc[=table]       FETCH_SIZE / WRITE_SIZE passes of K1 / K2 on every layout -> profiles/pmc_traffic.json (+ the counter table of the bench layout)
+#   clitrace          which kernels `kbbq recalibrate -f` launches (tests/tools/trace_cli.sh: rocprofv3 kernel trace of the command line)
 #   evidence          bench.py as the driver runs it + rocprofv3 --kernel-trace --stats of the same command (with and without `extra`)
 TAG=$1; shift
 mkdir -p gpurun_out
@@ -81,6 +82,7 @@ for step in "$@"; do
                && cp $(find gpurun_out/stats_$TAG -name 's_kernel_trace.csv' | head -1) gpurun_out/bench_kernel_trace_$TAG.csv \
                && cp $(find gpurun_out/stats_${TAG}_extra -name 's_kernel_stats.csv' | head -1) gpurun_out/bench_with_extra_kernel_stats_$TAG.csv \
                && find gpurun_out/stats_$TAG gpurun_out/stats_${TAG}_extra -name '*.db' -delete 2> /dev/null; head -8 gpurun_out/bench_kernel_stats_$TAG.csv ;;
+    clitrace)  run clitrace 600 bash tests/tools/trace_cli.sh $TAG ;;
     *)         echo "unknown step $step"; false ;;
   esac || { echo "job stopped at $step"; exit 1; }
 done

@@ -1,4 +1,4 @@
-# usage (GPU box): bash scripts/gpu_trace_cli.sh TAG -- rocprofv3 kernel trace of `kbbq recalibrate -f A B --infer-rg` on an 8-read-group input:
+# usage (GPU box): bash tests/tools/trace_cli.sh TAG (test infrastructure: its input files come from the oracle's generator) -- rocprofv3 kernel trace of `kbbq recalibrate -f A B --infer-rg` on an 8-read-group input:
 # which kernels does the product path launch?
 TAG=${1:-cli}
 R=$GRAFT_REPO_ROOT
