@@ -16,7 +16,10 @@
  *     with kbbq_ctx_status() (which synchronises).
  *   - host-pointer functions (no suffix) stage through device memory owned by
  *     the context and synchronise before returning.
- *   - one context per device; a context is not thread-safe.
+ *   - one context per device; a context is not thread-safe -- with one exception the file path relies on (kbbq/_egress.py, kbbq/_stream.py:
+ *     the output pipeline copies slab k off the device while the producer thread launches K2 on slab k + 1): kbbq_dev_alloc / _free,
+ *     kbbq_dev_copy_async and kbbq_event_create / _record / _sync touch nothing of the context but its stream and may be called
+ *     from a second thread while the first one launches kernels and reads the status.
  *
  * Read layout ("padded SoA"): three byte planes seq / cseq / qual, one row of
  * `pitch` bytes per read, pitch a multiple of 16, rows 16-byte aligned.  Bytes

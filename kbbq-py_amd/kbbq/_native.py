@@ -262,7 +262,8 @@ def ptr(x):
 
 
 class Context:
-    """One per device (kbbq_ctx).  Not thread-safe."""
+    """One per device (kbbq_ctx).  Not thread-safe, except that device allocations, asynchronous copies and events (what the
+    output pipeline's copy stage uses) may run on a second thread beside the one that launches kernels: include/kbbq_hip.h."""
 
     def __init__(self, device=0):
         lib = load()
