@@ -976,3 +976,51 @@ def test_wrapped_fastq_reads_like_four_line_fastq(oracle, tmp_path):
         p = str(tmp_path / 'bad.fq'); open(p, 'w').write(text)
         with pytest.raises(ValueError):
             fastx.NativeFastq(p)
+
+
+def test_streaming_helpers_without_a_device(oracle, tmp_path):
+    """The host-only pieces of the streamed file path (kbbq/recalibrate.py, kbbq/_stream.py, kbbq/_device.py): byte-size parsing,
+    slab sizing, the prefetching iterator (order, an exception of the producer, a consumer that stops early) and the pairing of
+    a leading and a following sequential reader segment by segment."""
+    import threading
+    import time
+    from kbbq import _device as D, recalibrate, _stream
+    assert [D.parse_bytes(x) for x in ('1024', '64k', '256M', '1.5G', '2GB', '1e6')] == [1024, 65536, 256 << 20, 3 << 29, 2 << 30, 1000000]
+    assert _stream.slab_reads(256 << 20, 484) % 2 == 0 and 400000 < _stream.slab_reads(256 << 20, 484) < 450000
+    assert _stream.slab_reads(1, 10 ** 9) == 2 and _stream.resident_bytes(10, 150) == 10 * 644
+    assert fastx._too_large(8_000_000, 150, 256 << 20) and not fastx._too_large(1000, 150, 256 << 20)
+    # order, and one item read ahead
+    made = []
+
+    def numbers(n, fail_at=None):
+        for i in range(n):
+            if i == fail_at:
+                raise RuntimeError('producer failed at %d' % i)
+            made.append(i)
+            yield i
+    assert list(recalibrate._prefetched(numbers(50))) == list(range(50))
+    with pytest.raises(RuntimeError, match='failed at 7'):
+        list(recalibrate._prefetched(numbers(20, fail_at=7)))
+    del made[:]
+    it = recalibrate._prefetched(numbers(1000))
+    assert [next(it) for _ in range(3)] == [0, 1, 2]
+    it.close()                                               # joins the producer: nothing is made afterwards
+    n_made = len(made)
+    time.sleep(0.05)
+    assert len(made) == n_made <= 6 and threading.active_count() < 20
+    # leader / follower pairing over real sequential readers, the follower ending early and exactly at a segment's end
+    n = 3000
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 2, 100, 100, 2)
+    names = oracle.synth_names(0, n, 2, with_rg=True)
+    fa, fb = str(tmp_path / 'a.fq'), str(tmp_path / 'b.fq')
+    oracle.write_fastq(fa, names, seq, qual, meta)
+    for keep in (n, 1777, 0):
+        oracle.write_fastq(fb, names[:keep], cseq[:keep], qual[:keep], meta[:keep])
+        sa, sb = fastx.FastqStream(fa), fastx.FastqStream(fb)
+        na = nb = 0
+        for a, b in recalibrate._pair_segments(sa, sb, 1 << 16):
+            assert b is None or (b.first == a.first and b.n <= a.n)
+            na, nb = na + a.n, nb + (b.n if b is not None else 0)
+        assert (na, nb) == (n, keep)
+    sa = fastx.FastqStream(fa)
+    assert sum(a.n for a, b in recalibrate._pair_segments(sa, None, 1 << 16) if b is None) == n
