@@ -561,7 +561,8 @@ int         kbbq_fastq_scan(kbbq_fastq* a, const kbbq_fastq* b, int infer_rg, in
  * fill_rows / format work on it; close it with kbbq_fastq_close): the leading file about `max_bytes` per segment
  * (records = 0), the following file exactly the leader's number of records (records > 0; fewer only when it ends first: zip()
  * stops there).  *segment = NULL when the input has ended; *at_end = 1 when it ends behind this segment.  path: a regular
- * file, a named pipe / process substitution, "-" = standard input; gzip bytes are refused (decompress in the pipe).
+ * file, a named pipe / process substitution, "-" = standard input; gzip / bgzip bytes (a .fq.gz file of any size, a pipe that
+ * carries them) are inflated as they are read, member after member, in constant memory -- as pysam.FastxFile reads them.
  * kbbq_fastq_stream_tee: every byte handed out is also appended to `fd` -- the spool a pipe's file A is kept in for pass 2.
  * kbbq_fastq_scan_next: kbbq_fastq_scan of one segment, with what the reference's walk carries from read to read handed
  * over by the caller: the read groups met so far (kbbq_fastq_set_rg_names first; new ones are appended, first-appearance

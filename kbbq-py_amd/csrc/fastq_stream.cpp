@@ -9,6 +9,7 @@
 // (kbbq_fastq_scan_next).  File A leads (segments of about max_bytes), file B follows with the same NUMBER of records per
 // segment; a shorter file B ends pass 1 where zip() would.  Pass 2 needs file A a second time: a regular file is
 // simply read again, a pipe is copied to a spool file as it is read (kbbq_fastq_stream_tee) and pass 2 reads the spool.
+// gzip / bgzip bytes -- a .fq.gz file of any size, or a pipe that carries them -- are inflated as they are read, member after member.
 #include "../../include/kbbq_hip.h"
 #include "fastq_host.h"
 #include "host_threads.h"
@@ -26,6 +27,7 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 int kbbq_set_error_(int code, const char* msg);      // defined in kbbq_hip.hip
 
@@ -38,7 +40,12 @@ struct kbbq_fastq_stream {
     int tee_fd = -1;                                   // every byte handed out is also written here (the spool of a pipe)
     int64_t records = 0, bytes = 0;                    // handed out so far
     std::string path;
-    ~kbbq_fastq_stream() { if (own_fd && fd >= 0) close(fd); }
+    // gzip / bgzip input (what pysam.FastxFile reads transparently): inflated as it is read, member after member, in constant memory
+    bool gz = false, zs_open = false, in_member = false, fd_eof = false;
+    z_stream zs;
+    raw_vector<uint8_t> zin; size_t zin_pos = 0, zin_len = 0;
+    std::string zerr;
+    ~kbbq_fastq_stream() { if (zs_open) inflateEnd(&zs); if (own_fd && fd >= 0) close(fd); }
 };
 
 namespace {
@@ -94,10 +101,63 @@ size_t behind_kth_newline(const uint8_t* buf, size_t n, size_t k, const std::vec
     return n;
 }
 
+// compressed bytes from the descriptor into s->zin (behind what is still unread there); false on a read error
+bool refill_compressed(kbbq_fastq_stream* s)
+{
+    if (s->zin_pos == s->zin_len) s->zin_pos = s->zin_len = 0;
+    if (s->fd_eof || s->zin_len == s->zin.size()) return true;
+    for (;;) {
+        const ssize_t k = read(s->fd, s->zin.data() + s->zin_len, s->zin.size() - s->zin_len);
+        if (k < 0 && errno == EINTR) continue;
+        if (k < 0) return false;
+        if (k == 0) s->fd_eof = true;
+        s->zin_len += (size_t)k; s->pos += k;
+        return true;
+    }
+}
+
+// up to `want` INFLATED bytes into dst (fewer only at the end of the input); -1 on damaged input (s->zerr says what)
+int64_t inflate_some(kbbq_fastq_stream* s, uint8_t* dst, size_t want)
+{
+    size_t got = 0;
+    while (got < want) {
+        if (s->zin_pos == s->zin_len) {
+            if (!refill_compressed(s)) { s->zerr = "read failed"; return -1; }
+            if (s->zin_pos == s->zin_len) {                                       // the compressed input has ended
+                if (s->in_member) { s->zerr = "truncated gzip data"; return -1; }
+                s->eof = true;
+                break;
+            }
+        }
+        if (!s->in_member) {
+            // a new member (bgzip files are thousands of them); NUL padding behind the last member is tolerated as gzip(1) does
+            while (s->zin_pos < s->zin_len && s->zin[s->zin_pos] == 0) ++s->zin_pos;
+            if (s->zin_pos == s->zin_len) continue;
+            if (inflateReset2(&s->zs, 15 + 32) != Z_OK) { s->zerr = "inflateReset failed"; return -1; }
+            s->in_member = true;
+        }
+        s->zs.next_in = s->zin.data() + s->zin_pos;
+        s->zs.avail_in = (uInt)std::min<size_t>(s->zin_len - s->zin_pos, 1u << 30);
+        s->zs.next_out = dst + got;
+        s->zs.avail_out = (uInt)std::min<size_t>(want - got, 1u << 30);
+        const uInt in0 = s->zs.avail_in, out0 = s->zs.avail_out;
+        const int rc = inflate(&s->zs, Z_NO_FLUSH);
+        s->zin_pos += in0 - s->zs.avail_in;
+        got += out0 - s->zs.avail_out;
+        if (rc == Z_STREAM_END) { s->in_member = false; continue; }
+        if (rc != Z_OK && rc != Z_BUF_ERROR) { s->zerr = std::string("damaged gzip data (") + (s->zs.msg ? s->zs.msg : "inflate failed") + ")"; return -1; }
+        if (rc == Z_BUF_ERROR && in0 == s->zs.avail_in && out0 == s->zs.avail_out && s->zin_pos < s->zin_len) {
+            s->zerr = "damaged gzip data (no progress)"; return -1;
+        }
+    }
+    return (int64_t)got;
+}
+
 // read up to `want` bytes at the stream's position into dst; returns the bytes read (< want only at the end of the input)
 int64_t read_some(kbbq_fastq_stream* s, uint8_t* dst, size_t want)
 {
     if (s->eof || want == 0) return 0;
+    if (s->gz) return inflate_some(s, dst, want);
     if (s->regular) {
         const size_t have = (size_t)std::max<int64_t>(0, s->size - s->pos);
         const size_t take = std::min(want, have);
@@ -161,11 +221,35 @@ int kbbq_fastq_stream_open(const char* path, kbbq_fastq_stream** out)
 #ifdef F_SETPIPE_SZ
     else if (S_ISFIFO(st.st_mode)) (void)fcntl(s->fd, F_SETPIPE_SZ, 1 << 20);      // 64 KB by default: fewer wake-ups per GB
 #endif
+    // gzip / bgzip bytes?  The first two bytes decide (a pipe's are read here and kept)
+    s->zin.resize((size_t)4 << 20);
+    if (!s->eof) {
+        while (s->zin_len < 2 && !s->fd_eof) {
+            const ssize_t k = read(s->fd, s->zin.data() + s->zin_len, 2 - s->zin_len);
+            if (k < 0 && errno == EINTR) continue;
+            if (k < 0) { delete s; return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": read failed").c_str()); }
+            if (k == 0) s->fd_eof = true;
+            s->zin_len += (size_t)k;
+        }
+        if (s->zin_len == 2 && s->zin[0] == 0x1f && s->zin[1] == 0x8b) {
+            memset(&s->zs, 0, sizeof s->zs);
+            if (inflateInit2(&s->zs, 15 + 32) != Z_OK) { delete s; return kbbq_set_error_(KBBQ_E_ARG, "inflateInit failed"); }
+            s->zs_open = true; s->gz = true; s->pos = (int64_t)s->zin_len;
+        } else if (s->regular) {
+            s->zin_len = 0;                                                          // plain text of a regular file: positioned reads from byte 0
+            if (lseek(s->fd, 0, SEEK_SET) < 0) { delete s; return kbbq_set_error_(KBBQ_E_ARG, "lseek failed"); }
+        } else {
+            s->carry.assign(s->zin.data(), s->zin.data() + s->zin_len);             // plain text of a pipe: the bytes read belong to the first segment
+            s->pos = (int64_t)s->zin_len; s->zin_len = 0;
+            if (s->fd_eof) s->eof = true;
+        }
+    }
     *out = s;
     return KBBQ_OK;
 }
 
-int kbbq_fastq_stream_is_regular(const kbbq_fastq_stream* s) { return s && s->regular ? 1 : 0; }
+// 1: an uncompressed regular file (it can be read a second time as it is); 0: a pipe, standard input, compressed bytes -- pass 2 reads a spool
+int kbbq_fastq_stream_is_regular(const kbbq_fastq_stream* s) { return s && s->regular && !s->gz ? 1 : 0; }
 
 // every byte handed out from now on is appended to `fd` (the caller's spool file; not closed here); -1 stops it
 int kbbq_fastq_stream_tee(kbbq_fastq_stream* s, int fd)
@@ -187,7 +271,7 @@ int kbbq_fastq_stream_prefetch(kbbq_fastq_stream* s, size_t bytes)
     s->carry.resize(have + bytes);
     const int64_t got = read_some(s, s->carry.data() + have, bytes);
     s->carry.resize(have + (size_t)std::max<int64_t>(got, 0));
-    if (got < 0) return kbbq_set_error_(KBBQ_E_ARG, (s->path + ": read failed").c_str());
+    if (got < 0) return kbbq_set_error_(KBBQ_E_ARG, (s->path + ": " + (s->zerr.empty() ? "read failed" : s->zerr)).c_str());
     return KBBQ_OK;
 }
 
@@ -195,7 +279,7 @@ int kbbq_fastq_stream_prefetch(kbbq_fastq_stream* s, size_t bytes)
 //   records == 0  (the leading file): about max_bytes of text (at least one record, however long);
 //   records  > 0  (the following file): exactly that many records, fewer only when the input ends first.
 // *segment: a reader over memory of its own (close it with kbbq_fastq_close), NULL when the input has ended and nothing is
-// left; *at_end: 1 when the input has ended behind this segment.  Gzip-compressed bytes are refused (pipe them through zcat).
+// left; *at_end: 1 when the input has ended behind this segment.
 int kbbq_fastq_stream_next(kbbq_fastq_stream* s, size_t max_bytes, int64_t records, kbbq_fastq** segment, int* at_end)
 {
     if (!s || !segment || records < 0) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_fastq_stream_next: bad argument");
@@ -218,12 +302,8 @@ int kbbq_fastq_stream_next(kbbq_fastq_stream* s, size_t max_bytes, int64_t recor
     for (;;) {
         if (!s->eof && have < cap) {
             const int64_t got = read_some(s, buf.data() + have, cap - have);
-            if (got < 0) { delete f; return kbbq_set_error_(KBBQ_E_ARG, (s->path + ": read failed").c_str()); }
+            if (got < 0) { delete f; return kbbq_set_error_(KBBQ_E_ARG, (s->path + ": " + (s->zerr.empty() ? "read failed" : s->zerr)).c_str()); }
             have += (size_t)got;
-        }
-        if (s->bytes == 0 && have >= 2 && buf[0] == 0x1f && buf[1] == 0x8b) {
-            delete f;
-            return kbbq_set_error_(KBBQ_E_ARG, (s->path + ": gzip-compressed bytes in a sequentially read input -- decompress them in the pipe, e.g. <(zcat file.fq.gz)").c_str());
         }
         const size_t nlines = count_lines(buf.data(), have, parts, starts);
         // at the end of the input the last line needs no line end (as in the mapped reader)

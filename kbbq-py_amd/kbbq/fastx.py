@@ -454,16 +454,27 @@ class FastqStream:
             pass
 
 
+GZ_STREAM_BYTES = 1 << 30               # a compressed file of at least this size is inflated segment by segment (KBBQ_GZ_STREAM_BYTES)
+
+
 def is_sequential_input(path):
-    """True for an input that cannot be mapped and indexed as a whole: standard input, a pipe, a character device."""
+    """True for an input that is read sequentially instead of being mapped and indexed as a whole: standard input, a pipe, a
+    character device -- and a gzip / bgzip-compressed regular file of 1 GB or more (KBBQ_GZ_STREAM_BYTES), which the mapped
+    reader would have to inflate into memory as a whole (a 100 GB .fq.gz is 300 GB of text; pysam streams it, so does
+    FastqStream).  Smaller compressed files keep the mapped reader: bgzip blocks are inflated in parallel there."""
     import os
     import stat
     if str(path) == '-':
         return True
     try:
-        return not stat.S_ISREG(os.stat(str(path)).st_mode)
+        st = os.stat(str(path))
     except OSError:
         return False
+    if not stat.S_ISREG(st.st_mode):
+        return True
+    limit = os.environ.get('KBBQ_GZ_STREAM_BYTES')
+    limit = GZ_STREAM_BYTES if not limit else int(float(limit))
+    return st.st_size >= limit and st.st_size >= 2 and _is_gzip(str(path))
 
 
 _SCAN_ERRORS = {

@@ -75,8 +75,9 @@ def _cli(args, env=None, timeout=300, shell=False):
 @pytest.mark.parametrize('name', ['c1_10k_1rg', 'c3cut_2k_8rg', 'c5cut_2k_mixed'])
 def test_the_command_line_reads_pipes(dev, oracle, name, tmp_path):
     """`kbbq recalibrate -f <(cat a.fq) <(cat b.fq)` (two process substitutions: neither input can be mapped, sought or read
-    twice -- file A is spooled for pass 2) and `-f - b.fq` with file A on standard input print the golden; a gzip-compressed
-    file decompressed in the pipe likewise; the torch-free command line streams within a budget too."""
+    twice -- file A is spooled for pass 2) and `-f - b.fq` with file A on standard input print the golden; gzip-compressed
+    input likewise -- decompressed in the pipe, carried by the pipe, or a .gz file read segment by segment; the torch-free command
+    line streams within a budget too."""
     import gzip, shutil
     info, _ = load_golden(name)
     fa, fb = _files(oracle, info, tmp_path)
@@ -94,9 +95,14 @@ def test_the_command_line_reads_pipes(dev, oracle, name, tmp_path):
     r = _cli('%s -m kbbq.main recalibrate -f %s <(zcat %s.gz)%s -o %s' % (py, fa, fb, rg, out), shell=True)
     assert r.returncode == 0 and not r.stdout, r.stderr.decode()[-2000:]
     assert oracle.sha256(open(out, 'rb').read()) == info['output_sha256']
-    # a compressed stream is refused with advice, not mis-parsed
+    # compressed bytes in a pipe, and a compressed FILE read segment by segment (as files of 1 GB and more are): inflated as they are read
+    with open(fa, 'rb') as src, gzip.open(fa + '.gz', 'wb') as dst:
+        shutil.copyfileobj(src, dst)
     r = _cli('%s -m kbbq.main recalibrate -f %s <(cat %s.gz)%s' % (py, fa, fb, rg), shell=True)
-    assert r.returncode != 0 and b'zcat' in r.stderr
+    assert r.returncode == 0 and oracle.sha256(r.stdout) == info['output_sha256'], r.stderr.decode()[-2000:]
+    r = _cli([py, '-m', 'kbbq.main', 'recalibrate', '-f', fa + '.gz', fb + '.gz'] + rg.split(), env={'KBBQ_GZ_STREAM_BYTES': '1', 'KBBQ_SEGMENT_BYTES': '200K', 'KBBQ_TIMING': '1'})
+    assert r.returncode == 0 and oracle.sha256(r.stdout) == info['output_sha256'], r.stderr.decode()[-2000:]
+    assert b'open+index+scan' not in r.stderr and b' scan ' in r.stderr           # no mapped, indexed reader took part
     # regular files over budget, no torch
     r = _cli([py, '-X', 'importtime', '-m', 'kbbq.main', 'recalibrate', '-f', fa, fb] + rg.split(), env={'KBBQ_DEVICE_BUDGET': '2M'})
     assert r.returncode == 0, r.stderr.decode()[-2000:]

@@ -105,7 +105,11 @@ def test_malformed_inputs_do_not_touch_memory_they_do_not_own(harness, tmp_path)
     raw = open(gz, 'rb').read()
     harness('pair', _write(tmp_path / 'cut.fq.gz', raw[:len(raw) // 2], 'wb'), '-', '0')
     harness('pair', _write(tmp_path / 'junk.fq.gz', b'\x1f\x8b' + b'\x00' * 50, 'wb'), '-', '0')
-    assert 'zcat' in harness('stream', str(gz), '-', '0')          # compressed bytes in a sequentially read input: refused with advice
+    assert 'stream records=1000 usable=1000' in harness('stream', str(gz), str(gz), '1', '65536')      # inflated as it is read
+    harness('stream', str(tmp_path / 'cut.fq.gz'), '-', '0')
+    harness('stream', str(tmp_path / 'junk.fq.gz'), '-', '0')
+    harness('stream', _write(tmp_path / 'members.fq.gz', gzip.compress(good_text[:30000]) + gzip.compress(good_text[30000:]) + b'\0' * 64, 'wb'), str(gz), '1', '65536')
+    harness('stream', _write(tmp_path / 'flip.fq.gz', raw[:len(raw) // 2] + bytes([raw[len(raw) // 2] ^ 0x11]) + raw[len(raw) // 2 + 1:], 'wb'), '-', '0')
     # many records in small segments, a follower that ends early, a follower whose records are longer than the leader's
     many = _write(tmp_path / 'many.fq', ''.join('@r%d/1_RG:Z:g%d\n%s\n+\n%s\n' % (i, i % 5, 'ACGT' * (5 + i // 3000), 'IIII' * (5 + i // 3000)) for i in range(20000)))
     longer = _write(tmp_path / 'longer.fq', ''.join('@r%d/1_RG:Z:g%d and a long comment %s\n%s\n+\n%s\n' % (i, i % 5, 'x' * 200, 'ACGT' * (5 + i // 3000), 'IIII' * (5 + i // 3000)) for i in range(20000)))

@@ -65,8 +65,8 @@ while time.time() < t_end:
             skipped += 1
             continue
         # how the path walks the reads: resident (everything on the device between the passes), streamed within a small device
-        # budget (kbbq/_stream.py), or read sequentially like a pipe (fastx.FastqStream; compressed files cannot be)
-        mode = str(rng.choice(['resident', 'budget', 'sequential'] if ga == fa else ['resident', 'budget']))
+        # budget (kbbq/_stream.py), or read sequentially like a pipe (fastx.FastqStream; compressed files are inflated as they are read)
+        mode = str(rng.choice(['resident', 'budget', 'sequential']))
         for k in ('KBBQ_DEVICE_BUDGET', 'KBBQ_SEQUENTIAL', 'KBBQ_SEGMENT_BYTES'):
             os.environ.pop(k, None)
         if mode != 'resident':
