@@ -116,11 +116,75 @@ bool refill_compressed(kbbq_fastq_stream* s)
     }
 }
 
+// BGZF (bgzip): every member is a block of at most 64 KB that says its own compressed size (extra field 'B' 'C') and, in its last
+// four bytes, its inflated size -- so the whole blocks waiting in s->zin can be inflated AT THE SAME TIME, each straight to its
+// place in dst.  Returns the bytes written (0: the next member is not such a block, or does not fit dst any more: the caller's
+// serial loop takes it), -1 on a damaged block.
+int64_t inflate_bgzf_blocks(kbbq_fastq_stream* s, uint8_t* dst, size_t room)
+{
+    struct Blk { size_t src, csize, isize, dst; uint32_t crc; };
+    std::vector<Blk> blocks;
+    const uint8_t* z = s->zin.data();
+    size_t at = s->zin_pos, out = 0;
+    auto le16 = [](const uint8_t* p) { return (size_t)p[0] | ((size_t)p[1] << 8); };
+    auto le32 = [](const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
+    while (s->zin_len - at >= 18) {
+        if (z[at] != 0x1f || z[at + 1] != 0x8b || z[at + 2] != 8 || !(z[at + 3] & 4)) break;
+        const size_t xlen = le16(z + at + 10);
+        if (s->zin_len - at < 12 + xlen) break;
+        size_t bsize = 0;
+        for (size_t x = at + 12; x + 4 <= at + 12 + xlen;) {
+            const size_t slen = le16(z + x + 2);
+            if (z[x] == 'B' && z[x + 1] == 'C' && slen == 2 && x + 6 <= at + 12 + xlen) bsize = le16(z + x + 4) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8) break;                       // not a BGZF block: the serial loop decides what it is
+        if (s->zin_len - at < bsize) break;                     // not all of it has been read yet
+        Blk b;
+        b.src = at + 12 + xlen; b.csize = bsize - (12 + xlen) - 8; b.crc = le32(z + at + bsize - 8); b.isize = le32(z + at + bsize - 4);
+        if (b.isize > (1u << 16) || out + b.isize > room) break;
+        b.dst = out; out += b.isize; at += bsize;
+        blocks.push_back(b);
+    }
+    if (blocks.size() < 2) return 0;                             // (one block: the serial loop is as good)
+    std::atomic<int> bad(0);
+    const unsigned nt = (unsigned)std::min<size_t>(kbbq_threads_for(out), blocks.size());
+    kbbq_parallel(nt, [&](unsigned t) {
+        z_stream zz; memset(&zz, 0, sizeof zz);
+        if (inflateInit2(&zz, -15) != Z_OK) { bad = 1; return; }
+        for (size_t b = t; b < blocks.size() && !bad.load(); b += nt) {
+            const Blk& k = blocks[b];
+            Bytef nothing = 0;
+            zz.next_in = const_cast<Bytef*>(z + k.src); zz.avail_in = (uInt)k.csize;
+            zz.next_out = k.isize ? dst + k.dst : &nothing; zz.avail_out = (uInt)k.isize;
+            const int rc = (k.isize || k.csize) ? inflate(&zz, Z_FINISH) : Z_STREAM_END;
+            if ((rc != Z_STREAM_END && !(rc == Z_OK && zz.avail_out == 0)) || zz.avail_out != 0
+                || crc32(crc32(0L, Z_NULL, 0), k.isize ? dst + k.dst : &nothing, (uInt)k.isize) != k.crc) { bad = 2; break; }
+            inflateReset(&zz);
+        }
+        inflateEnd(&zz);
+    });
+    if (bad.load()) { s->zerr = "damaged BGZF block (inflate / CRC mismatch)"; return -1; }
+    s->zin_pos = at;
+    return (int64_t)out;
+}
+
 // up to `want` INFLATED bytes into dst (fewer only at the end of the input); -1 on damaged input (s->zerr says what)
 int64_t inflate_some(kbbq_fastq_stream* s, uint8_t* dst, size_t want)
 {
     size_t got = 0;
     while (got < want) {
+        if (!s->in_member && s->zin_pos < s->zin_len) {
+            if (s->zin_len - s->zin_pos < ((size_t)1 << 20) && !s->fd_eof) {                   // keep whole blocks coming: top the buffer up
+                memmove(s->zin.data(), s->zin.data() + s->zin_pos, s->zin_len - s->zin_pos);
+                s->zin_len -= s->zin_pos; s->zin_pos = 0;
+                if (!refill_compressed(s)) { s->zerr = "read failed"; return -1; }
+            }
+            const int64_t k = inflate_bgzf_blocks(s, dst + got, want - got);
+            if (k < 0) return -1;
+            got += (size_t)k;
+            if (k > 0) continue;
+        }
         if (s->zin_pos == s->zin_len) {
             if (!refill_compressed(s)) { s->zerr = "read failed"; return -1; }
             if (s->zin_pos == s->zin_len) {                                       // the compressed input has ended

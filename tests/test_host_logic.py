@@ -938,7 +938,9 @@ def test_sequential_reader_hands_out_whole_records(oracle, tmp_path):
     cut = whole.index(b'\n@', cut) + 1                          # (members need not end at record ends; this one happens to end at a line end)
     p2 = str(tmp_path / 'm.fq.gz')
     open(p2, 'wb').write(gzip.compress(whole[:cut]) + gzip.compress(whole[cut:cut + 100]) + gzip.compress(whole[cut + 100:]) + b'\0' * 40)
-    for path in (p, p2):
+    import bamwriter                                            # BGZF blocks (bgzip): inflated many at a time
+    p3 = str(tmp_path / 'b.fq.gz'); open(p3, 'wb').write(bamwriter.bgzf(whole, block=0x3000))
+    for path in (p, p2, p3):
         s, got = fastx.FastqStream(path), b''
         assert not s.regular                                    # compressed: pass 2 reads a spool
         while True:
@@ -961,7 +963,9 @@ def test_sequential_reader_hands_out_whole_records(oracle, tmp_path):
     th.join()
     assert total == n
     raw = open(p, 'rb').read()
-    for name, data in (('cut', raw[:len(raw) // 2]), ('flip', raw[:len(raw) // 2] + bytes([raw[len(raw) // 2] ^ 0x5A]) + raw[len(raw) // 2 + 1:]), ('magic', b'\x1f\x8b')):
+    bz = open(p3, 'rb').read()
+    for name, data in (('cut', raw[:len(raw) // 2]), ('flip', raw[:len(raw) // 2] + bytes([raw[len(raw) // 2] ^ 0x5A]) + raw[len(raw) // 2 + 1:]), ('magic', b'\x1f\x8b'),
+                       ('bgzf_cut', bz[:len(bz) // 2]), ('bgzf_flip', bz[:len(bz) // 2] + bytes([bz[len(bz) // 2] ^ 0x5A]) + bz[len(bz) // 2 + 1:])):
         bad = str(tmp_path / (name + '.gz')); open(bad, 'wb').write(data)
         with pytest.raises(ValueError):
             s = fastx.FastqStream(bad)

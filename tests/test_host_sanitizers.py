@@ -109,6 +109,12 @@ def test_malformed_inputs_do_not_touch_memory_they_do_not_own(harness, tmp_path)
     harness('stream', str(tmp_path / 'cut.fq.gz'), '-', '0')
     harness('stream', str(tmp_path / 'junk.fq.gz'), '-', '0')
     harness('stream', _write(tmp_path / 'members.fq.gz', gzip.compress(good_text[:30000]) + gzip.compress(good_text[30000:]) + b'\0' * 64, 'wb'), str(gz), '1', '65536')
+    import bamwriter
+    bz = bamwriter.bgzf(good_text, block=0x1000)
+    assert 'stream records=1000 usable=1000' in harness('stream', _write(tmp_path / 'blocks.fq.gz', bz, 'wb'), str(gz), '1', '65536')
+    harness('stream', _write(tmp_path / 'blocks_cut.fq.gz', bz[:len(bz) // 2 + 7], 'wb'), '-', '0')
+    harness('stream', _write(tmp_path / 'blocks_flip.fq.gz', bz[:len(bz) // 2] + bytes([bz[len(bz) // 2] ^ 0x11]) + bz[len(bz) // 2 + 1:], 'wb'), '-', '0')
+    harness('stream', _write(tmp_path / 'blocks_bsize.fq.gz', bz[:16] + b'\xff\xff' + bz[18:], 'wb'), '-', '0')
     harness('stream', _write(tmp_path / 'flip.fq.gz', raw[:len(raw) // 2] + bytes([raw[len(raw) // 2] ^ 0x11]) + raw[len(raw) // 2 + 1:], 'wb'), '-', '0')
     # many records in small segments, a follower that ends early, a follower whose records are longer than the leader's
     many = _write(tmp_path / 'many.fq', ''.join('@r%d/1_RG:Z:g%d\n%s\n+\n%s\n' % (i, i % 5, 'ACGT' * (5 + i // 3000), 'IIII' * (5 + i // 3000)) for i in range(20000)))
