@@ -4,7 +4,7 @@
 # timed-out step ends the job: no further GPU step is started after a kill).
 #   tests[=EXPR]      pytest -m gpu (optionally -k EXPR)
 #   file=PATH[::K]    pytest -m gpu of one test file (optionally -k K)
-#   ranks             the 4-rank rehearsals (tests/test_gpu_ranks.py)
+#   ranks[=N]         the N-rank rehearsals (tests/test_gpu_ranks.py; default 4: all the box's process guard admits)
 #   bench[=ARGS]      python bench.py (default: the driver's form, --steps 20 --warmup 5)
 #   benchq            python bench.py --no-extra --cpu-sample 0 --steps 10 --warmup 3
 #   hostentry         scripts/time_host_entry.py (kbbq_accumulate / kbbq_apply on host buffers, PCIe included)
@@ -33,7 +33,7 @@ for step in "$@"; do
     tests)     if [ -n "$arg" ]; then run tests 1100 python -m pytest tests -x -q -m gpu -k "$arg"; else run tests 1100 python -m pytest tests -x -q -m gpu; fi ;;
     file)      f=${arg%%::*}; k=""; [[ "$arg" == *::* ]] && k=${arg#*::}
                if [ -n "$k" ]; then run file_$(basename $f .py) 1000 python -m pytest $f -x -q -m gpu -k "$k"; else run file_$(basename $f .py) 1000 python -m pytest $f -x -q -m gpu; fi ;;
-    ranks)     run ranks 900 python -m pytest tests/test_gpu_ranks.py -x -q -m gpu ;;
+    ranks)     KBBQ_TEST_RANKS=${arg:-4} run ranks 900 python -m pytest tests/test_gpu_ranks.py -x -q -m gpu ;;
     bench)     run bench 900 python bench.py ${arg:---steps 20 --warmup 5}; grep '^{' gpurun_out/bench_$TAG.log | tail -1 > gpurun_out/bench_$TAG.json ;;
     benchq)    run benchq 600 python bench.py --no-extra --cpu-sample 0 --steps 10 --warmup 3; grep '^{' gpurun_out/benchq_$TAG.log | tail -1 > gpurun_out/benchq_$TAG.json ;;
     hostentry) run hostentry 400 python scripts/time_host_entry.py ;;

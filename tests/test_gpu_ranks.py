@@ -1,8 +1,9 @@
 """
 Rehearsals of the one-process-per-GPU mode with as many ranks as a one-GPU box allows: its process guard admits six
 processes with the card open -- this test runner is one, the torch.distributed.run launcher another (5 ranks were
-killed by the guard: "7 processes had the GPU open") -- so FOUR ranks share the GPU here and talk over gloo
-(KBBQ_DIST_BACKEND=gloo); the 8-rank forms of the host logic run on the CPU (tests/test_parallel_gloo.py,
+killed by the guard: "7 processes had the GPU open") -- so at most FOUR ranks can share the GPU here; the suite runs THREE
+by default (one slot left free for whatever else the box's harness keeps open; KBBQ_TEST_RANKS=4 is what the builder's own
+jobs ran) and they talk over gloo (KBBQ_DIST_BACKEND=gloo); the 8-rank forms of the host logic run on the CPU (tests/test_parallel_gloo.py,
 tests/test_host_logic.py::test_every_rank_cuts_its_own_byte_range, tests/test_host_threads.py).  What runs here is the
 whole product path per rank -- own byte range, packer, K1, ONE allreduce of the count tables, replicated solve, K2,
 writer -- on the reference's goldens (BASELINE configs 1, 3 and 5's cuts), `kbbq benchmark -f`, the BAM-sourced tally
@@ -22,7 +23,7 @@ import pytest
 from conftest import ROOT, load_golden
 
 pytestmark = pytest.mark.gpu
-RANKS = 4
+RANKS = int(os.environ.get('KBBQ_TEST_RANKS', '3'))          # 4 fills the guard's six slots exactly (verified: gpurun_out/ranks_r4a.log); the suite leaves one free
 
 
 @pytest.fixture(scope='module')
@@ -50,9 +51,9 @@ def _usable_cpus():
 
 
 @pytest.mark.parametrize('name', ['c1_10k_1rg', 'c3cut_2k_8rg', 'c5cut_2k_mixed'])
-def test_four_ranks_write_the_reference_output(dev, oracle, name, tmp_path):
-    """`kbbq recalibrate -f A B -o FILE` on 4 ranks: FILE.rank0000 ... rank0003 concatenated are the reference's bytes;
-    every rank cut its own byte range; every rank started 1 / 4 of the host threads."""
+def test_ranks_write_the_reference_output(dev, oracle, name, tmp_path):
+    """`kbbq recalibrate -f A B -o FILE` on RANKS ranks: FILE.rank0000 ... concatenated are the reference's bytes;
+    every rank cut its own byte range; every rank started 1 / RANKS of the host threads."""
     from test_gpu_parity import _files
     info, _ = load_golden(name)
     fa, fb = _files(oracle, info, tmp_path)
@@ -71,7 +72,7 @@ def test_four_ranks_write_the_reference_output(dev, oracle, name, tmp_path):
     assert len(threads) == RANKS and sum(threads) <= max(_usable_cpus(), RANKS), err[-1500:]
 
 
-def test_four_ranks_print_in_rank_order(dev, oracle, tmp_path):
+def test_ranks_print_in_rank_order(dev, oracle, tmp_path):
     """The same to a shared stdout (the ranks print in turn): BASELINE config 3's cut, 8 read groups."""
     from test_gpu_parity import _files
     info, _ = load_golden('c3cut_2k_8rg')
@@ -82,9 +83,9 @@ def test_four_ranks_print_in_rank_order(dev, oracle, tmp_path):
     assert len(text) == info['output_len'] and oracle.sha256(text) == info['output_sha256']
 
 
-def test_four_ranks_print_the_reference_benchmark(dev, oracle, tmp_path):
-    """`kbbq benchmark -f` on 4 ranks (BASELINE config 5's benchmark half): the golden table, every rank flagging about a
-    quarter of the alignments, all of them together."""
+def test_ranks_print_the_reference_benchmark(dev, oracle, tmp_path):
+    """`kbbq benchmark -f` on RANKS ranks (BASELINE config 5's benchmark half): the golden table, every rank flagging about its
+    share of the alignments, all of them together."""
     import oracle_benchmark as OB
     info, _ = load_golden('bench_a')
     paths = OB.synth_truthset(str(tmp_path), **info['case'])
@@ -96,15 +97,15 @@ def test_four_ranks_print_the_reference_benchmark(dev, oracle, tmp_path):
     seen = re.findall(r'rank (\d) of %d counts FASTQ reads \[\d+, \d+\) and flagged alignments \[\d+, \d+\): (\d+) of (\d+)' % RANKS, err)
     assert sorted(x[0] for x in seen) == [str(i) for i in range(RANKS)], err[-1500:]
     total = int(seen[0][2])
-    assert all(int(k) <= 0.5 * total for _, k, _ in seen) and sum(int(k) for _, k, _ in seen) >= total
+    assert all(int(k) <= 0.6 * total for _, k, _ in seen) and sum(int(k) for _, k, _ in seen) >= total
     # and without -f: the alignments themselves sharded
     r = _run_ranks(RANKS, argv[:-2])
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     assert r.stdout.decode() == info['printed']['bam']
 
 
-def test_four_ranks_tally_alignments_like_one(dev, oracle, tmp_path):
-    """kbbq.gatk.bqsr.bam_to_bqsr_covariates on 4 ranks (the one-pass tally on shards of the alignments, one allreduce):
+def test_ranks_tally_alignments_like_one(dev, oracle, tmp_path):
+    """kbbq.gatk.bqsr.bam_to_bqsr_covariates on RANKS ranks (the one-pass tally on shards of the alignments, one allreduce):
     the nine vectors of the reference golden `bqsr_b`."""
     from test_oracle_bqsr import VEC, _inputs
     info, gold, paths = _inputs('bqsr_b', tmp_path, oracle)
@@ -116,8 +117,8 @@ def test_four_ranks_tally_alignments_like_one(dev, oracle, tmp_path):
         assert np.array_equal(np.array(g, dtype=np.int64), gold[k]), k
 
 
-def test_bench_with_four_ranks_checks_every_rank(dev):
-    """`python bench.py --gpus 4` through its own launcher (gloo rehearsal on the shared GPU): one JSON line, every rank
+def test_bench_with_several_ranks_checks_every_rank(dev):
+    """`python bench.py --gpus RANKS` through its own launcher (gloo rehearsal on the shared GPU): one JSON line, every rank
     verified its own batch and the line carries the AND, every rank reports its share of the host threads."""
     env = dict(os.environ); env.pop('RANK', None); env.pop('WORLD_SIZE', None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(RANKS), '--steps', '2', '--warmup', '1',
