@@ -186,7 +186,7 @@ def fastq_to_covariate_arrays(fastq, infer_rg=False, minscore=6, maxscore=42):
         run = _Sequential(fastq, infer_rg)
         try:
             _warm_up()
-            tables = run.pass1(minscore)
+            tables = run.pass1(minscore, spool=False)
         finally:
             run.close()
         packed = dict(R=len(run.rgs) if run.usable else 0, S=run.longest)
@@ -472,19 +472,19 @@ class _Sequential:
                 pass
             self.spool = None
 
-    def _open_a(self):
+    def _open_a(self, spool=True):
         sa = fastx.FastqStream(self.fastq[0])
         fd = None
-        if not sa.regular:
+        if not sa.regular and spool:
             import tempfile
             fd, self.spool = tempfile.mkstemp(prefix='kbbq-spool-', suffix='.fq', dir=os.environ.get('KBBQ_SPOOL_DIR') or None)
             sa.tee(fd)
         return sa, fd
 
-    def pass1(self, minscore=6, tally=True):
+    def pass1(self, minscore=6, tally=True, spool=True):
         """Count tables of the pair (None when no read was tallied); tally=False: file A alone, read groups and the spool
-        only (a model file replaces pass 1)."""
-        sa, fd = self._open_a()
+        only (a model file replaces pass 1); spool=False: no pass 2 will follow (fastq_to_covariate_arrays)."""
+        sa, fd = self._open_a(spool)
         sb = fastx.FastqStream(self.fastq[1]) if tally else None
         budget = dev.device_budget()
         self.peak = _stream.Peak(budget)
@@ -496,8 +496,8 @@ class _Sequential:
                 if tally and b is None:
                     b_ended = True                               # file B ended at the last segment's end
                 if b_ended:
-                    if sa.regular:
-                        break                                    # zip() has stopped (H6) and file A can be read again
+                    if sa.regular or not spool:
+                        break                                    # zip() has stopped (H6) and file A can be read again (or is not needed again)
                     continue                                     # ... a pipe is drained into the spool for pass 2
                 with stage('scan'):
                     usable, S_seg, R, kind, idx = a.scan_next(b, self.infer_rg, self.rgs, self.longest)
