@@ -88,8 +88,8 @@ def init_from_env():
     (backend "nccl" is RCCL on ROCm; KBBQ_DIST_BACKEND=gloo lets several ranks share one GPU for
     rehearsals).  No-op outside a launcher or when already initialised."""
     import os
-    if 'RANK' not in os.environ or int(os.environ.get('WORLD_SIZE', '1')) <= 1:
-        return world_rank()
+    if 'RANK' not in os.environ or (int(os.environ.get('WORLD_SIZE', '1')) <= 1 and not os.environ.get('KBBQ_DIST_ALWAYS')):
+        return world_rank()                  # (KBBQ_DIST_ALWAYS=1: join the group even as its only rank -- the RCCL path on a one-GPU box)
     import torch
     import torch.distributed as dist
     if dist.is_initialized():

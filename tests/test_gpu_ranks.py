@@ -132,3 +132,27 @@ def test_bench_with_several_ranks_checks_every_rank(dev):
     assert len(d['per_rank_ms_per_step']['ranks']) == RANKS
     assert d['host_binding']['local_ranks'] == RANKS and d['host_binding']['host_threads'] >= 1
     assert abs(d['value'] - RANKS * 200000 * 150 / (d['ms_per_step'] / 1e3)) / d['value'] < 1e-6
+
+
+def test_one_rank_over_rccl(dev, oracle, tmp_path):
+    """The RCCL path itself, as far as one GPU allows: bench.py and the command line under torch.distributed.run with ONE rank and
+    backend nccl (= RCCL on ROCm) -- process group on the device, the int64 sum-allreduce of the count tables, the gathers and
+    barriers of the sharded path, all through librccl instead of gloo."""
+    env = {k: v for k, v in os.environ.items() if k != 'KBBQ_DIST_BACKEND'}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); port = s_.getsockname()[1]; s_.close()
+    launch = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', str(port)]
+    r = subprocess.run(launch + [os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--reads', '400000',
+                                 '--no-extra', '--cpu-sample', '0'], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.split('\n') if ln.startswith('{')][-1])
+    assert d['backend'] == 'nccl' and d['ranks_seen'] == 1 and 'rehearsal' not in d['data']
+    assert d['allreduce_ms_per_step'] is not None and d['allreduce_ms_per_step'] > 0 and d['verified'] is True
+    from test_gpu_parity import _files
+    info, _ = load_golden('c3cut_2k_8rg')
+    fa, fb = _files(oracle, info, tmp_path)
+    s_ = socket.socket(); s_.bind(('127.0.0.1', 0)); launch[-1] = str(s_.getsockname()[1]); s_.close()
+    r = subprocess.run(launch + [os.path.join(ROOT, 'tests', 'dist_cli_worker.py'), 'recalibrate', '-f', fa, fb, '--infer-rg'],
+                       capture_output=True, timeout=600, env=dict(env, KBBQ_DIST_ALWAYS='1', KBBQ_DIST_BACKEND='nccl'))
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    assert oracle.sha256(r.stdout.decode()) == info['output_sha256']
