@@ -266,6 +266,13 @@ class Resident:
             chk = dev.ReadBatch(int(reads.numel()), self.rows.pitch, with_corrected=False)
             chk.seq.copy_(self.rows.seq[reads]); chk.qual.copy_(self.rows.qual[reads]); chk.meta.copy_(self.rows.meta[reads])
             self.check = (chk, nrows, two)
+        elif b is self.rows and check_reads and b.seg is None and not isinstance(b, dev.PairBatch):
+            # character rows as they are (what a caller's rows get: since round 4 the short-lived K2): the first rows once more, for the
+            # persistent kernel to look at
+            nrows = min(b.n, check_reads)
+            chk = dev.ReadBatch(nrows, b.pitch, with_corrected=False)
+            chk.seq.copy_(b.seq[:nrows]); chk.qual.copy_(b.qual[:nrows]); chk.meta.copy_(b.meta[:nrows])
+            self.check = (chk, nrows, False)
         self.rows = None
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
