@@ -37,7 +37,7 @@ for step in "$@"; do
     bench)     run bench 900 python bench.py ${arg:---steps 20 --warmup 5}; grep '^{' gpurun_out/bench_$TAG.log | tail -1 > gpurun_out/bench_$TAG.json ;;
     benchq)    run benchq 600 python bench.py --no-extra --cpu-sample 0 --steps 10 --warmup 3; grep '^{' gpurun_out/benchq_$TAG.log | tail -1 > gpurun_out/benchq_$TAG.json ;;
     hostentry) run hostentry 400 python scripts/time_host_entry.py ;;
-    e2e)       run e2e 900 python tests/tools/e2e_cli.py --reads 8000000 --reps 3 --modes ${arg:-resident} ;;
+    e2e)       run e2e 900 python tests/tools/e2e_cli.py --reads ${E2E_READS:-8000000} --reps ${E2E_REPS:-3} --modes ${arg:-resident} ;;
     fuzz)      seed=$(( $(date +%s) % 100000 ))
                run fuzz_kernels $((arg + 240)) python tests/tools/fuzz_gpu.py --seconds $arg --seed $seed && run fuzz_aligned $((arg + 240)) python tests/tools/fuzz_gpu_aligned.py --seconds $arg --seed $seed && run fuzz_cli $((arg + 240)) python tests/tools/fuzz_gpu_cli.py --seconds $arg --seed $seed ;;
     py)        s=${arg%%::*}; a=""; [[ "$arg" == *::* ]] && a=${arg#*::}
