@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -56,13 +57,7 @@ unsigned threads_for(size_t work) { return kbbq_threads_for(work); }
 template <typename F> void par_for(int64_t n, unsigned nt, F f)
 {
     if (nt <= 1 || n < 4096) { f(0, n); return; }
-    std::vector<std::thread> th;
-    const int64_t per = (n + nt - 1) / nt;
-    for (unsigned t = 0; t < nt; ++t) {
-        const int64_t lo = std::min<int64_t>(n, t * per), hi = std::min<int64_t>(n, lo + per);
-        if (lo < hi) th.emplace_back([=]() { f(lo, hi); });
-    }
-    for (auto& t : th) t.join();
+    kbbq_parallel_parts((size_t)n, nt, [&](unsigned, size_t lo, size_t hi) { f((int64_t)lo, (int64_t)hi); });      // parked workers (host_threads.h)
 }
 
 bool parse_int(const uint8_t* p, const uint8_t* e, int64_t& out)
@@ -141,40 +136,59 @@ int kbbq_sam_open(const char* path, kbbq_sam** out)
         if (f->owned.empty()) f->owned.push_back('\n');          // keeps "owned" distinguishable from "mapped"
         f->buf = f->owned.data(); f->size = f->owned.size();
     }
-    // line ends, in parallel
+    // line ends, in parallel; then every thread classifies ITS lines (blank / header / alignment) into lists of its own, which are
+    // concatenated in thread order = file order (round 4: this loop and the list merge used to run on one thread: 16 M lines)
     const unsigned nt = threads_for(f->size);
-    std::vector<std::vector<uint64_t>> parts(nt);
+    struct Part { std::vector<uint64_t> nl, hdr0, line0; std::vector<uint32_t> hdrlen, linelen; uint64_t first_start = 0; };
+    std::vector<Part> parts(nt);
+    const size_t per = (f->size + nt - 1) / std::max(nt, 1u);
+    kbbq_parallel(nt, [&](unsigned t) {
+        const size_t lo = std::min(f->size, (size_t)t * per), hi = std::min(f->size, lo + per);
+        const uint8_t* p = f->buf + lo; const uint8_t* e = f->buf + hi;
+        auto& v = parts[t].nl;
+        v.reserve((hi - lo) / 200 + 16);
+        while (p < e) {
+            const uint8_t* nl = (const uint8_t*)memchr(p, '\n', (size_t)(e - p));
+            if (!nl) break;
+            v.push_back((uint64_t)(nl - f->buf));
+            p = nl + 1;
+        }
+    });
     {
-        std::vector<std::thread> th;
-        const size_t per = (f->size + nt - 1) / nt;
-        for (unsigned t = 0; t < nt; ++t) {
-            const size_t lo = std::min(f->size, t * per), hi = std::min(f->size, lo + per);
-            th.emplace_back([f, lo, hi, &parts, t]() {
-                const uint8_t* p = f->buf + lo; const uint8_t* e = f->buf + hi;
-                while (p < e) {
-                    const uint8_t* nl = (const uint8_t*)memchr(p, '\n', (size_t)(e - p));
-                    if (!nl) break;
-                    parts[t].push_back((uint64_t)(nl - f->buf));
-                    p = nl + 1;
-                }
-            });
-        }
-        for (auto& t : th) t.join();
+        // the last line may lack its line end; a part's first line starts behind the last line end of the parts before it
+        int last = -1;
+        for (unsigned t = 0; t < nt; ++t) if (!parts[t].nl.empty()) last = (int)t;
+        if (f->size && (last < 0 || parts[(size_t)last].nl.back() != f->size - 1)) parts[nt - 1].nl.push_back(f->size);
+        uint64_t start = 0;
+        for (unsigned t = 0; t < nt; ++t) { parts[t].first_start = start; if (!parts[t].nl.empty()) start = parts[t].nl.back() + 1; }
     }
-    std::vector<uint64_t> nl;
-    for (auto& v : parts) nl.insert(nl.end(), v.begin(), v.end());
-    if (f->size && (nl.empty() || nl.back() != f->size - 1)) nl.push_back(f->size);
-    uint64_t start = 0;
-    for (uint64_t end : nl) {
-        uint64_t e = end;
-        if (e > start && f->buf[e - 1] == '\r') --e;
-        bool blank = true;
-        for (uint64_t k = start; k < e; ++k) if (f->buf[k] != ' ' && f->buf[k] != '\t') { blank = false; break; }
-        if (!blank) {
-            if (f->buf[start] == '@') { f->hdr0.push_back(start); f->hdrlen.push_back((uint32_t)(e - start)); }
-            else { f->line0.push_back(start); f->linelen.push_back((uint32_t)(e - start)); }
+    kbbq_parallel(nt, [&](unsigned t) {
+        Part& P = parts[t];
+        uint64_t start = P.first_start;
+        for (uint64_t end : P.nl) {
+            uint64_t e = end;
+            if (e > start && f->buf[e - 1] == '\r') --e;
+            bool blank = true;
+            for (uint64_t k = start; k < e; ++k) if (f->buf[k] != ' ' && f->buf[k] != '\t') { blank = false; break; }
+            if (!blank) {
+                if (f->buf[start] == '@') { P.hdr0.push_back(start); P.hdrlen.push_back((uint32_t)(e - start)); }
+                else { P.line0.push_back(start); P.linelen.push_back((uint32_t)(e - start)); }
+            }
+            start = end + 1;
         }
-        start = end + 1;
+    });
+    {
+        size_t nh = 0, nl_ = 0;
+        for (auto& P : parts) { nh += P.hdr0.size(); nl_ += P.line0.size(); }
+        f->hdr0.reserve(nh); f->hdrlen.reserve(nh); f->line0.resize(nl_); f->linelen.resize(nl_);
+        std::vector<size_t> at(nt + 1, 0);
+        for (unsigned t = 0; t < nt; ++t) at[t + 1] = at[t] + parts[t].line0.size();
+        for (auto& P : parts) { f->hdr0.insert(f->hdr0.end(), P.hdr0.begin(), P.hdr0.end()); f->hdrlen.insert(f->hdrlen.end(), P.hdrlen.begin(), P.hdrlen.end()); }
+        kbbq_parallel(nt, [&](unsigned t) {
+            if (parts[t].line0.empty()) return;
+            memcpy(f->line0.data() + at[t], parts[t].line0.data(), parts[t].line0.size() * sizeof(uint64_t));
+            memcpy(f->linelen.data() + at[t], parts[t].linelen.data(), parts[t].linelen.size() * sizeof(uint32_t));
+        });
     }
     // @RG IDs in header order
     for (size_t h = 0; h < f->hdr0.size(); ++h) {
@@ -194,11 +208,20 @@ int kbbq_sam_open(const char* path, kbbq_sam** out)
     for (size_t i = 0; i < f->rg_ids.size(); ++i) rgmap.emplace(f->rg_ids[i], (int)i);
 
     const int64_t n = (int64_t)f->line0.size();
-    f->name_len.assign(n, 0); f->seq_len.assign(n, 0); f->qual_len.assign(n, 0); f->oq_len.assign(n, 0); f->rgtag_len.assign(n, 0);
-    f->cig_n.assign(n, 0); f->clip.assign(n, 0); f->seq0.assign(n, 0); f->qual0.assign(n, 0); f->oq0.assign(n, 0); f->rgtag0.assign(n, 0);
-    f->cig_off.assign(n + 1, 0); f->flag.assign(n, 0); f->contig.assign(n, -1); f->ref_span.assign(n, 0); f->rg.assign(n, -1);
-    f->pos.assign(n, 0); f->pnext.assign(n, 0); f->tlen.assign(n, 0);
-    std::vector<uint64_t> rname0(n, 0), cig0(n, 0); std::vector<uint32_t> rname_len(n, 0), cig_len(n, 0);
+    std::vector<uint64_t> rname0, cig0; std::vector<uint32_t> rname_len, cig_len;
+    {
+        // 23 arrays of n entries (2 GB at 16 M alignments): sized and zeroed side by side instead of one after the other
+        const std::function<void()> fills[] = {
+            [&]() { f->name_len.assign(n, 0); }, [&]() { f->seq_len.assign(n, 0); }, [&]() { f->qual_len.assign(n, 0); }, [&]() { f->oq_len.assign(n, 0); },
+            [&]() { f->rgtag_len.assign(n, 0); }, [&]() { f->cig_n.assign(n, 0); }, [&]() { f->clip.assign(n, 0); }, [&]() { f->seq0.assign(n, 0); },
+            [&]() { f->qual0.assign(n, 0); }, [&]() { f->oq0.assign(n, 0); }, [&]() { f->rgtag0.assign(n, 0); }, [&]() { f->cig_off.assign(n + 1, 0); },
+            [&]() { f->flag.assign(n, 0); }, [&]() { f->contig.assign(n, -1); }, [&]() { f->ref_span.assign(n, 0); }, [&]() { f->rg.assign(n, -1); },
+            [&]() { f->pos.assign(n, 0); }, [&]() { f->pnext.assign(n, 0); }, [&]() { f->tlen.assign(n, 0); }, [&]() { rname0.assign(n, 0); },
+            [&]() { cig0.assign(n, 0); }, [&]() { rname_len.assign(n, 0); }, [&]() { cig_len.assign(n, 0); }};
+        const unsigned nf = (unsigned)(sizeof fills / sizeof fills[0]);
+        std::atomic<unsigned> next(0);
+        kbbq_parallel(std::min(nt, nf), [&](unsigned) { for (unsigned k; (k = next.fetch_add(1)) < nf;) fills[k](); });
+    }
     std::atomic<int64_t> badline(-1);
     auto flagbad = [&](int64_t i) { int64_t cur = badline.load(); while ((cur < 0 || i < cur) && !badline.compare_exchange_weak(cur, i)) {} };
     // pass 1: split fields, numbers, tags, count CIGAR operations
@@ -256,11 +279,16 @@ int kbbq_sam_open(const char* path, kbbq_sam** out)
     }
     // contigs in first-appearance order (serial: the order matters)
     std::unordered_map<std::string, int> cmap;
+    const uint8_t* last_name = nullptr; uint32_t last_len = 0; int last_id = -1;        // neighbours mostly share a contig: no string, no hash for them
     for (int64_t i = 0; i < n; ++i) {
-        std::string name((const char*)f->buf + rname0[i], rname_len[i]);
-        auto it = cmap.find(name);
-        if (it == cmap.end()) { it = cmap.emplace(name, (int)f->contigs.size()).first; f->contigs.push_back(name); }
-        f->contig[i] = it->second;
+        const uint8_t* nm = f->buf + rname0[i];
+        if (last_name && rname_len[i] == last_len && memcmp(nm, last_name, last_len) == 0) f->contig[i] = last_id;
+        else {
+            std::string name((const char*)nm, rname_len[i]);
+            auto it = cmap.find(name);
+            if (it == cmap.end()) { it = cmap.emplace(name, (int)f->contigs.size()).first; f->contigs.push_back(name); }
+            f->contig[i] = last_id = it->second; last_name = nm; last_len = rname_len[i];
+        }
         f->cig_off[i + 1] = f->cig_off[i] + f->cig_n[i];
     }
     f->cigar.assign(f->cig_off[n], 0);
