@@ -338,7 +338,8 @@ int kbbq_sam_fields(const kbbq_sam* f, int32_t* flag, int32_t* contig, int64_t* 
         for (int64_t i = 0; i < n; ++i)
             if (f->qual_len[i] > 65535 || f->oq_len[i] > 32768)
                 return kbbq_set_error_(KBBQ_E_ARG, "a QUAL field longer than 65535 or an OQ tag longer than 32768 characters: malformed line");
-    for (int64_t i = 0; i < n; ++i) {
+    par_for(n, threads_for((size_t)n * 64), [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; ++i) {
         if (flag) flag[i] = f->flag[i];
         if (contig) contig[i] = f->contig[i];
         if (pos) pos[i] = f->pos[i];
@@ -355,6 +356,7 @@ int kbbq_sam_fields(const kbbq_sam* f, int32_t* flag, int32_t* contig, int64_t* 
             has_qual_oq[i] = (noqual ? 0 : (int32_t)f->qual_len[i]) | (f->oq_len[i] ? (int32_t)(f->oq_len[i] - 1) << 16 : -65536);
         }
     }
+    });
     return KBBQ_OK;
 }
 
