@@ -297,6 +297,27 @@ def _qual_plane(reads, lens, pitch, use_oq, rows=None):
     return q
 
 
+def _qual_chars_dev(reads, lens, pitch, use_oq, rows=None):
+    """The quality characters (QUAL, or the OQ tag) of a native reader's alignments as a device plane [n, pitch], zero behind every
+    read -- checked like _qual_plane: lengths on the host arrays, the value range on the device (every byte below '!' must be padding)."""
+    from . import _device as dev
+    torch = dev._torch()
+    b = reads.batch()
+    lo, hi = (0, b.n) if rows is None else rows
+    n = hi - lo
+    have = (b.oq_len if use_oq else b.qual_len)[lo:hi]
+    if use_oq and n and int(have.min()) < 0:
+        raise KeyError("tag 'OQ' not present")
+    if n and np.any(have != lens):
+        i = int(np.flatnonzero(have != lens)[0])
+        raise _at(IndexError('boolean index did not match indexed array: read %d has %d qualities for %d bases'
+                             % (lo + i, int(have[i]), int(lens[i]))), i)
+    chars = torch.from_numpy(b.plane(2 if use_oq else 1, pitch, lo, n)).cuda()
+    if n and int((chars[:n] < 33).sum().item()) != n * pitch - int(np.asarray(lens, dtype=np.int64).sum()):
+        raise ValueError('qualities must lie in 0..255')
+    return chars
+
+
 def _at(exc, index):
     """Tag an exception with the read of this rank's shard it is about (as the kernels' status does): the ranks then
     agree on the first one (parallel.raise_first_error)."""
@@ -329,10 +350,15 @@ def benchmark_bam(bamfile, ref, var_sites, use_oq=False, bedfh=None):
 
     def shard():
         err, skip, lens, pitch = _flag_batch(reads, genome, flip_reverse=False, rows=rows, fused=True)
-        qual = torch.from_numpy(_qual_plane(reads, lens, pitch, use_oq, rows)).cuda()
-        return qual, err, skip, lens, pitch
-    qual, err, skip, lens, pitch = _on_all_ranks(shard, rows[0] if rows else 0)
-    return _actual_q(*_count_q(qual, err, skip, lens, pitch, 0, reduce=world > 1))
+        if isinstance(reads, aln.AlignmentFile):
+            # the native reader's plane of quality CHARACTERS goes up as it is and K5 subtracts the 33 (three masked NumPy passes over
+            # the plane were 60 % of this function: 47 ms per 200 K alignments); a character below '!' is the reference's ValueError
+            qual, offset = _qual_chars_dev(reads, lens, pitch, use_oq, rows), 33
+        else:
+            qual, offset = torch.from_numpy(_qual_plane(reads, lens, pitch, use_oq, rows)).cuda(), 0
+        return qual, err, skip, lens, pitch, offset
+    qual, err, skip, lens, pitch, offset = _on_all_ranks(shard, rows[0] if rows else 0)
+    return _actual_q(*_count_q(qual, err, skip, lens, pitch, offset, reduce=world > 1))
 
 
 LAST_RUN = {}            # what the most recent benchmark_fastq flagged on this rank (tests, KBBQ_TIMING): K4's share of the alignments
