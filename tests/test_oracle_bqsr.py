@@ -263,3 +263,23 @@ def test_per_read_applybqsr_functions_match_the_reference(oracle, name, tmp_path
         assert np.array_equal(np.concatenate([applybqsr.bamread_dinuc_covariates(r) for r in reads]), gold['ab_dinuc'])
         got = np.concatenate([applybqsr.recalibrate_bamread(r, vectors[0], *dqs, rg_to_int) for r in reads])
         assert got.dtype == np.int_ and np.array_equal(got, gold['ab_recal'])
+
+
+def test_closed_form_trim_of_one_op_alignments_is_the_cigar_walk():
+    """bam_to_bqsr_covariates skips the per-read CIGAR walk for alignments of one match op: the closed form against
+    _trim_range on every (start, length, boundary, strand) of a small grid, with the candidate conditions of the caller
+    (boundary inside the alignment)."""
+    from kbbq.gatk import bqsr
+    rows = []
+    for op in (0, 7, 8):
+        for start in (0, 3, 100):
+            for n in (1, 2, 7, 151):
+                for boundary in range(start, start + n):
+                    for rev in (False, True):
+                        rows.append((op, start, n, boundary, rev))
+    rev = np.array([r[4] for r in rows]); start = np.array([r[1] for r in rows]); n = np.array([r[2] for r in rows])
+    bnd = np.array([r[3] for r in rows])
+    got = bqsr._plain_trim(rev, start, n, bnd, bnd)
+    for (op, s, l, b, rv), g in zip(rows, got):
+        lo, hi = bqsr._trim_range(bqsr._CigarView([(op, l)], s, s + l, rv, l), b)
+        assert (int(g) & 0xFFFF, int(g) >> 16) == (lo, hi), (op, s, l, b, rv, lo, hi, g)
