@@ -519,6 +519,9 @@ int kbbq_sam_fields(const kbbq_sam* f, int32_t* flag, int32_t* contig, int64_t* 
                     int32_t* qlen, int32_t* ref_span, uint32_t* clip, uint32_t* cig_off, uint32_t* cig_n, int32_t* rg,
                     int32_t* has_qual_oq);
 int kbbq_sam_cigar(const kbbq_sam* f, uint32_t* ops);
+/* trim[i] = lo | hi << 16: query positions [lo, hi) of alignment i lie past its adaptor boundary (0: none) -- the reference's
+ * bamread_adaptor_boundary + trim_bamread (gatk/bqsr.py:131-206) for every alignment of the file, by CIGAR walk. */
+int kbbq_sam_adaptor_trim(const kbbq_sam* f, uint32_t* trim);
 int kbbq_sam_fill(const kbbq_sam* f, int64_t first, int64_t n, int pitch, int which, uint8_t* plane);
 int kbbq_sam_text(const kbbq_sam* f, int what, int64_t i, const char** p, int64_t* len);
 

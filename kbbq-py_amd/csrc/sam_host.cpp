@@ -367,6 +367,75 @@ int kbbq_sam_cigar(const kbbq_sam* f, uint32_t* ops)
     return KBBQ_OK;
 }
 
+// Query positions [lo, hi) of every alignment that lie past its adaptor boundary, as lo | hi << 16 (0: nothing to trim) --
+// what gatk/bqsr.py bamread_adaptor_boundary + _trim_range compute per read (reference bqsr.py:131-206), for all
+// alignments at once: the boundary from FLAG / POS / PNEXT / TLEN, then one walk over the CIGAR of the few reads it falls into.
+int kbbq_sam_adaptor_trim(const kbbq_sam* f, uint32_t* trim)
+{
+    if (!f || (!trim && !f->line0.empty())) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_sam_adaptor_trim: NULL argument");
+    const int64_t n = (int64_t)f->line0.size();
+    par_for(n, threads_for((size_t)n * 64), [&](int64_t lo_i, int64_t hi_i) {
+    for (int64_t i = lo_i; i < hi_i; ++i) {
+        trim[i] = 0;
+        const int32_t fl = f->flag[i];
+        const bool rev = fl & 16, mate_rev = fl & 32;
+        if (f->tlen[i] == 0 || !(fl & 1) || (fl & 4) || (fl & 8) || rev == mate_rev) continue;
+        const int64_t start = f->pos[i], end = start + f->ref_span[i];
+        const bool noqual = f->qual_len[i] == 1 && f->buf[f->qual0[i]] == '*';
+        const int64_t nq = noqual ? 0 : (int64_t)f->qual_len[i];
+        const uint32_t* ops = f->cigar.data() + f->cig_off[i];
+        const int64_t nops = f->cig_n[i];
+        auto on_query_and_ref = [](uint32_t op) { return op == 0 || op == 7 || op == 8; };
+        int64_t lo = 0, hi = 0;
+        if (rev) {
+            if (!(end - 1 > f->pnext[i])) continue;
+            const int64_t boundary = f->pnext[i] - 1;
+            if (boundary < start) continue;
+            int64_t q = 0, r = end;
+            for (int64_t k = 0; k < nops; ++k) { const uint32_t op = ops[k] & 15; if (on_query_and_ref(op) || op == 1 || op == 4) q += ops[k] >> 4; }
+            bool reached = false, found = false;
+            for (int64_t k = nops - 1; k >= 0 && !found; --k) {
+                const uint32_t op = ops[k] & 15; const int64_t l = ops[k] >> 4;
+                if (on_query_and_ref(op)) {
+                    if (reached) { hi = q; found = true; }
+                    else if (r - l <= boundary) { hi = q - ((r - 1) - std::min(boundary, r - 1)); found = true; }
+                    else { q -= l; r -= l; }
+                } else if (op == 1 || op == 4) {
+                    if (reached) { hi = q; found = true; } else q -= l;
+                } else if (op == 2 || op == 3) {
+                    if (r - l <= boundary) reached = true;
+                    r -= l;
+                }
+            }
+            if (!found) continue;
+        } else {
+            if (!(start <= f->pnext[i] + f->tlen[i])) continue;
+            const int64_t boundary = start + (f->tlen[i] < 0 ? -f->tlen[i] : f->tlen[i]);
+            if (boundary > end - 1) continue;
+            int64_t q = 0, r = start;
+            bool reached = false, found = false;
+            hi = nq;
+            for (int64_t k = 0; k < nops && !found; ++k) {
+                const uint32_t op = ops[k] & 15; const int64_t l = ops[k] >> 4;
+                if (on_query_and_ref(op)) {
+                    if (reached) { lo = q; found = true; }
+                    else if (r + l > boundary) { lo = q + std::max<int64_t>(boundary - r, 0); found = true; }
+                    else { q += l; r += l; }
+                } else if (op == 1 || op == 4) {
+                    if (reached) { lo = q; found = true; } else q += l;
+                } else if (op == 2 || op == 3) {
+                    if (r + l > boundary) reached = true;
+                    r += l;
+                }
+            }
+            if (!found) lo = nq;
+        }
+        trim[i] = (uint32_t)(lo & 0xFFFF) | (uint32_t)(hi & 0xFFFF) << 16;
+    }
+    });
+    return KBBQ_OK;
+}
+
 // which: 0 SEQ, 1 QUAL, 2 OQ tag; rows [0, n) <- alignments [first, first + n), zero padded; a missing / '*' field
 // leaves its row zero
 int kbbq_sam_fill(const kbbq_sam* f, int64_t first, int64_t n, int pitch, int which, uint8_t* plane)

@@ -116,6 +116,7 @@ PROTOTYPES = {
     'kbbq_sam_info': (_i, [_vp, _vp]),
     'kbbq_sam_fields': (_i, [_vp] * 13),
     'kbbq_sam_cigar': (_i, [_vp, _vp]),
+    'kbbq_sam_adaptor_trim': (_i, [_vp, _vp]),
     'kbbq_sam_fill': (_i, [_vp, _i64, _i64, _i, _i, _vp]),
     'kbbq_sam_text': (_i, [_vp, _i, _i64, _vp, _vp]),
     'kbbq_sam_match_fastq': (_i, [_vp, _vp, _vp]),

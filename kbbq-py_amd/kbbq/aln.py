@@ -224,6 +224,14 @@ class SamBatch:
         N.check(N.load().kbbq_sam_fill(self._native, first, n, pitch, which, N.ptr(out)))
         return out
 
+    def adaptor_trim(self):
+        """uint32 [n]: lo | hi << 16, the query positions [lo, hi) past each alignment's adaptor boundary (0: none) -- what
+        gatk.bqsr.bamread_adaptor_boundary + _trim_range give read by read (reference bqsr.py:131-206)."""
+        from . import _native as N
+        out = np.zeros(max(self.n, 1), dtype=np.uint32)
+        N.check(N.load().kbbq_sam_adaptor_trim(self._native, N.ptr(out)))
+        return out[:self.n]
+
     def names(self):
         return [self._text(0, i) for i in range(self.n)]
 

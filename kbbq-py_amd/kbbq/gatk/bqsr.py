@@ -122,15 +122,6 @@ def _trim_range(read, boundary=_UNSET):
     return n, n
 
 
-def _plain_trim(rev, start, nqual, bnd_rev, bnd_fwd):
-    """_trim_range for alignments whose CIGAR is one match op, whose boundary lies inside them (arrays in, lo | hi << 16
-    out): reverse [0, boundary - start + 1), forward [max(boundary - start, 0), n)."""
-    start = np.asarray(start, dtype=np.int64)
-    hi_r = np.clip(np.asarray(bnd_rev, dtype=np.int64) - start + 1, 0, 0xFFFF)
-    lo_f = np.clip(np.asarray(bnd_fwd, dtype=np.int64) - start, 0, 0xFFFF)
-    return np.where(rev, hi_r << 16, lo_f | (np.asarray(nqual, dtype=np.int64) << 16)).astype(np.uint32)
-
-
 def trim_bamread(read, boundary=_UNSET):
     """Boolean array: bases to skip because they lie past the adaptor boundary (reference
     bqsr.py:158-206).  `boundary` defaults to bamread_adaptor_boundary(read), looked up at call
@@ -185,26 +176,8 @@ def bam_to_bqsr_covariates(bamfileobj, fastafilename, var_pos, minscore=6, maxsc
         if wrong.size:
             bad_length = int(wrong[0])
         clip = b.clip.copy()
-        rev, mate_rev = (b.flag & 16) != 0, (b.flag & 32) != 0
-        ref_end = b.pos + b.ref_span
-        usable = (b.tlen != 0) & ((b.flag & 1) != 0) & ((b.flag & 4) == 0) & ((b.flag & 8) == 0) & (rev != mate_rev)
-        bnd_rev = b.pnext - 1
-        cand_rev = usable & rev & ((ref_end - 1) > b.pnext) & (bnd_rev >= b.pos)
-        bnd_fwd = b.pos + np.abs(b.tlen)
-        cand_fwd = usable & ~rev & (b.pos <= b.pnext + b.tlen) & (bnd_fwd <= ref_end - 1)
-        trim = np.zeros(n, dtype=np.uint32)
-        cand = cand_rev | cand_fwd
-        # one match op and nothing else (most reads): _trim_range in closed form -- reverse [0, boundary - start + 1),
-        # forward [max(boundary - start, 0), n)
-        first_op = b.cigar[np.minimum(b.cig_off, max(len(b.cigar) - 1, 0))] if len(b.cigar) else np.zeros(n, dtype=np.uint32)
-        plain = cand & (b.cig_n == 1) & np.isin(first_op & 15, (0, 7, 8))
-        if plain.any():
-            trim[plain] = _plain_trim(rev, b.pos, b.qual_len, bnd_rev, bnd_fwd)[plain]
-        for i in np.flatnonzero(cand & ~plain):
-            ops = [(int(x) & 15, int(x) >> 4) for x in b.cigar[b.cig_off[i]:b.cig_off[i] + b.cig_n[i]]]
-            shim = _CigarView(ops, int(b.pos[i]), int(ref_end[i]), bool(rev[i]), int(b.qual_len[i]))
-            lo, hi = _trim_range(shim, int(bnd_rev[i]) if rev[i] else int(bnd_fwd[i]))
-            trim[i] = lo | (hi << 16)
+        rev = (b.flag & 16) != 0
+        trim = b.adaptor_trim()                # boundary + CIGAR walk per alignment, in the reader (csrc/sam_host.cpp)
         flags = (rev.astype(np.uint32) | (((b.flag & 128) != 0).astype(np.uint32) << 1) | (b.rg.astype(np.uint32) << 16))
     else:
         S = len(reads[0].query_qualities)

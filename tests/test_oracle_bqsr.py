@@ -265,21 +265,46 @@ def test_per_read_applybqsr_functions_match_the_reference(oracle, name, tmp_path
         assert got.dtype == np.int_ and np.array_equal(got, gold['ab_recal'])
 
 
-def test_closed_form_trim_of_one_op_alignments_is_the_cigar_walk():
-    """bam_to_bqsr_covariates skips the per-read CIGAR walk for alignments of one match op: the closed form against
-    _trim_range on every (start, length, boundary, strand) of a small grid, with the candidate conditions of the caller
-    (boundary inside the alignment)."""
+def test_native_adaptor_trim_is_the_per_read_walk(oracle, tmp_path):
+    """SamBatch.adaptor_trim() (csrc/sam_host.cpp, every alignment at once -- what bam_to_bqsr_covariates uses) against
+    the reference's own trim arrays on the goldens, and against the per-read bamread_adaptor_boundary + _trim_range on
+    random pairs: every CIGAR operation, boundaries inside deletions / insertions / clips, both strands, odd flags."""
+    from kbbq import aln
     from kbbq.gatk import bqsr
-    rows = []
-    for op in (0, 7, 8):
-        for start in (0, 3, 100):
-            for n in (1, 2, 7, 151):
-                for boundary in range(start, start + n):
-                    for rev in (False, True):
-                        rows.append((op, start, n, boundary, rev))
-    rev = np.array([r[4] for r in rows]); start = np.array([r[1] for r in rows]); n = np.array([r[2] for r in rows])
-    bnd = np.array([r[3] for r in rows])
-    got = bqsr._plain_trim(rev, start, n, bnd, bnd)
-    for (op, s, l, b, rv), g in zip(rows, got):
-        lo, hi = bqsr._trim_range(bqsr._CigarView([(op, l)], s, s + l, rv, l), b)
-        assert (int(g) & 0xFFFF, int(g) >> 16) == (lo, hi), (op, s, l, b, rv, lo, hi, g)
+
+    def expand(trim, nq):
+        out = np.zeros(int(nq.sum()), dtype=bool)
+        at = np.concatenate([[0], np.cumsum(nq)])
+        for i, t in enumerate(trim):
+            out[at[i] + (int(t) & 0xFFFF):at[i] + (int(t) >> 16)] = True
+        return out
+    for name in ('bqsr_a', 'bqsr_b'):
+        _, gold, paths = _inputs(name, tmp_path, oracle)
+        b = aln.AlignmentFile(paths['sam']).batch()
+        assert np.array_equal(expand(b.adaptor_trim(), b.qual_len), gold['trim'].astype(bool))
+    rng = np.random.default_rng(11)
+    lines = ['@HD\tVN:1.6', '@SQ\tSN:c\tLN:100000', '@RG\tID:g']
+    for i in range(3000):
+        ops, q = [], 0
+        for k in range(int(rng.integers(1, 7))):
+            op = 'MIDNS=X'[int(rng.integers(0, 7))] if k else 'MS=X'[int(rng.integers(0, 4))]
+            l = int(rng.integers(1, 12))
+            ops.append((l, op)); q += l if op in 'MIS=X' else 0
+        if q == 0 or not any(op in 'M=X' for _, op in ops):
+            ops.append((5, 'M')); q += 5
+        span = sum(l for l, op in ops if op in 'MDN=X')
+        pos = int(rng.integers(1, 500))
+        flag = int(rng.choice([99, 147, 83, 163] * 3 + [67, 115, 73, 97, 0, 16, 1 | 16 | 8, 4 | 1 | 32]))
+        pnext = max(1, pos + int(rng.integers(-span - 5, span + 6)))
+        tlen = int(rng.integers(-span - 8, span + 9))
+        qual = 'I' * q
+        lines.append('\t'.join(['r%d' % i, str(flag), 'c', str(pos), '60', ''.join('%d%s' % o for o in ops), '=', str(pnext), str(tlen),
+                                'A' * q, qual, 'RG:Z:g', 'OQ:Z:' + 'I' * q]))
+    sam = tmp_path / 'rand.sam'
+    sam.write_text('\n'.join(lines) + '\n')
+    f = aln.AlignmentFile(str(sam))
+    got = f.batch().adaptor_trim()
+    reads = list(aln.AlignmentFile(str(sam)))
+    want = [bqsr._trim_range(r) for r in reads]
+    assert [(int(t) & 0xFFFF, int(t) >> 16) for t in got] == want
+    assert sum(1 for lo, hi in want if hi > lo) > 300                      # the cases do trim
