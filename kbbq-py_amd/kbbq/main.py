@@ -82,14 +82,16 @@ def _leave():
     import sys
     if 'torch' in sys.modules or os.environ.get('KBBQ_SLOW_EXIT'):
         return
+    code = 0
     try:
         sys.stdout.flush()
         sys.stderr.flush()
         atexit._run_exitfuncs()
         sys.stdout.flush()
         sys.stderr.flush()
-    finally:
-        os._exit(0)
+    except BaseException:                    # noqa: BLE001 -- a flush that fails (closed pipe, full disk) must not look like success:
+        code = 120                           # the status the interpreter itself leaves with when its final flush fails
+    os._exit(code)
 
 
 if __name__ == '__main__':

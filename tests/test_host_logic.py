@@ -1067,3 +1067,16 @@ def test_streaming_helpers_without_a_device(oracle, tmp_path):
         assert (na, nb) == (n, keep)
     sa = fastx.FastqStream(fa)
     assert sum(a.n for a, b in recalibrate._pair_segments(sa, None, 1 << 16) if b is None) == n
+
+
+def test_fast_exit_reports_a_failed_flush():
+    """main._leave (the single-process command's os._exit): output that cannot be flushed must not end in status 0."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from kbbq import main; sys.stdout.write('x' * 100); main._leave(); sys.exit(7)"
+            % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'kbbq-py_amd'))
+    with open('/dev/full', 'wb') as full:
+        r = subprocess.run([sys.executable, '-c', code], stdout=full, stderr=subprocess.PIPE)
+    assert r.returncode == 120, (r.returncode, r.stderr)
+    r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout == b'x' * 100
