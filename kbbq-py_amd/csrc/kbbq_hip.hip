@@ -101,9 +101,19 @@ int kbbq_ctx_create(int device, kbbq_ctx** out)
 {
     if (!out) return fail(KBBQ_E_ARG, "kbbq_ctx_create: out is NULL");
     *out = nullptr;
+    const bool dbg = getenv("KBBQ_CTX_DBG") != nullptr;         // where the context's first-use milliseconds go (stderr)
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[kbbq_ctx_create] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     HIPCHK(hipSetDevice(device));
+    lap("hipSetDevice");
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
+    lap("hipGetDeviceProperties");
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(KBBQ_E_HIP, "libkbbq_hip is built for gfx950 only; device %d is %s", device, prop.gcnArchName);
     kbbq_ctx* c = new kbbq_ctx();
@@ -115,12 +125,15 @@ int kbbq_ctx_create(int device, kbbq_ctx** out)
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(KBBQ_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     c->stream = c->own_stream;
+    lap("hipStreamCreate");
     e = hipMalloc((void**)&c->d_status, sizeof ST_INIT);
     if (e != hipSuccess) { (void)hipStreamDestroy(c->own_stream); delete c; return fail(KBBQ_E_HIP, "hipMalloc(status): %s", hipGetErrorString(e)); }
     e = hipMemcpy(c->d_status, ST_INIT, sizeof ST_INIT, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(c->d_status); (void)hipStreamDestroy(c->own_stream); delete c; return fail(KBBQ_E_HIP, "hipMemcpy(status): %s", hipGetErrorString(e)); }
+    lap("hipMalloc + hipMemcpy");
     // allow the full 160 KiB of LDS as dynamic shared memory
     (void)hipFuncSetAttribute((const void*)k1_accumulate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
+    lap("first hipFuncSetAttribute");
     (void)hipFuncSetAttribute((const void*)k1_accumulate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k1v3_accumulate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k1v3_accumulate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
@@ -155,6 +168,7 @@ int kbbq_ctx_create(int device, kbbq_ctx** out)
     (void)hipFuncSetAttribute((const void*)k2_apply<int16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipFuncSetAttribute((const void*)k2_apply<int8_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_bytes);
     (void)hipGetLastError();
+    lap("the other attributes");
     *out = c;
     return KBBQ_OK;
 }

@@ -102,7 +102,14 @@ class _Pool:
             if self.limit is not None and self.kept and self.reserved + nbytes > self.limit:
                 self._release_kept()
         p = ctypes.c_void_p()
-        N.check(N.load().kbbq_dev_alloc(_ctx(index).handle, nbytes, ctypes.byref(p)))
+        rc = N.load().kbbq_dev_alloc(_ctx(index).handle, nbytes, ctypes.byref(p))
+        if rc:                               # out of memory while blocks are being kept: give them back and ask once more
+            with self.lock:
+                had = bool(self.kept)
+                self._release_kept()
+            if had:
+                rc = N.load().kbbq_dev_alloc(_ctx(index).handle, nbytes, ctypes.byref(p))
+        N.check(rc)
         with self.lock:
             self._count(nbytes, nbytes)
         return p.value, nbytes
