@@ -277,10 +277,12 @@ class NativeFastq:
     def is_plain(self):
         return bool(_N.load().kbbq_fastq_is_plain(self._h))
 
+    _h = None                                # (class default: what a closed reader's handle reads as)
+
     def close(self):
-        if getattr(self, '_h', None):
-            _N.load().kbbq_fastq_close(self._h)
-            self._h = None
+        h = self.__dict__.pop('_h', None)    # one atomic step: a close on a helper thread (close_later) and another here cannot both get it
+        if h:
+            _N.load().kbbq_fastq_close(h)
 
     def __del__(self):
         try:
@@ -442,10 +444,12 @@ class FastqStream:
         self.records += f.n
         return f, bool(end.value)
 
+    _h = None
+
     def close(self):
-        if getattr(self, '_h', None):
-            _N.load().kbbq_fastq_stream_close(self._h)
-            self._h = None
+        h = self.__dict__.pop('_h', None)
+        if h:
+            _N.load().kbbq_fastq_stream_close(h)
 
     def __del__(self):
         try:

@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'kbbq-py_amd'))
 import numpy as np
 NATIVE = '--native' in sys.argv          # device memory from the library's own C ABI (kbbq/_hipmem.py), as the command line without torch
+TIMELINE = '--timeline' in sys.argv       # the default configuration only, every stage's start and end since recalibrate_fastq was called
+if TIMELINE:
+    sys.argv.remove('--timeline')
 if NATIVE:
     sys.argv.remove('--native')
     from kbbq import _device as dev
@@ -66,6 +69,22 @@ def run(label, env, reps=3):
 
 
 try:
+    if TIMELINE:
+        _trace.TIMELINE = True
+        for rep in range(3):
+            if os.path.exists(fo):
+                os.remove(fo)
+            _trace.collect(True); del _trace._events[:]
+            w0 = time.time(); t0 = time.perf_counter()
+            recalibrate.recalibrate_fastq([fa, fb], output=fo)
+            wall = time.perf_counter() - t0
+            _trace.collect(False)
+            print('repetition %d: wall %.3f s' % (rep, wall))
+            for a, b, name in sorted(_trace._events):
+                if b - a >= 0.001:
+                    print('  %7.3f .. %7.3f  %s' % (a - w0, b - w0, name))
+            sys.stdout.flush()
+        raise SystemExit(0)
     if NATIVE:
         for rep in range(3):             # every repetition on its own line: is `apply` (40 ms in the command line) a first-call cost?
             run('repetition %d' % rep, {}, reps=1)
