@@ -584,6 +584,12 @@ def close_later(reader):
     threading.Thread(target=reader.close, daemon=True).start()
 
 
+def retire(reader):
+    """No new work may start on the reader (band_rows treats it as closed); it stays mapped until somebody closes it."""
+    reader._closing = True
+    return reader
+
+
 class PairScan:
     """Both files of a pair being opened (mapped, line-indexed) and scanned by the C++ reader on its own threads --
     started by the constructor, which returns at once; result() waits.  The work needs no interpreter lock, so a

@@ -169,8 +169,11 @@ def _pack_and_tally(fastq, infer_rg, minscore, maxscore):
     try:
         tables = _tally(packed, minscore, maxscore)
     finally:
+        # the corrected file is not needed past the tally.  It is only RETIRED here (no new work starts on it) and unmapped by the
+        # caller after its last byte: unmapping 2.5 GB holds the address space's lock for 30-40 ms, and done beside pass 2 --
+        # as rounds 3 and 4 did -- it stalled the first slabs' page faults, buffer allocations and write(2) for as long
         if packed.get('other') is not None:
-            fastx.close_later(packed.pop('other'))     # the corrected file is not needed past the tally: unmap it off the critical path
+            packed['retired'] = fastx.retire(packed.pop('other'))
     if tables is not None and packed.get('total', packed['n']) == 0:
         tables = None
     return packed, tables
@@ -192,6 +195,8 @@ def fastq_to_covariate_arrays(fastq, infer_rg=False, minscore=6, maxscore=42):
         packed = dict(R=len(run.rgs) if run.usable else 0, S=run.longest)
     else:
         packed, tables = _pack_and_tally(fastq, infer_rg, minscore, maxscore)
+        if packed.get('retired') is not None:
+            fastx.close_later(packed.pop('retired'))
     if tables is None:
         z = lambda *s: np.zeros(s, dtype=np.int64)
         R, S = packed['R'], packed['S']
@@ -251,11 +256,23 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None, output=None):
     if any(fastx.is_sequential_input(p) for p in fastq) or os.environ.get('KBBQ_SEQUENTIAL'):
         return _recalibrate_sequential(fastq, infer_rg, gatkreport, output)
     shard = (rank, world) if world > 1 else None
+    done_with = []                           # readers to unmap on a helper thread once the last byte is out (or the call has failed)
+    try:
+        return _recalibrate_mapped(fastq, infer_rg, gatkreport, output, world, rank, shard, done_with)
+    finally:
+        for reader in done_with:
+            if reader is not None:
+                fastx.close_later(reader)
+
+
+def _recalibrate_mapped(fastq, infer_rg, gatkreport, output, world, rank, shard, done_with):
+    """recalibrate_fastq on mapped, indexed inputs (regular files): resident on the device, or slab by slab within the budget."""
     packed, single = None, None
     if gatkreport is not None and os.path.exists(gatkreport):
         scan = fastx.PairScan(fastq[0], None, infer_rg)
         _warm_up()
         text = scan.result()[0]
+        done_with.append(text)
         if text.n == 0:
             return
         single = fastx.pack_single(text, infer_rg, shard, bands=True, to_device=True, budget=dev.device_budget())
@@ -263,6 +280,7 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None, output=None):
     else:
         packed, tables = _pack_and_tally(fastq, infer_rg, 6, 42)
         text = packed['text']
+        done_with.extend([text, packed.get('retired')])
         if text.total == 0:
             return
         if tables is None:
@@ -284,6 +302,7 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None, output=None):
         if single is None:
             if text.n != text.total:
                 text = fastx.NativeFastq(fastq[0])                 # a shard's reader: pass 2 needs all of file A
+                done_with.append(text)
             single = fastx.pack_single(text, infer_rg, shard, bands=True, to_device=True, budget=dev.device_budget())
 
     if single.get('streamed'):
@@ -340,7 +359,6 @@ def recalibrate_fastq(fastq, infer_rg=False, gatkreport=None, output=None):
     else:
         with open(output if world == 1 else '%s.rank%04d' % (output, rank), 'wb') as sink:
             _egress.emit_records(text, single['first'], single['bands'], outs, sink=sink)
-    fastx.close_later(text)                  # unmapping GBs of input and freeing its index: 30-60 ms nobody needs to wait for
 
 
 def _prefetched(items, depth=1):
@@ -617,9 +635,6 @@ def _emit_streamed(text, single, lut, shape, output, world, rank):
                                     tables_bytes=8 * int(dev.N.load().kbbq_tables_count(shape[0], shape[2])), lut_bytes=int(lut.numel()))
     finally:
         peak.close()
-    fastx.close_later(st['A'])
-    if text is not st['A']:
-        fastx.close_later(text)
 
 
 def recalibrate_bam(bam, use_oq=False, set_oq=False):
