@@ -86,6 +86,7 @@ class _Pool:
         self.lock = threading.Lock()
         self.live = self.peak = self.reserved = self.peak_reserved = 0
         self.limit = None                    # bytes this module may hold (live + kept); None: nothing is kept
+        self.keep_all = False                # a process about to end (the command line): nothing goes back to the runtime
         self.kept = []                       # (nbytes, ptr, index)
 
     def take(self, index, nbytes):
@@ -117,7 +118,7 @@ class _Pool:
     def give(self, index, ptr, size):
         with self.lock:
             self.live -= size
-            if self.limit is not None and size >= (1 << 20) and self.reserved <= self.limit:
+            if (self.keep_all and self.limit is None) or (self.limit is not None and size >= (1 << 20) and self.reserved <= self.limit):
                 self.kept.append((size, ptr, index))
                 return
             self.reserved -= size
@@ -418,8 +419,15 @@ class _Cuda:
         """From now on released device allocations are kept for reuse while the module holds no more than `nbytes` (None:
         back to releasing everything at once)."""
         _pool.limit = None if nbytes is None else int(nbytes)
-        if nbytes is None:
+        if nbytes is None and not _pool.keep_all:
             _pool.empty_cache()
+
+    @staticmethod
+    def keep_released_memory(on=True):
+        """Released device allocations stay with this module (to be reused, or to go with the process): hipFree waits for the
+        device and unmaps -- 10-20 ms per GB-sized plane, 80 ms at the end of the command line for memory the exiting
+        process returns anyway.  An allocation that fails gives everything kept back first (_Pool.take)."""
+        _pool.keep_all = bool(on)
 
     @staticmethod
     def current_device():

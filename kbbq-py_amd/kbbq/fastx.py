@@ -581,7 +581,17 @@ def close_later(reader):
     the path to the first kernel (the C call runs without the interpreter lock)."""
     import threading
     reader._closing = True                   # from here on nobody may start new work on it (band_rows)
+    if LEAVE_OPEN:
+        _left_open.append(reader)
+        return
     threading.Thread(target=reader.close, daemon=True).start()
+
+
+# The command line as a single process ends with os._exit right after its last byte (main._leave): unmapping GBs of input -- on a
+# helper thread or not -- only makes everything else that needs the address space's lock wait (the interpreter freeing its arrays
+# on the way out: 80 ms); the readers are parked here and go with the process.
+LEAVE_OPEN = False
+_left_open = []
 
 
 def retire(reader):

@@ -9,6 +9,9 @@ from . import __version__
 from . import recalibrate as _recal
 
 
+_ENDS_WITH_THE_COMMAND = False               # set by `python -m kbbq.main`: the process ends (main._leave) when the command has run
+
+
 def recalibrate(args):
     import os
     from . import parallel
@@ -16,8 +19,12 @@ def recalibrate(args):
     if world == 1 and 'torch' not in __import__('sys').modules and not os.environ.get('KBBQ_USE_TORCH'):
         # one GPU: nothing of PyTorch is needed -- device memory, page-locked slabs, copies and events come from the library's
         # own C ABI (kbbq/_hipmem.py) and `import torch` (~1 s with its HIP context) never happens
-        from . import _device
+        from . import _device, _hipmem, fastx
         _device.use_native_memory()
+        if _ENDS_WITH_THE_COMMAND and not os.environ.get('KBBQ_SLOW_EXIT'):
+            # this process ends right after its last byte (_leave): what it holds goes with it instead of being returned piece by piece
+            _hipmem.cuda.keep_released_memory(True)
+            fastx.LEAVE_OPEN = True
     _recal.recalibrate(bam=args.bam, fastq=args.fastq, infer_rg=args.infer_rg,
                        use_oq=args.use_oq, set_oq=args.set_oq, gatkreport=args.gatkreport, output=args.output)
 
@@ -95,5 +102,6 @@ def _leave():
 
 
 if __name__ == '__main__':
+    _ENDS_WITH_THE_COMMAND = True
     main()
     _leave()

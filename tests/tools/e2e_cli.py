@@ -32,7 +32,7 @@ def sha(path):
         for blk in iter(lambda: f.read(1 << 24), b''):
             h.update(blk)
     return h.hexdigest()[:16]
-base_env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, 'kbbq-py_amd'), KBBQ_TIMING='1')
+base_env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, 'kbbq-py_amd'), KBBQ_TIMING=os.environ.get('KBBQ_TIMING', '1'))     # 2: the stages' timeline since the process started
 shas = {}
 for mode in a.modes.split(','):
     env = dict(base_env)
