@@ -1,5 +1,6 @@
 // bam_host.cpp -- see bam_host.h.  Host only, no GPU code.
 #include "bam_host.h"
+#include "fast_inflate.h"
 #include "host_threads.h"
 
 #include <algorithm>
@@ -56,8 +57,33 @@ bool index_bgzf(const uint8_t* s, size_t n, std::vector<Block>& blocks)
     return true;
 }
 
-bool inflate_serial(const uint8_t* src, size_t n, std::vector<uint8_t>& out, std::string& err)
+// gzip members one after the other through libdeflate (fast_inflate.h); false: not available or anything but success -- zlib
+// takes the input from its start and decides what is wrong with it
+bool inflate_members_fast(const uint8_t* src, size_t n, kbbq_bytes& out)
 {
+    const kbbq_libdeflate* l = kbbq_libdeflate_get();
+    if (!l || n < 18) return false;
+    void* d = l->alloc_decompressor();
+    if (!d) return false;
+    // a single member's trailer names its inflated size (mod 2^32); several members, or more than 4 GB: the buffer grows
+    out.resize(std::max<size_t>({n * 4, (size_t)le32(src + n - 4) + 64, (size_t)1 << 16}));
+    size_t used = 0, at = 0;
+    bool ok = true;
+    while (at < n && ok) {
+        size_t in_used = 0, out_used = 0;
+        const int rc = l->gzip_decompress_ex(d, src + at, n - at, out.data() + used, out.size() - used, &in_used, &out_used);
+        if (rc == 3) { out.resize(out.size() * 2); continue; }                 // insufficient space: the member again, into twice the room
+        if (rc != 0 || in_used == 0) { ok = false; break; }
+        at += in_used; used += out_used;
+    }
+    l->free_decompressor(d);
+    if (ok) out.resize(used);
+    return ok;
+}
+
+bool inflate_serial(const uint8_t* src, size_t n, kbbq_bytes& out, std::string& err)
+{
+    if (inflate_members_fast(src, n, out)) return true;
     z_stream z; memset(&z, 0, sizeof z);
     if (inflateInit2(&z, 15 + 32) != Z_OK) { err = "zlib: inflateInit2 failed"; return false; }
     out.resize(std::max<size_t>(n * 4, 1 << 16));
@@ -92,15 +118,15 @@ bool inflate_serial(const uint8_t* src, size_t n, std::vector<uint8_t>& out, std
 const char kSeqCodes[] = "=ACMGRSVTWYHKDBN";
 const char kCigarOps[] = "MIDNSHP=X???????";
 
-inline void put(std::vector<uint8_t>& o, const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; o.insert(o.end(), b, b + n); }
-inline void put(std::vector<uint8_t>& o, char c) { o.push_back((uint8_t)c); }
-template <typename I> inline void put_int(std::vector<uint8_t>& o, I v)
+inline void put(kbbq_bytes& o, const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; o.insert(o.end(), b, b + n); }
+inline void put(kbbq_bytes& o, char c) { o.push_back((uint8_t)c); }
+template <typename I> inline void put_int(kbbq_bytes& o, I v)
 {
     char tmp[24];
     auto r = std::to_chars(tmp, tmp + sizeof tmp, v);
     put(o, tmp, (size_t)(r.ptr - tmp));
 }
-inline void put_float(std::vector<uint8_t>& o, float v)
+inline void put_float(kbbq_bytes& o, float v)
 {
     char tmp[40];
     const int k = snprintf(tmp, sizeof tmp, "%g", (double)v);
@@ -108,7 +134,7 @@ inline void put_float(std::vector<uint8_t>& o, float v)
 }
 
 // one record (without its block_size word) -> one SAM line; false if the record is inconsistent
-bool format_record(const uint8_t* r, size_t len, const std::vector<std::string>& refs, std::vector<uint8_t>& o)
+bool format_record(const uint8_t* r, size_t len, const std::vector<std::string>& refs, kbbq_bytes& o)
 {
     if (len < 32) return false;
     const int32_t ref_id = les32(r), pos = les32(r + 4);
@@ -170,7 +196,7 @@ bool format_record(const uint8_t* r, size_t len, const std::vector<std::string>&
 
 }  // namespace
 
-bool kbbq_inflate_all(const uint8_t* src, size_t n, std::vector<uint8_t>& out, std::string& err)
+bool kbbq_inflate_all(const uint8_t* src, size_t n, kbbq_bytes& out, std::string& err)
 {
     std::vector<Block> blocks;
     if (!index_bgzf(src, n, blocks)) return inflate_serial(src, n, out, err);   // plain gzip (or a damaged BGZF: zlib decides)
@@ -178,10 +204,12 @@ bool kbbq_inflate_all(const uint8_t* src, size_t n, std::vector<uint8_t>& out, s
     out.resize(total);
     std::atomic<int> bad(0);
     threads_over(blocks.size(), kbbq_threads_for(n), [&](size_t lo, size_t hi) {
+        kbbq_block_inflater fast;
         z_stream z; memset(&z, 0, sizeof z);
         if (inflateInit2(&z, -15) != Z_OK) { bad = 1; return; }
         for (size_t b = lo; b < hi && !bad.load(); ++b) {
             const Block& k = blocks[b];
+            if (fast.block(src + k.src, k.csize, out.data() + k.dst, k.isize, k.crc)) continue;
             Bytef nothing = 0;                                   // an empty block (bgzip's EOF marker; an empty file is ONLY that):
             z.next_in = const_cast<Bytef*>(src + k.src); z.avail_in = (uInt)k.csize;   // zlib rejects a NULL next_out
             z.next_out = k.isize ? out.data() + k.dst : &nothing; z.avail_out = k.isize;
@@ -196,7 +224,7 @@ bool kbbq_inflate_all(const uint8_t* src, size_t n, std::vector<uint8_t>& out, s
     return true;
 }
 
-bool kbbq_bam_to_sam(const uint8_t* bam, size_t n, std::vector<uint8_t>& text, std::string& err)
+bool kbbq_bam_to_sam(const uint8_t* bam, size_t n, kbbq_bytes& text, std::string& err)
 {
     if (n < 12 || memcmp(bam, "BAM\1", 4) != 0) { err = "not a BAM file"; return false; }
     size_t at = 4;
@@ -231,7 +259,7 @@ bool kbbq_bam_to_sam(const uint8_t* bam, size_t n, std::vector<uint8_t>& text, s
     }
     rec.push_back(n + 4);
     const unsigned nt = kbbq_threads_for(n);
-    std::vector<std::vector<uint8_t>> parts(nt);
+    std::vector<kbbq_bytes> parts(nt);
     std::atomic<long long> bad(-1);
     const size_t nrec = rec.size() - 1, per = (nrec + nt - 1) / std::max(1u, nt);
     {
@@ -256,6 +284,6 @@ bool kbbq_bam_to_sam(const uint8_t* bam, size_t n, std::vector<uint8_t>& text, s
     size_t total = text.size();
     for (auto& p : parts) total += p.size();
     text.reserve(total);
-    for (auto& p : parts) { text.insert(text.end(), p.begin(), p.end()); std::vector<uint8_t>().swap(p); }
+    for (auto& p : parts) { text.insert(text.end(), p.begin(), p.end()); kbbq_bytes().swap(p); }
     return true;
 }

@@ -10,8 +10,10 @@
 #include <string>
 #include <vector>
 
+#include "raw_vector.h"
+
 // Inflate a whole gzip / BGZF file image (any number of members).  false + err on corrupt input.
-bool kbbq_inflate_all(const uint8_t* src, size_t n, std::vector<uint8_t>& out, std::string& err);
+bool kbbq_inflate_all(const uint8_t* src, size_t n, kbbq_bytes& out, std::string& err);
 
 // Uncompressed BAM image -> SAM text (header lines, then one line per record).  false + err on malformed input.
-bool kbbq_bam_to_sam(const uint8_t* bam, size_t n, std::vector<uint8_t>& text, std::string& err);
+bool kbbq_bam_to_sam(const uint8_t* bam, size_t n, kbbq_bytes& text, std::string& err);

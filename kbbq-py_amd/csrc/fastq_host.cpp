@@ -65,7 +65,7 @@ template <typename F> static void parallel_for(int64_t n, unsigned nt, F f)
 // '+'; quality lines follow until they hold at least as many characters as the sequence -- exactly as many, or the file is refused.
 // Only printable characters of a sequence / quality line count.  `out` receives the same records four lines each.  False when the
 // text is not such a file (no record at all, a record without '+' line, qualities of another length).
-static bool unwrap_fastq(const uint8_t* buf, size_t size, std::vector<uint8_t>& out)
+static bool unwrap_fastq(const uint8_t* buf, size_t size, kbbq_bytes& out)
 {
     out.clear();
     out.reserve(size + 16);
@@ -222,7 +222,7 @@ static int open_impl(const char* path, int64_t range_lo, int64_t range_hi, kbbq_
     if (bad && bad != 3 && whole) {
         // not four lines per record: a WRAPPED file (sequence and quality over several lines each), which pysam's reader -- kseq --
         // accepts (recalibrate.py:56)?  Unwrap it into memory of our own and index that; anything kseq would not take keeps the error.
-        std::vector<uint8_t> flat;
+        kbbq_bytes flat;
         if (unwrap_fastq(f->buf, f->size, flat)) {
             if (f->mapped && f->buf) munmap((void*)f->buf, f->size);
             f->owned.swap(flat);

@@ -9,16 +9,7 @@
 
 #include <sys/mman.h>
 
-// std::vector whose resize() leaves new elements uninitialised: the index arrays of a 50 M-read file are GBs that
-// the indexing threads overwrite anyway (and first-touch in parallel instead of in one zero-filling thread)
-template <typename T> struct raw_alloc : std::allocator<T> {
-    template <typename U> struct rebind { using other = raw_alloc<U>; };
-    template <typename U, typename... A> void construct(U* p, A&&... a)
-    {
-        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
-    }
-};
-template <typename T> using raw_vector = std::vector<T, raw_alloc<T>>;
+#include "raw_vector.h"
 
 struct kbbq_fastq {
     const uint8_t* buf = nullptr; size_t size = 0; bool mapped = false;
@@ -26,7 +17,7 @@ struct kbbq_fastq {
     raw_vector<uint64_t> h0, s0, q0;       // start offsets of header / sequence / quality lines
     raw_vector<uint32_t> hlen, slen;       // header line length (without '@', up to whitespace = name), sequence length
     std::vector<std::string> rg_names;     // first-appearance order (filled by scan / fill with infer_rg)
-    std::vector<uint8_t> owned;            // the inflated text of a compressed file
+    kbbq_bytes owned;                      // the inflated text of a compressed file
     raw_vector<uint8_t> text;              // a segment of a sequentially read file (fastq_stream.cpp): uninitialised until read into
     ~kbbq_fastq() { if (mapped && buf) munmap((void*)buf, size); }
 };

@@ -11,6 +11,7 @@
 // simply read again, a pipe is copied to a spool file as it is read (kbbq_fastq_stream_tee) and pass 2 reads the spool.
 // gzip / bgzip bytes -- a .fq.gz file of any size, or a pipe that carries them -- are inflated as they are read, member after member.
 #include "../../include/kbbq_hip.h"
+#include "fast_inflate.h"
 #include "fastq_host.h"
 #include "host_threads.h"
 
@@ -150,10 +151,12 @@ int64_t inflate_bgzf_blocks(kbbq_fastq_stream* s, uint8_t* dst, size_t room)
     std::atomic<int> bad(0);
     const unsigned nt = (unsigned)std::min<size_t>(kbbq_threads_for(out), blocks.size());
     kbbq_parallel(nt, [&](unsigned t) {
+        kbbq_block_inflater fast;
         z_stream zz; memset(&zz, 0, sizeof zz);
         if (inflateInit2(&zz, -15) != Z_OK) { bad = 1; return; }
         for (size_t b = t; b < blocks.size() && !bad.load(); b += nt) {
             const Blk& k = blocks[b];
+            if (fast.block(z + k.src, k.csize, dst + k.dst, k.isize, k.crc)) continue;
             Bytef nothing = 0;
             zz.next_in = const_cast<Bytef*>(z + k.src); zz.avail_in = (uInt)k.csize;
             zz.next_out = k.isize ? dst + k.dst : &nothing; zz.avail_out = (uInt)k.isize;

@@ -36,7 +36,7 @@ int kbbq_set_error_(int code, const char* msg);      // defined in kbbq_hip.hip
 
 struct kbbq_sam {
     const uint8_t* buf = nullptr; size_t size = 0;
-    std::vector<uint8_t> owned;                // the text when it was inflated / rendered from BAM instead of mapped
+    kbbq_bytes owned;                          // the text when it was inflated / rendered from BAM instead of mapped
     std::vector<uint64_t> hdr0; std::vector<uint32_t> hdrlen;      // header lines ('@...')
     std::vector<uint64_t> line0; std::vector<uint32_t> linelen;    // alignment lines
     // per alignment
@@ -123,7 +123,7 @@ int kbbq_sam_open(const char* path, kbbq_sam** out)
     close(fd);
     if (f->size >= 4 && (!memcmp(f->buf, "BAM\1", 4) || (f->buf[0] == 0x1f && f->buf[1] == 0x8b))) {
         // gzip / BGZF: inflate; BAM (inflated or not): render the records as SAM lines; then parse the text as usual
-        std::vector<uint8_t> raw, text; std::string err;
+        kbbq_bytes raw, text; std::string err;
         bool ok = true;
         const bool zipped = f->buf[0] == 0x1f;
         if (zipped) ok = kbbq_inflate_all(f->buf, f->size, raw, err);

@@ -1080,3 +1080,55 @@ def test_fast_exit_reports_a_failed_flush():
     assert r.returncode == 120, (r.returncode, r.stderr)
     r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0 and r.stdout == b'x' * 100
+
+
+def test_libdeflate_and_zlib_inflate_alike(oracle, tmp_path):
+    """csrc/fast_inflate.h: BGZF blocks and whole gzip files go through libdeflate when the machine has it, through zlib otherwise
+    (KBBQ_LIBDEFLATE=0) -- same text, same records, the same error for the same damage (zlib decides what a damaged input is in
+    both).  gzip files: one member, two members, highly compressible (the output buffer has to grow), BGZF with an empty block."""
+    import gzip
+    import hashlib
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import bamwriter
+    n = 2000
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 5, 60, 150, 1)
+    fa = str(tmp_path / 'a.fq')
+    oracle.write_fastq(fa, oracle.synth_names(0, n, 1, with_rg=False), seq, qual, meta)
+    raw = open(fa, 'rb').read()
+    cut = raw.index(b'\n@', len(raw) // 2) + 1
+    files = {'one.fq.gz': gzip.compress(raw), 'two.fq.gz': gzip.compress(raw[:cut]) + gzip.compress(raw[cut:]),
+             'bgzf.fq.gz': bamwriter.bgzf(raw, block=9000),
+             'flat.fq.gz': gzip.compress(b''.join(b'@r%d\n%s\n+\n%s\n' % (i, b'A' * 5000, b'I' * 5000) for i in range(300)))}
+    damaged = bytearray(files['bgzf.fq.gz']); damaged[len(damaged) // 3] ^= 0x41
+    files['bad_block.fq.gz'] = bytes(damaged)
+    files['cut.fq.gz'] = files['one.fq.gz'][:len(files['one.fq.gz']) // 2]
+    files['tail.fq.gz'] = files['one.fq.gz'] + b'garbage'
+    for name, blob in files.items():
+        (tmp_path / name).write_bytes(blob)
+    code = ('import sys, hashlib; sys.path.insert(0, %r)\n'
+            'from kbbq import fastx\n'
+            'for p in sys.argv[1:]:\n'
+            '    try:\n'
+            '        r = fastx.NativeFastq(p)\n'
+            '        h = hashlib.sha256()\n'
+            '        for i in (0, r.n // 2, r.n - 1):\n'
+            '            h.update(r.name(i).encode())\n'
+            '        planes = r.fill(None, False, r.n, fastx.pitch_for(int(r.lengths().max())))\n'
+            '        for x in planes:\n'
+            '            if x is not None: h.update(x.tobytes())\n'
+            '        print(p.rsplit("/", 1)[1], r.n, h.hexdigest()[:16])\n'
+            '    except Exception as e:\n'
+            '        print(p.rsplit("/", 1)[1], type(e).__name__, str(e).rsplit("/", 1)[-1])\n' % os.path.join(ROOT, 'kbbq-py_amd'))
+    paths = [str(tmp_path / k) for k in sorted(files)]
+    outs = []
+    for env in ({}, {'KBBQ_LIBDEFLATE': '0'}):
+        r = subprocess.run([sys.executable, '-c', code] + paths, capture_output=True, env=dict(os.environ, **env), timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append(r.stdout.decode())
+    assert outs[0] == outs[1], outs
+    lines = dict(l.split(' ', 1) for l in outs[0].splitlines())
+    assert lines['one.fq.gz'] == lines['two.fq.gz'] == lines['bgzf.fq.gz'] and lines['one.fq.gz'].startswith('%d ' % n)
+    assert lines['flat.fq.gz'].startswith('300 ')
+    assert all(lines[k].startswith('ValueError') for k in ('bad_block.fq.gz', 'cut.fq.gz', 'tail.fq.gz')), lines

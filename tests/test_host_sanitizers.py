@@ -18,7 +18,7 @@ def harness(tmp_path_factory):
     cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-pthread',
            '-o', exe, os.path.join(ROOT, 'tests', 'native', 'host_sanitize.cpp'),
            os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'fastq_stream.cpp'), os.path.join(csrc, 'solve_host.cpp'),
-           os.path.join(csrc, 'sam_host.cpp'), os.path.join(csrc, 'bam_host.cpp'), '-lz']
+           os.path.join(csrc, 'sam_host.cpp'), os.path.join(csrc, 'bam_host.cpp'), '-lz', '-ldl']
     subprocess.check_call(cmd)
 
     def run(*args):
@@ -184,7 +184,7 @@ def test_threaded_readers_under_thread_sanitizer(tmp_path, oracle):
     cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=thread', '-pthread', '-o', exe,
            os.path.join(ROOT, 'tests', 'native', 'host_sanitize.cpp'),
            os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'fastq_stream.cpp'), os.path.join(csrc, 'solve_host.cpp'),
-           os.path.join(csrc, 'sam_host.cpp'), os.path.join(csrc, 'bam_host.cpp'), '-lz']
+           os.path.join(csrc, 'sam_host.cpp'), os.path.join(csrc, 'bam_host.cpp'), '-lz', '-ldl']
     if subprocess.run(cmd, capture_output=True).returncode != 0:
         pytest.skip('this g++ cannot link -fsanitize=thread')
     n = 20000
