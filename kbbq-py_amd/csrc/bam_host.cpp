@@ -133,10 +133,32 @@ inline void put_float(kbbq_bytes& o, float v)
     put(o, tmp, (size_t)std::max(k, 0));
 }
 
-// one record (without its block_size word) -> one SAM line; false if the record is inconsistent
-bool format_record(const uint8_t* r, size_t len, const std::vector<std::string>& refs, kbbq_bytes& o)
+// Where a thread renders its records: room() once per record for the longest line the record can become, then unchecked writes
+// (vector::insert per field -- a capacity check and an iterator dance for every few bytes -- ran at 130 MB/s per thread).
+struct Sink {
+    kbbq_bytes buf; size_t n = 0;
+    void room(size_t k) { if (buf.size() - n < k) buf.resize(std::max(buf.size() * 2, n + k)); }
+    uint8_t* at() { return buf.data() + n; }
+};
+inline void put(Sink& o, const void* p, size_t n) { memcpy(o.at(), p, n); o.n += n; }
+inline void put(Sink& o, char c) { *o.at() = (uint8_t)c; ++o.n; }
+template <typename I> inline void put_int(Sink& o, I v)
+{
+    auto r = std::to_chars((char*)o.at(), (char*)o.at() + 24, v);
+    o.n = (size_t)((uint8_t*)r.ptr - o.buf.data());
+}
+inline void put_float(Sink& o, float v)
+{
+    const int k = snprintf((char*)o.at(), 40, "%g", (double)v);
+    o.n += (size_t)std::max(k, 0);
+}
+
+// one record (without its block_size word) -> one SAM line; false if the record is inconsistent.  longest_ref: of the reference names.
+// No field expands more than 5x (an element of a B:c array: one byte -> ",-128"), the fixed fields are < 100 characters.
+bool format_record(const uint8_t* r, size_t len, const std::vector<std::string>& refs, size_t longest_ref, Sink& o)
 {
     if (len < 32) return false;
+    o.room(6 * len + 2 * longest_ref + 256);
     const int32_t ref_id = les32(r), pos = les32(r + 4);
     const uint32_t l_name = r[8], mapq = r[9], n_cig = le16(r + 12), flag = le16(r + 14);
     const int32_t l_seq = les32(r + 16), next_ref = les32(r + 20), next_pos = les32(r + 24), tlen = les32(r + 28);
@@ -155,10 +177,15 @@ bool format_record(const uint8_t* r, size_t len, const std::vector<std::string>&
     if (next_ref < 0) put(o, '*'); else if (next_ref == ref_id) put(o, '='); else if ((size_t)next_ref < refs.size()) put(o, refs[(size_t)next_ref].data(), refs[(size_t)next_ref].size()); else return false;
     put(o, '\t'); put_int(o, (int64_t)next_pos + 1); put(o, '\t'); put_int(o, tlen); put(o, '\t');
     if (l_seq == 0) put(o, '*');
-    else { const size_t at = o.size(); o.resize(at + (size_t)l_seq); for (int32_t i = 0; i < l_seq; ++i) o[at + (size_t)i] = (uint8_t)kSeqCodes[(seq[i >> 1] >> ((~i & 1) << 2)) & 15]; }
+    else {
+        uint8_t* w = o.at();
+        for (int32_t i = 0; i + 1 < l_seq; i += 2) { const uint8_t b = seq[i >> 1]; w[i] = (uint8_t)kSeqCodes[b >> 4]; w[i + 1] = (uint8_t)kSeqCodes[b & 15]; }
+        if (l_seq & 1) w[l_seq - 1] = (uint8_t)kSeqCodes[seq[(l_seq - 1) >> 1] >> 4];
+        o.n += (size_t)l_seq;
+    }
     put(o, '\t');
     if (l_seq == 0 || qual[0] == 0xFF) put(o, '*');
-    else { const size_t at = o.size(); o.resize(at + (size_t)l_seq); for (int32_t i = 0; i < l_seq; ++i) o[at + (size_t)i] = (uint8_t)(qual[i] + 33); }
+    else { uint8_t* w = o.at(); for (int32_t i = 0; i < l_seq; ++i) w[i] = (uint8_t)(qual[i] + 33); o.n += (size_t)l_seq; }
     // optional fields: tag(2) type(1) value
     const uint8_t* p = aux;
     while (p < end) {
@@ -259,31 +286,30 @@ bool kbbq_bam_to_sam(const uint8_t* bam, size_t n, kbbq_bytes& text, std::string
     }
     rec.push_back(n + 4);
     const unsigned nt = kbbq_threads_for(n);
-    std::vector<kbbq_bytes> parts(nt);
+    std::vector<Sink> parts(nt);
     std::atomic<long long> bad(-1);
     const size_t nrec = rec.size() - 1, per = (nrec + nt - 1) / std::max(1u, nt);
-    {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t) {
-            const size_t lo = std::min(nrec, t * per), hi = std::min(nrec, lo + per);
-            if (lo >= hi) continue;
-            th.emplace_back([&, t, lo, hi]() {
-                auto& o = parts[t];
-                o.reserve((rec[hi] - rec[lo]) * 2);
-                for (size_t i = lo; i < hi; ++i)
-                    if (!format_record(bam + rec[i], rec[i + 1] - rec[i] - 4, refs, o)) {
-                        long long cur = bad.load();
-                        while ((cur < 0 || (long long)i < cur) && !bad.compare_exchange_weak(cur, (long long)i)) {}
-                        return;
-                    }
-            });
-        }
-        for (auto& t : th) t.join();
-    }
+    size_t longest_ref = 0;
+    for (const auto& nm : refs) longest_ref = std::max(longest_ref, nm.size());
+    kbbq_parallel(nt, [&](unsigned t) {
+        const size_t lo = std::min(nrec, t * per), hi = std::min(nrec, lo + per);
+        if (lo >= hi) return;
+        Sink& o = parts[t];
+        o.buf.resize((rec[hi] - rec[lo]) * 2 + 4096);
+        for (size_t i = lo; i < hi; ++i)
+            if (!format_record(bam + rec[i], rec[i + 1] - rec[i] - 4, refs, longest_ref, o)) {
+                long long cur = bad.load();
+                while ((cur < 0 || (long long)i < cur) && !bad.compare_exchange_weak(cur, (long long)i)) {}
+                return;
+            }
+    });
     if (bad.load() >= 0) { err = "BAM: malformed alignment record " + std::to_string(bad.load()); return false; }
-    size_t total = text.size();
-    for (auto& p : parts) total += p.size();
-    text.reserve(total);
-    for (auto& p : parts) { text.insert(text.end(), p.begin(), p.end()); kbbq_bytes().swap(p); }
+    std::vector<size_t> at_part(nt + 1, text.size());                          // the parts side by side into their places
+    for (unsigned t = 0; t < nt; ++t) at_part[t + 1] = at_part[t] + parts[t].n;
+    text.resize(at_part[nt]);
+    kbbq_parallel(nt, [&](unsigned t) {
+        if (parts[t].n) memcpy(text.data() + at_part[t], parts[t].buf.data(), parts[t].n);
+        kbbq_bytes().swap(parts[t].buf);
+    });
     return true;
 }
