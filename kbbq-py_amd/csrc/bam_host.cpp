@@ -2,6 +2,7 @@
 #include "bam_host.h"
 #include "fast_inflate.h"
 #include "host_threads.h"
+#include "parallel_gunzip.h"
 
 #include <algorithm>
 #include <atomic>
@@ -83,6 +84,15 @@ bool inflate_members_fast(const uint8_t* src, size_t n, kbbq_bytes& out)
 
 bool inflate_serial(const uint8_t* src, size_t n, kbbq_bytes& out, std::string& err)
 {
+    // large members on all threads (parallel_gunzip.cpp), else one thread through libdeflate, else -- and for whatever those two
+    // do not report as success -- zlib
+    if (n >= kbbq_pgz_min_bytes() && n >= 18 && kbbq_host_thread_ceiling() > 1) {
+        out.clear();
+        const size_t hint = le32(src + n - 4);                                 // one member below 4 GB: its size; else the vector grows
+        out.reserve(std::max<size_t>(hint >= n ? hint : 0, n * 3));
+        if (kbbq_parallel_gunzip(src, n, out, 0)) return true;
+        out.clear();
+    }
     if (inflate_members_fast(src, n, out)) return true;
     z_stream z; memset(&z, 0, sizeof z);
     if (inflateInit2(&z, 15 + 32) != Z_OK) { err = "zlib: inflateInit2 failed"; return false; }

@@ -14,6 +14,7 @@
 #include "fast_inflate.h"
 #include "fastq_host.h"
 #include "host_threads.h"
+#include "parallel_gunzip.h"
 
 #include <algorithm>
 #include <atomic>
@@ -26,6 +27,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -46,7 +48,14 @@ struct kbbq_fastq_stream {
     z_stream zs;
     raw_vector<uint8_t> zin; size_t zin_pos = 0, zin_len = 0;
     std::string zerr;
-    ~kbbq_fastq_stream() { if (zs_open) inflateEnd(&zs); if (own_fd && fd >= 0) close(fd); }
+    // a large gzip member of a regular file: inflated on all threads from a mapping of the file (parallel_gunzip.cpp), a window of
+    // chunks at a time into `pend`; anything that decoder does not take on sends the stream back to byte 0 and zlib, which skips
+    // what has been handed out already
+    kbbq_pgz* pgz = nullptr; const uint8_t* map = nullptr; size_t map_n = 0;
+    kbbq_bytes pend; size_t pend_at = 0;
+    uint64_t served = 0, skip = 0;
+    void drop_pgz() { if (pgz) kbbq_pgz_close(pgz); pgz = nullptr; if (map) munmap((void*)map, map_n); map = nullptr; kbbq_bytes().swap(pend); pend_at = 0; }
+    ~kbbq_fastq_stream() { drop_pgz(); if (zs_open) inflateEnd(&zs); if (own_fd && fd >= 0) close(fd); }
 };
 
 namespace {
@@ -173,7 +182,7 @@ int64_t inflate_bgzf_blocks(kbbq_fastq_stream* s, uint8_t* dst, size_t room)
 }
 
 // up to `want` INFLATED bytes into dst (fewer only at the end of the input); -1 on damaged input (s->zerr says what)
-int64_t inflate_some(kbbq_fastq_stream* s, uint8_t* dst, size_t want)
+int64_t inflate_some_zlib(kbbq_fastq_stream* s, uint8_t* dst, size_t want)
 {
     size_t got = 0;
     while (got < want) {
@@ -218,6 +227,40 @@ int64_t inflate_some(kbbq_fastq_stream* s, uint8_t* dst, size_t want)
         }
     }
     return (int64_t)got;
+}
+
+int64_t inflate_some(kbbq_fastq_stream* s, uint8_t* dst, size_t want)
+{
+    size_t got = 0;
+    while (s->pgz && got < want) {
+        if (s->pend_at < s->pend.size()) {
+            const size_t k = std::min(want - got, s->pend.size() - s->pend_at);
+            memcpy(dst + got, s->pend.data() + s->pend_at, k);
+            s->pend_at += k; got += k; s->served += k;
+            continue;
+        }
+        s->pend.clear(); s->pend_at = 0;
+        const int rc = kbbq_pgz_next(s->pgz, s->pend);
+        if (rc == 1) continue;
+        if (rc == 0) { s->eof = true; return (int64_t)got; }
+        // not taken: back to the file's first byte with zlib, past what has been handed out
+        s->drop_pgz();
+        if (lseek(s->fd, 0, SEEK_SET) < 0) { s->zerr = "lseek failed"; return -1; }
+        s->pos = 0; s->zin_pos = s->zin_len = 0; s->fd_eof = false; s->in_member = false;
+        s->skip = s->served;
+    }
+    if (s->skip) {
+        raw_vector<uint8_t> scratch((size_t)1 << 20);
+        while (s->skip) {
+            const int64_t k = inflate_some_zlib(s, scratch.data(), (size_t)std::min<uint64_t>(s->skip, scratch.size()));
+            if (k < 0) return -1;
+            if (k == 0) { s->zerr = "damaged gzip data"; return -1; }        // (the input ended before the text already handed out did)
+            s->skip -= (uint64_t)k;
+        }
+    }
+    if (got == want || s->eof) return (int64_t)got;
+    const int64_t k = inflate_some_zlib(s, dst + got, want - got);
+    return k < 0 ? -1 : (int64_t)got + k;
 }
 
 // read up to `want` bytes at the stream's position into dst; returns the bytes read (< want only at the end of the input)
@@ -302,6 +345,23 @@ int kbbq_fastq_stream_open(const char* path, kbbq_fastq_stream** out)
             memset(&s->zs, 0, sizeof s->zs);
             if (inflateInit2(&s->zs, 15 + 32) != Z_OK) { delete s; return kbbq_set_error_(KBBQ_E_ARG, "inflateInit failed"); }
             s->zs_open = true; s->gz = true; s->pos = (int64_t)s->zin_len;
+            if (s->regular && (size_t)s->size >= std::max<size_t>(kbbq_pgz_min_bytes(), 18) && kbbq_host_thread_ceiling() > 1) {
+                void* m = mmap(nullptr, (size_t)s->size, PROT_READ, MAP_PRIVATE, s->fd, 0);
+                if (m != MAP_FAILED) {
+                    const uint8_t* z = (const uint8_t*)m;
+                    bool bgzf = false;                                        // (blocks that say their sizes go side by side as they are read)
+                    if (z[3] & 4) {
+                        const size_t xlen = (size_t)z[10] | (size_t)z[11] << 8;
+                        for (size_t x = 12; x + 4 <= 12 + xlen && x + 4 <= (size_t)s->size;) {
+                            const size_t slen = (size_t)z[x + 2] | (size_t)z[x + 3] << 8;
+                            if (z[x] == 'B' && z[x + 1] == 'C' && slen == 2) bgzf = true;
+                            x += 4 + slen;
+                        }
+                    }
+                    if (bgzf) munmap(m, (size_t)s->size);
+                    else { s->map = z; s->map_n = (size_t)s->size; madvise(m, s->map_n, MADV_SEQUENTIAL); s->pgz = kbbq_pgz_open(z, s->map_n, 0); }
+                }
+            }
         } else if (s->regular) {
             s->zin_len = 0;                                                          // plain text of a regular file: positioned reads from byte 0
             if (lseek(s->fd, 0, SEEK_SET) < 0) { delete s; return kbbq_set_error_(KBBQ_E_ARG, "lseek failed"); }

@@ -1132,3 +1132,63 @@ def test_libdeflate_and_zlib_inflate_alike(oracle, tmp_path):
     assert lines['one.fq.gz'] == lines['two.fq.gz'] == lines['bgzf.fq.gz'] and lines['one.fq.gz'].startswith('%d ' % n)
     assert lines['flat.fq.gz'].startswith('300 ')
     assert all(lines[k].startswith('ValueError') for k in ('bad_block.fq.gz', 'cut.fq.gz', 'tail.fq.gz')), lines
+
+
+def test_gzip_members_inflate_on_many_threads(oracle, tmp_path):
+    """csrc/parallel_gunzip.cpp: one gzip member cut into chunks, block starts searched, chunks decoded against an unknown window and
+    resolved in order -- through the mapped reader (the whole file) and the sequential reader (window by window), with chunks small
+    enough that a test file has dozens; against the plain file and against zlib (KBBQ_PGZ_MIN_BYTES too large for the file).  Every
+    compression level, two members, a stored member, a damaged and a truncated file (zlib words the error), and the way back to zlib in
+    mid-stream (KBBQ_PGZ_TEST_FAIL_AFTER: the text handed out before is skipped)."""
+    import gzip
+    import subprocess
+    import sys
+    n = 6000
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 7, 80, 150, 1)
+    fa = str(tmp_path / 'a.fq')
+    oracle.write_fastq(fa, oracle.synth_names(0, n, 1, with_rg=False), seq, qual, meta)
+    raw = open(fa, 'rb').read()
+    cut = raw.index(b'\n@', len(raw) // 2) + 1
+    files = {'l1.fq.gz': gzip.compress(raw, 1), 'l6.fq.gz': gzip.compress(raw, 6), 'l9.fq.gz': gzip.compress(raw, 9),
+             'l0.fq.gz': gzip.compress(raw, 0), 'two.fq.gz': gzip.compress(raw[:cut], 6) + gzip.compress(raw[cut:], 4)}
+    damaged = bytearray(files['l6.fq.gz']); damaged[len(damaged) // 2] ^= 0x08
+    files['bad.fq.gz'] = bytes(damaged)
+    files['cut.fq.gz'] = files['l6.fq.gz'][:len(files['l6.fq.gz']) * 2 // 3]
+    for name, blob in files.items():
+        (tmp_path / name).write_bytes(blob)
+    code = ('import sys, hashlib; sys.path.insert(0, %r)\n'
+            'from kbbq import fastx\n'
+            'def digest(r, h):\n'
+            '    planes = r.fill(None, False, r.n, 160, first=r.first)\n'
+            '    for x in planes:\n'
+            '        if x is not None: h.update(x.tobytes())\n'
+            '    h.update(("%%d %%s %%s" %% (r.n, r.name(r.first), r.name(r.first + r.n - 1))).encode())\n'
+            'for p in sys.argv[1:]:\n'
+            '    for mode in ("mapped", "stream"):\n'
+            '        h = hashlib.sha256(); total = 0\n'
+            '        try:\n'
+            '            if mode == "mapped":\n'
+            '                r = fastx.NativeFastq(p); digest(r, h); total = r.n\n'
+            '            else:\n'
+            '                s = fastx.FastqStream(p)\n'
+            '                while True:\n'
+            '                    seg, end = s.next(300000)\n'
+            '                    if seg is None: break\n'
+            '                    digest(seg, h); total += seg.n\n'
+            '            print(p.rsplit("/", 1)[1], mode, total, h.hexdigest()[:16] if mode == "mapped" else "")\n'
+            '        except Exception as e:\n'
+            '            print(p.rsplit("/", 1)[1], mode, type(e).__name__, str(e).rsplit("/", 1)[-1])\n' % os.path.join(ROOT, 'kbbq-py_amd'))
+    paths = [fa] + [str(tmp_path / k) for k in sorted(files)]
+    runs = {}
+    for label, env in (('zlib', {'KBBQ_PGZ_MIN_BYTES': '1000000000', 'KBBQ_LIBDEFLATE': '0'}),
+                       ('threads', {'KBBQ_PGZ_MIN_BYTES': '0', 'KBBQ_PGZ_CHUNK': '20000', 'KBBQ_HOST_THREADS': '4'}),
+                       ('tiny chunks', {'KBBQ_PGZ_MIN_BYTES': '0', 'KBBQ_PGZ_CHUNK': '3000', 'KBBQ_HOST_THREADS': '3'}),
+                       ('back to zlib', {'KBBQ_PGZ_MIN_BYTES': '0', 'KBBQ_PGZ_CHUNK': '20000', 'KBBQ_HOST_THREADS': '2', 'KBBQ_PGZ_TEST_FAIL_AFTER': '2'})):
+        r = subprocess.run([sys.executable, '-c', code] + paths, capture_output=True, env=dict(os.environ, **env), timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        runs[label] = r.stdout.decode()
+    assert runs['threads'] == runs['zlib'] == runs['tiny chunks'] == runs['back to zlib'], runs
+    lines = runs['zlib'].splitlines()
+    good = [l.split(' ', 2)[2] for l in lines if l.startswith(('a.fq ', 'l0', 'l1', 'l6', 'l9', 'two')) and ' mapped ' in l]
+    assert len(set(good)) == 1 and good[0].startswith('%d ' % n), lines
+    assert all('ValueError' in l for l in lines if l.startswith(('bad', 'cut'))), lines

@@ -18,12 +18,13 @@ def harness(tmp_path_factory):
     cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-pthread',
            '-o', exe, os.path.join(ROOT, 'tests', 'native', 'host_sanitize.cpp'),
            os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'fastq_stream.cpp'), os.path.join(csrc, 'solve_host.cpp'),
-           os.path.join(csrc, 'sam_host.cpp'), os.path.join(csrc, 'bam_host.cpp'), '-lz', '-ldl']
+           os.path.join(csrc, 'sam_host.cpp'), os.path.join(csrc, 'bam_host.cpp'), os.path.join(csrc, 'parallel_gunzip.cpp'), '-lz', '-ldl']
     subprocess.check_call(cmd)
 
     def run(*args):
         env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='halt_on_error=1:print_stacktrace=1',
-                   KBBQ_HOST_THREADS='4', KBBQ_SCAN_CHUNK='97')      # the scan's chunks on threads even for small inputs
+                   KBBQ_HOST_THREADS='4', KBBQ_SCAN_CHUNK='97',       # the scan's chunks on threads even for small inputs
+                   KBBQ_PGZ_MIN_BYTES='0', KBBQ_PGZ_CHUNK='2000')   # ... and gzip members cut into chunks (csrc/parallel_gunzip.cpp)
         r = subprocess.run([exe] + list(args), capture_output=True, timeout=300, env=env)
         out, err = r.stdout.decode('latin-1'), r.stderr.decode('latin-1')      # error texts may quote bytes of a damaged file
         assert 'ERROR: AddressSanitizer' not in err and 'runtime error' not in err, err[-3000:]
@@ -184,7 +185,7 @@ def test_threaded_readers_under_thread_sanitizer(tmp_path, oracle):
     cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=thread', '-pthread', '-o', exe,
            os.path.join(ROOT, 'tests', 'native', 'host_sanitize.cpp'),
            os.path.join(csrc, 'fastq_host.cpp'), os.path.join(csrc, 'fastq_stream.cpp'), os.path.join(csrc, 'solve_host.cpp'),
-           os.path.join(csrc, 'sam_host.cpp'), os.path.join(csrc, 'bam_host.cpp'), '-lz', '-ldl']
+           os.path.join(csrc, 'sam_host.cpp'), os.path.join(csrc, 'bam_host.cpp'), os.path.join(csrc, 'parallel_gunzip.cpp'), '-lz', '-ldl']
     if subprocess.run(cmd, capture_output=True).returncode != 0:
         pytest.skip('this g++ cannot link -fsanitize=thread')
     n = 20000
