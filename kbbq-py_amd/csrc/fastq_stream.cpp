@@ -240,8 +240,19 @@ int64_t inflate_some(kbbq_fastq_stream* s, uint8_t* dst, size_t want)
             continue;
         }
         s->pend.clear(); s->pend_at = 0;
-        const int rc = kbbq_pgz_next(s->pgz, s->pend);
-        if (rc == 1) continue;
+        size_t total = 0;
+        int rc = kbbq_pgz_prepare(s->pgz, &total);
+        if (rc == 1) {
+            if (total <= want - got) {                                        // straight to the caller's memory
+                rc = kbbq_pgz_emit(s->pgz, dst + got);
+                if (rc == 1) { got += total; s->served += total; continue; }
+            } else {
+                s->pend.resize(total);
+                rc = kbbq_pgz_emit(s->pgz, s->pend.data());
+                if (rc == 1) continue;
+                s->pend.clear();
+            }
+        }
         if (rc == 0) { s->eof = true; return (int64_t)got; }
         // not taken: back to the file's first byte with zlib, past what has been handed out
         s->drop_pgz();

@@ -374,6 +374,10 @@ struct kbbq_pgz {
     long calls = 0, fail_after = -1;      // KBBQ_PGZ_TEST_FAIL_AFTER: the (n + 1)-th window is "not taken" (the callers' way back to zlib, for the tests)
     size_t k_cap = ~(size_t)0 >> 2;       // chunks per window at most
     std::vector<Chunk> chunks;
+    // a decoded window waiting to be written out (kbbq_pgz_prepare -> kbbq_pgz_emit)
+    bool ready = false;
+    std::vector<size_t> order; std::vector<std::vector<uint8_t>> before;
+    size_t total = 0, end_bit = 0; bool member_ends = false; unsigned nt = 1;
 };
 
 kbbq_pgz* kbbq_pgz_open(const uint8_t* src, size_t n, unsigned threads)
@@ -404,9 +408,10 @@ static size_t gzip_header(const uint8_t* s, size_t n)
     return at + 8 <= n ? at : 0;
 }
 
-int kbbq_pgz_next(kbbq_pgz* z, kbbq_bytes& out)
+int kbbq_pgz_prepare(kbbq_pgz* z, size_t* total_out)
 {
     if (z->failed) return -1;
+    if (z->ready) { *total_out = z->total; return 1; }
     if (z->fail_after >= 0 && z->calls++ >= z->fail_after) { z->failed = true; return -1; }
     const uint8_t* src = z->src; const size_t n = z->n;
     if (!z->in_member) {
@@ -446,7 +451,7 @@ int kbbq_pgz_next(kbbq_pgz* z, kbbq_bytes& out)
         });
     }
     // the chain: every chunk must have ended where the next one began
-    std::vector<size_t> order;
+    std::vector<size_t>& order = z->order; order.clear();
     bool member_ends = false; size_t end_bit = 0;
     for (size_t k = 0; k < K;) {
         if (ch[k].end < 0) { z->failed = true; return -1; }
@@ -461,7 +466,8 @@ int kbbq_pgz_next(kbbq_pgz* z, kbbq_bytes& out)
     // windows in file order: chunk j's markers point into the WIN bytes before it
     size_t total = 0;
     for (size_t k : order) total += ch[k].n;
-    std::vector<std::vector<uint8_t>> before(order.size());      // the window before every chunk that has markers
+    std::vector<std::vector<uint8_t>>& before = z->before;       // the window before every chunk that has markers
+    before.assign(order.size(), std::vector<uint8_t>());
     {
         std::vector<uint8_t> w(z->win, z->win + WIN); size_t valid = z->valid;
         for (size_t j = 0; j < order.size(); ++j) {
@@ -484,8 +490,21 @@ int kbbq_pgz_next(kbbq_pgz* z, kbbq_bytes& out)
         }
         before.emplace_back(std::move(w));                       // the window behind the last chunk: committed below, once the trailer agrees
     }
-    const size_t old = out.size();
-    out.resize(old + total);
+    z->total = total; z->end_bit = end_bit; z->member_ends = member_ends; z->nt = nt; z->ready = true;
+    *total_out = total;
+    return 1;
+}
+
+// The prepared window's text to out[0, total): markers resolved, CRC-32 taken, the member's trailer checked when it ends here.
+// 1 = written and committed; -1 = not taken (what was written is to be ignored).
+int kbbq_pgz_emit(kbbq_pgz* z, uint8_t* out)
+{
+    if (z->failed || !z->ready) return -1;
+    z->ready = false;
+    const uint8_t* src = z->src; const size_t n = z->n;
+    std::vector<Chunk>& ch = z->chunks;
+    const std::vector<size_t>& order = z->order; const std::vector<std::vector<uint8_t>>& before = z->before;
+    const size_t total = z->total, end_bit = z->end_bit; const bool member_ends = z->member_ends; const unsigned nt = z->nt;
     std::vector<size_t> at(order.size() + 1, 0);
     for (size_t j = 0; j < order.size(); ++j) at[j + 1] = at[j] + ch[order[j]].n;
     {
@@ -494,7 +513,7 @@ int kbbq_pgz_next(kbbq_pgz* z, kbbq_bytes& out)
             std::vector<uint8_t> lut;
             for (size_t j; (j = nextj.fetch_add(1)) < order.size();) {
                 Chunk& c = ch[order[j]];
-                uint8_t* dst = out.data() + old + at[j];
+                uint8_t* dst = out + at[j];
                 const uint16_t* s = c.sym.data() + WIN;
                 if (c.markers) {
                     lut.resize(65536);
@@ -517,10 +536,10 @@ int kbbq_pgz_next(kbbq_pgz* z, kbbq_bytes& out)
     size_t next_pos = 0;
     if (member_ends) {
         const size_t p = (end_bit + 7) >> 3;
-        if (p + 8 > n) { out.resize(old); z->failed = true; return -1; }
+        if (p + 8 > n) { z->failed = true; return -1; }
         const uint32_t want_crc = (uint32_t)src[p] | (uint32_t)src[p + 1] << 8 | (uint32_t)src[p + 2] << 16 | (uint32_t)src[p + 3] << 24;
         const uint32_t want_size = (uint32_t)src[p + 4] | (uint32_t)src[p + 5] << 8 | (uint32_t)src[p + 6] << 16 | (uint32_t)src[p + 7] << 24;
-        if (want_crc != crc || want_size != (uint32_t)isize) { out.resize(old); z->failed = true; return -1; }
+        if (want_crc != crc || want_size != (uint32_t)isize) { z->failed = true; return -1; }
         next_pos = p + 8;
     }
     // commit
@@ -531,6 +550,17 @@ int kbbq_pgz_next(kbbq_pgz* z, kbbq_bytes& out)
     z->delivered += total; if (getenv("KBBQ_PGZ_TRACE")) fprintf(stderr, "[pgz] window: %zu chunks, %zu bytes\n", order.size(), total);
     if (member_ends) { z->in_member = false; z->pos = next_pos; z->k_cap = std::max<size_t>(2 * order.size(), 2); }
     else { z->bit = end_bit; z->k_cap = std::max<size_t>(z->k_cap * 2, 2); }
+    return 1;
+}
+
+int kbbq_pgz_next(kbbq_pgz* z, kbbq_bytes& out)
+{
+    size_t total = 0;
+    const int rc = kbbq_pgz_prepare(z, &total);
+    if (rc != 1) return rc;
+    const size_t old = out.size();
+    out.resize(old + total);
+    if (kbbq_pgz_emit(z, out.data() + old) != 1) { out.resize(old); return -1; }
     return 1;
 }
 

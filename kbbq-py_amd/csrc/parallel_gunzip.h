@@ -19,6 +19,10 @@ void kbbq_pgz_close(kbbq_pgz* z);
 //      all -- the caller inflates the input from its start with zlib, which also decides what a damaged input's error is, and
 //      skips that much.
 int kbbq_pgz_next(kbbq_pgz* z, kbbq_bytes& out);
+// The same in two steps, for a caller that has memory of its own for the text: prepare decodes the next window and says how many
+// bytes it holds (1 / 0 / -1 as above; a prepared window stays prepared until it is emitted), emit writes them to dst[0, total).
+int kbbq_pgz_prepare(kbbq_pgz* z, size_t* total);
+int kbbq_pgz_emit(kbbq_pgz* z, uint8_t* dst);
 size_t kbbq_pgz_delivered(const kbbq_pgz* z);
 
 // The smallest input (compressed bytes) worth handing to this decoder: 8 MB, or KBBQ_PGZ_MIN_BYTES.
