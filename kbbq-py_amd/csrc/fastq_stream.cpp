@@ -54,6 +54,7 @@ struct kbbq_fastq_stream {
     kbbq_pgz* pgz = nullptr; const uint8_t* map = nullptr; size_t map_n = 0;
     kbbq_bytes pend; size_t pend_at = 0;
     uint64_t served = 0, skip = 0;
+    bool reread = false;                               // compressed, but pass 2 may simply read the file again (no spool)
     void drop_pgz() { if (pgz) kbbq_pgz_close(pgz); pgz = nullptr; if (map) munmap((void*)map, map_n); map = nullptr; kbbq_bytes().swap(pend); pend_at = 0; }
     ~kbbq_fastq_stream() { drop_pgz(); if (zs_open) inflateEnd(&zs); if (own_fd && fd >= 0) close(fd); }
 };
@@ -356,7 +357,8 @@ int kbbq_fastq_stream_open(const char* path, kbbq_fastq_stream** out)
             memset(&s->zs, 0, sizeof s->zs);
             if (inflateInit2(&s->zs, 15 + 32) != Z_OK) { delete s; return kbbq_set_error_(KBBQ_E_ARG, "inflateInit failed"); }
             s->zs_open = true; s->gz = true; s->pos = (int64_t)s->zin_len;
-            if (s->regular && (size_t)s->size >= std::max<size_t>(kbbq_pgz_min_bytes(), 18) && kbbq_host_thread_ceiling() > 1) {
+            s->reread = s->regular && s->size < ((int64_t)64 << 20);          // (a small file: inflating it twice is nothing)
+            if (s->regular && s->size >= 18) {
                 void* m = mmap(nullptr, (size_t)s->size, PROT_READ, MAP_PRIVATE, s->fd, 0);
                 if (m != MAP_FAILED) {
                     const uint8_t* z = (const uint8_t*)m;
@@ -369,8 +371,10 @@ int kbbq_fastq_stream_open(const char* path, kbbq_fastq_stream** out)
                             x += 4 + slen;
                         }
                     }
-                    if (bgzf) munmap(m, (size_t)s->size);
+                    const bool wide = (size_t)s->size >= kbbq_pgz_min_bytes() && kbbq_host_thread_ceiling() > 1;
+                    if (bgzf || !wide) munmap(m, (size_t)s->size);
                     else { s->map = z; s->map_n = (size_t)s->size; madvise(m, s->map_n, MADV_SEQUENTIAL); s->pgz = kbbq_pgz_open(z, s->map_n, 0); }
+                    if (bgzf || s->pgz) s->reread = true;                     // inflated on all threads: cheaper to do again than to keep a spool of the text
                 }
             }
         } else if (s->regular) {
@@ -386,8 +390,10 @@ int kbbq_fastq_stream_open(const char* path, kbbq_fastq_stream** out)
     return KBBQ_OK;
 }
 
-// 1: an uncompressed regular file (it can be read a second time as it is); 0: a pipe, standard input, compressed bytes -- pass 2 reads a spool
-int kbbq_fastq_stream_is_regular(const kbbq_fastq_stream* s) { return s && s->regular && !s->gz ? 1 : 0; }
+// 1: a regular file that pass 2 reads a second time as it is -- plain text, or compressed bytes that inflate on all threads (bgzip
+// blocks, large gzip members: parallel_gunzip.cpp) or are few; 0: a pipe, standard input, a large gzip file on a one-thread host --
+// pass 2 reads a spool of the text
+int kbbq_fastq_stream_is_regular(const kbbq_fastq_stream* s) { return s && s->regular && (!s->gz || s->reread) ? 1 : 0; }
 
 // every byte handed out from now on is appended to `fd` (the caller's spool file; not closed here); -1 stops it
 int kbbq_fastq_stream_tee(kbbq_fastq_stream* s, int fd)
