@@ -541,6 +541,9 @@ int kbbq_pgz_emit(kbbq_pgz* z, uint8_t* out)
         const uint32_t want_size = (uint32_t)src[p + 4] | (uint32_t)src[p + 5] << 8 | (uint32_t)src[p + 6] << 16 | (uint32_t)src[p + 7] << 24;
         if (want_crc != crc || want_size != (uint32_t)isize) { z->failed = true; return -1; }
         next_pos = p + 8;
+        // a FIRST member that is over within one chunk and is followed by more: a file of many short members (concatenated files,
+        // blocked formats other than BGZF) -- nothing to spread over threads, and a window's set-up per member costs more than zlib
+        if (z->delivered == 0 && order.size() <= 1 && next_pos + 18 < n) { z->failed = true; return -1; }
     }
     // commit
     const std::vector<uint8_t>& w = before.back();
@@ -548,7 +551,7 @@ int kbbq_pgz_emit(kbbq_pgz* z, uint8_t* out)
     z->valid = std::min<size_t>(WIN, z->valid + total);
     z->crc = crc; z->isize = isize;
     z->delivered += total; if (getenv("KBBQ_PGZ_TRACE")) fprintf(stderr, "[pgz] window: %zu chunks, %zu bytes\n", order.size(), total);
-    if (member_ends) { z->in_member = false; z->pos = next_pos; z->k_cap = std::max<size_t>(2 * order.size(), 2); }
+    if (member_ends) { z->in_member = false; z->pos = next_pos; z->k_cap = order.size() <= 1 ? 1 : 2 * order.size(); }     // (short members one after the other: no search ahead)
     else { z->bit = end_bit; z->k_cap = std::max<size_t>(z->k_cap * 2, 2); }
     return 1;
 }
