@@ -714,6 +714,80 @@ def extra_file_path(torch, dev, n=8_000_000):
             'streamed_within_256MB_of_device_memory': other.get('streamed_256M'), 'through_two_pipes': other.get('pipes')}
 
 
+def extra_compressed_inputs(torch, dev, n=1_000_000):
+    """The same text as a `.fq.gz` pair (one gzip member per file, level 1 for the bench's own time): recalibrate_fastq in this
+    process on the plain pair and on the compressed pair -- inflated on all host threads (csrc/parallel_gunzip.cpp) and, for
+    comparison, by zlib on one thread per file (KBBQ_PGZ_MIN_BYTES / KBBQ_LIBDEFLATE switch the faster paths off)."""
+    import hashlib
+    import zlib
+    import numpy as np
+    from kbbq import recalibrate
+    tmp = os.environ.get('TMPDIR', '/tmp')
+    fa, fb, fo = (os.path.join(tmp, 'kbbq_benchz_%d_%s.fq' % (os.getpid(), x)) for x in 'abo')
+    batch = dev.ReadBatch.synthetic(0, n, n, seed=1)
+    seq, cseq, qual = (getattr(batch, p)[:n, :READ_LEN].cpu().numpy() for p in ('seq', 'cseq', 'qual'))
+    del batch
+    made = []
+    try:
+        sizes = {}
+        for path, plane in ((fa, seq), (fb, cseq)):
+            rec = np.empty((n, 318), dtype=np.uint8)
+            ids = np.arange(n)
+            digits = ((ids >> 1)[:, None] // 10 ** np.arange(8, -1, -1)[None, :] % 10 + 48).astype(np.uint8)
+            rec[:, 0] = ord('@'); rec[:, 1] = ord('r'); rec[:, 2:11] = digits; rec[:, 11] = ord('/')
+            rec[:, 12] = 49 + (ids & 1); rec[:, 13] = 10
+            rec[:, 14:164] = plane; rec[:, 164] = 10; rec[:, 165] = ord('+'); rec[:, 166] = 10
+            rec[:, 167:317] = qual; rec[:, 317] = 10
+            raw = rec.tobytes()
+            del rec
+            with open(path, 'wb') as fh:
+                fh.write(raw)
+            z = zlib.compressobj(1, zlib.DEFLATED, 31)
+            with open(path + '.gz', 'wb') as fh:
+                fh.write(z.compress(raw)); fh.write(z.flush())
+            made += [path, path + '.gz']
+            sizes[os.path.basename(path)] = {'text_bytes': len(raw), 'gzip_bytes': os.path.getsize(path + '.gz')}
+            del raw
+
+        def run(a, b, env):
+            saved = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                best = None
+                for _ in range(2):
+                    if os.path.exists(fo):
+                        os.remove(fo)
+                    t0 = time.perf_counter()
+                    recalibrate.recalibrate_fastq([a, b], output=fo)
+                    wall = time.perf_counter() - t0
+                    best = wall if best is None else min(best, wall)
+                h = hashlib.sha256()
+                with open(fo, 'rb') as fh:
+                    for blk in iter(lambda: fh.read(1 << 24), b''):
+                        h.update(blk)
+                return best, h.hexdigest()[:16]
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+        plain, sha0 = run(fa, fb, {})
+        wide, sha1 = run(fa + '.gz', fb + '.gz', {})
+        one, sha2 = run(fa + '.gz', fb + '.gz', {'KBBQ_PGZ_MIN_BYTES': str(1 << 60)})
+        bases = n * READ_LEN
+        return {'workload': '%d synthetic 2x150 bp reads as plain text and as one gzip member per file (level 1)' % n, 'files': sizes,
+                'plain_text': {'wall_s': plain, 'value': bases / plain, 'unit': 'bases/s'},
+                'gzip_on_all_host_threads': {'wall_s': wide, 'value': bases / wide, 'unit': 'bases/s',
+                                             'how': 'csrc/parallel_gunzip.cpp: chunks of the DEFLATE stream decoded side by side against unknown windows, resolved in order'},
+                'gzip_on_one_thread_per_file': {'wall_s': one, 'value': bases / one, 'unit': 'bases/s', 'how': 'libdeflate (zlib without it), KBBQ_PGZ_MIN_BYTES=2^60'},
+                'same_output_sha256': sha0 == sha1 == sha2}
+    finally:
+        for p in made + [fo]:
+            if os.path.exists(p):
+                os.remove(p)
+
+
 def build_extra(torch, dev, parallel, args, headline_layout):
     extra, n = {}, args.reads
     small = max(args.steps // 2, 3)
@@ -723,7 +797,8 @@ def build_extra(torch, dev, parallel, args, headline_layout):
                     ('single_end_150', lambda: extra_layout(torch, dev, parallel, n, small, 1, 'packed', single_end=True)),
                     ('config5_mixed_lengths', lambda: extra_mixed_lengths(torch, dev, min(20_000_000, n), small, 1)),
                     ('aligned_read_kernels', lambda: extra_aligned(torch, dev, n=min(16_000_000, n), G=min(200_000_000, 50 * n))),
-                    ('file_path', lambda: extra_file_path(torch, dev, n=min(8_000_000, n)))):
+                    ('file_path', lambda: extra_file_path(torch, dev, n=min(8_000_000, n))),
+                    ('compressed_inputs', lambda: extra_compressed_inputs(torch, dev, n=min(1_000_000, n)))):
         if key == 'layout_' + headline_layout:
             continue
         t0 = time.perf_counter()
