@@ -238,3 +238,36 @@ def test_wrapped_fastq_through_the_command_line(dev, oracle, tmp_path):
     r = _cli([sys.executable, '-m', 'kbbq.main', 'recalibrate', '-f', wa, wb])
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert len(r.stdout) == info['output_len'] and oracle.sha256(r.stdout) == info['output_sha256']
+
+
+@pytest.mark.parametrize('mode', ['mapped', 'sequential', 'back_to_zlib'])
+@pytest.mark.parametrize('name', ['c1_10k_1rg', 'c3cut_2k_8rg', 'c5cut_2k_mixed'])
+def test_gzip_pairs_inflated_on_many_threads_give_the_reference_bytes(dev, oracle, name, mode, tmp_path, monkeypatch):
+    """The goldens as `.fq.gz` pairs -- what pysam.FastxFile reads transparently (recalibrate.py:56,141) -- with every gzip member cut
+    into 4 KB chunks that inflate side by side (csrc/parallel_gunzip.cpp): through the mapped reader, through the sequential reader
+    (file A inflated again in pass 2: no spool), and with the decoder giving up after its second window (zlib takes over from the
+    file's start, past what was handed out): the reference's count vectors and output bytes."""
+    import gzip
+    from kbbq import recalibrate
+    info, gold = load_golden(name)
+    fa, fb = _files(oracle, info, tmp_path)
+    for p in (fa, fb):
+        with open(p, 'rb') as src, open(p + '.gz', 'wb') as dst:
+            dst.write(gzip.compress(src.read(), 6))
+    infer = info['case']['infer_rg']
+    monkeypatch.setenv('KBBQ_PGZ_MIN_BYTES', '0')
+    monkeypatch.setenv('KBBQ_PGZ_CHUNK', '4096')
+    monkeypatch.setenv('KBBQ_HOST_THREADS', '4')
+    if mode != 'mapped':
+        monkeypatch.setenv('KBBQ_SEQUENTIAL', '1')
+        monkeypatch.setenv('KBBQ_SEGMENT_BYTES', '128K')
+    if mode == 'back_to_zlib':
+        monkeypatch.setenv('KBBQ_PGZ_TEST_FAIL_AFTER', '2')
+    vec = recalibrate.fastq_to_covariate_arrays([fa + '.gz', fb + '.gz'], infer_rg=infer)
+    for k, v in zip(VEC, vec):
+        assert np.array_equal(v, gold[k]), k
+    out = str(tmp_path / 'out.fq')
+    recalibrate.recalibrate_fastq([fa + '.gz', fb + '.gz'], infer_rg=infer, output=out)
+    assert oracle.sha256(open(out, 'rb').read()) == info['output_sha256']
+    if mode != 'mapped':
+        assert recalibrate.LAST_RUN['streamed']['sequential'] and not recalibrate.LAST_RUN['streamed']['spooled']
