@@ -8,6 +8,7 @@
 #   bench[=ARGS]      python bench.py (default: the driver's form, --steps 20 --warmup 5)
 #   benchq            python bench.py --no-extra --cpu-sample 0 --steps 10 --warmup 3
 #   hostentry         scripts/time_host_entry.py (kbbq_accumulate / kbbq_apply on host buffers, PCIe included)
+#   smoke             __graft_entry__.smoke()
 #   e2e[=MODES]       tests/tools/e2e_cli.py: the whole command line on 8 M synthetic reads; MODES e.g. resident,budget=256M,sequential,pipes
 #   fuzz=SECONDS      the three randomised campaigns, SECONDS each
 #   py=SCRIPT[::ARGS] python SCRIPT ARGS  (timing scripts under scripts/ and tests/tools/)
@@ -37,6 +38,7 @@ for step in "$@"; do
     bench)     run bench 900 python bench.py ${arg:---steps 20 --warmup 5}; grep '^{' gpurun_out/bench_$TAG.log | tail -1 > gpurun_out/bench_$TAG.json ;;
     benchq)    run benchq 600 python bench.py --no-extra --cpu-sample 0 --steps 10 --warmup 3; grep '^{' gpurun_out/benchq_$TAG.log | tail -1 > gpurun_out/benchq_$TAG.json ;;
     hostentry) run hostentry 400 python scripts/time_host_entry.py ;;
+    smoke)     run smoke 600 python -c 'import __graft_entry__ as g; g.smoke()' ;;
     e2e)       run e2e 900 python tests/tools/e2e_cli.py --reads ${E2E_READS:-8000000} --reps ${E2E_REPS:-3} --modes ${arg:-resident} ;;
     fuzz)      seed=$(( $(date +%s) % 100000 ))
                run fuzz_kernels $((arg + 240)) python tests/tools/fuzz_gpu.py --seconds $arg --seed $seed && run fuzz_aligned $((arg + 240)) python tests/tools/fuzz_gpu_aligned.py --seconds $arg --seed $seed && run fuzz_cli $((arg + 240)) python tests/tools/fuzz_gpu_cli.py --seconds $arg --seed $seed ;;
