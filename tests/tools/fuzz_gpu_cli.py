@@ -51,11 +51,19 @@ while time.time() < t_end:
         O.write_fastq(fa, names, seq, qual, meta)
         keep = n if rng.random() > 0.2 else int(rng.integers(1, n + 1))
         O.write_fastq(fb, names[:keep], cseq[:keep], qual[:keep], meta[:keep])
-        if rng.random() < 0.1:
+        for k in ('KBBQ_PGZ_MIN_BYTES', 'KBBQ_PGZ_CHUNK', 'KBBQ_PGZ_TEST_FAIL_AFTER'):
+            os.environ.pop(k, None)
+        if rng.random() < 0.25:
+            level = int(rng.integers(0, 10))
             for f in (fa, fb):
-                with open(f, 'rb') as i, gzip.open(f + '.gz', 'wb') as o:
-                    o.write(i.read())
+                with open(f, 'rb') as i, open(f + '.gz', 'wb') as o:
+                    o.write(gzip.compress(i.read(), level))
             ga, gb = fa + '.gz', fb + '.gz'
+            if rng.random() < 0.7:       # the member cut into chunks that inflate side by side (csrc/parallel_gunzip.cpp), sometimes giving up half way
+                os.environ['KBBQ_PGZ_MIN_BYTES'] = '0'
+                os.environ['KBBQ_PGZ_CHUNK'] = str(int(rng.choice([1024, 4096, 30000, 1 << 20])))
+                if rng.random() < 0.2:
+                    os.environ['KBBQ_PGZ_TEST_FAIL_AFTER'] = str(int(rng.integers(0, 4)))
         else:
             ga, gb = fa, fb
         info = dict(case=cases, n=n, keep=keep, S=S, lo=lo, nrg=nrg, infer=infer, gz=ga != fa, single_end=single_end)
