@@ -200,6 +200,7 @@ struct Chunk {
     size_t end_bit = 0;                      // where decoding stopped (a block boundary)
     int end = -1;                            // 0: at the requested stop / limit; 1: the member's last block ended; -1: failed
     bool markers = true;                     // decoded against an unknown window
+    size_t limit = ~(size_t)0;               // symbols a chunk may become: text that inflates 100-fold is left to zlib's constant memory
     uint32_t crc = 0;
 };
 
@@ -219,7 +220,7 @@ inline bool inflate_block(Bits& b, const Codes& c, Chunk& ch, size_t& o, size_t 
         unsigned s = e >> 16;
         if (s < 256) {
             if (COUNT_ONLY) { ++counted; continue; }
-            if (o + 1 > cap) { ch.sym.resize(cap * 2); out = ch.sym.data(); cap = ch.sym.size(); }
+            if (o + 1 > cap) { if (cap > ch.limit) return false; ch.sym.resize(cap * 2); out = ch.sym.data(); cap = ch.sym.size(); }
             out[o++] = (uint16_t)s;
             // a second literal from the same refill (two litlen codes are at most 30 of the >= 56 bits)
             e = decode_sym(c.lit, b); l = e & 0xFF;
@@ -227,7 +228,7 @@ inline bool inflate_block(Bits& b, const Codes& c, Chunk& ch, size_t& o, size_t 
             s = e >> 16;
             if (s >= 256) { b.drop(l); goto not_literal; }
             b.drop(l);
-            if (o + 1 > cap) { ch.sym.resize(cap * 2); out = ch.sym.data(); cap = ch.sym.size(); }
+            if (o + 1 > cap) { if (cap > ch.limit) return false; ch.sym.resize(cap * 2); out = ch.sym.data(); cap = ch.sym.size(); }
             out[o++] = (uint16_t)s;
             continue;
         }
@@ -246,7 +247,7 @@ inline bool inflate_block(Bits& b, const Codes& c, Chunk& ch, size_t& o, size_t 
         if (b.over) return false;
         if (COUNT_ONLY) { counted += len; continue; }
         if (dist > o - floor_o) return false;                    // further back than the member's own text (only known for its first chunk)
-        if (o + len > cap) { ch.sym.resize(std::max(cap * 2, o + len)); out = ch.sym.data(); cap = ch.sym.size(); }
+        if (o + len > cap) { if (cap > ch.limit) return false; ch.sym.resize(std::max(cap * 2, o + len)); out = ch.sym.data(); cap = ch.sym.size(); }
         const uint16_t* from = out + o - dist;
         uint16_t* to = out + o;
         if (dist >= len) memcpy(to, from, (size_t)len * 2);
@@ -262,6 +263,7 @@ void decode_chunk(const uint8_t* src, size_t nbytes, size_t stop_bit, size_t lim
 {
     ch.end = -1; ch.n = 0;
     ch.markers = window == nullptr;
+    ch.limit = std::max<size_t>(guess * 8, (size_t)32 << 20);      // (a chunk's share of the input inflating more than 40-fold: not sequencing text)
     if (ch.sym.size() < WIN + std::max<size_t>(guess, 1 << 16)) ch.sym.resize(WIN + std::max<size_t>(guess, 1 << 16));   // (kept from window to window: fresh pages cost more than the decoding)
     uint16_t* w = ch.sym.data();
     if (window) for (size_t i = 0; i < WIN; ++i) w[i] = window[i];
@@ -278,7 +280,7 @@ void decode_chunk(const uint8_t* src, size_t nbytes, size_t stop_bit, size_t lim
             b.align_byte(); b.refill();
             const unsigned len = b.take(16), nlen = b.take(16);
             if (b.over || (len ^ nlen) != 0xFFFF) return;
-            if (o + len > ch.sym.size()) ch.sym.resize(std::max(ch.sym.size() * 2, o + len));
+            if (o + len > ch.sym.size()) { if (ch.sym.size() > ch.limit) return; ch.sym.resize(std::max(ch.sym.size() * 2, o + len)); }
             uint16_t* out = ch.sym.data();
             // the stored bytes: first what the bit buffer holds, then straight from the input
             unsigned left = len;
