@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -380,6 +381,7 @@ struct kbbq_pgz {
     bool ready = false;
     std::vector<size_t> order; std::vector<std::vector<uint8_t>> before;
     size_t total = 0, end_bit = 0; bool member_ends = false; unsigned nt = 1;
+    bool trace = false; double ms[4] = {0, 0, 0, 0};      // KBBQ_PGZ_TRACE: search / decode / chain / emit milliseconds of the window (stderr)
 };
 
 kbbq_pgz* kbbq_pgz_open(const uint8_t* src, size_t n, unsigned threads)
@@ -389,6 +391,7 @@ kbbq_pgz* kbbq_pgz_open(const uint8_t* src, size_t n, unsigned threads)
     z->threads = threads ? threads : kbbq_host_thread_ceiling();
     const char* e = getenv("KBBQ_PGZ_CHUNK");                    // compressed bytes per chunk (tests: small chunks on small files)
     z->chunk_bytes = e && atoll(e) >= 64 ? (size_t)atoll(e) : (size_t)1 << 20;
+    z->trace = getenv("KBBQ_PGZ_TRACE") != nullptr;
     const char* f = getenv("KBBQ_PGZ_TEST_FAIL_AFTER");
     if (f) z->fail_after = atol(f);
     return z;
@@ -433,6 +436,8 @@ int kbbq_pgz_prepare(kbbq_pgz* z, size_t* total_out)
     const size_t limit_bit = (first_byte + K * C) * 8;
     ch[0].start_bit = z->bit;
     const unsigned nt = (unsigned)std::min<size_t>(z->threads, K);
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](int i) { if (!z->trace) return; const auto t = std::chrono::steady_clock::now(); z->ms[i] = std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; };
     {
         std::atomic<size_t> nextk(1);
         kbbq_parallel(nt, [&](unsigned) {
@@ -440,6 +445,7 @@ int kbbq_pgz_prepare(kbbq_pgz* z, size_t* total_out)
                 ch[k].start_bit = find_block(src, n, (first_byte + k * C) * 8, (first_byte + (k + 1) * C) * 8);
         });
     }
+    lap(0);
     std::vector<size_t> stop(K, NONE);
     { size_t later = NONE; for (size_t k = K; k-- > 0;) { stop[k] = later; if (ch[k].start_bit != NONE) later = ch[k].start_bit; } }
     {
@@ -452,6 +458,7 @@ int kbbq_pgz_prepare(kbbq_pgz* z, size_t* total_out)
             }
         });
     }
+    lap(1);
     // the chain: every chunk must have ended where the next one began
     std::vector<size_t>& order = z->order; order.clear();
     bool member_ends = false; size_t end_bit = 0;
@@ -492,6 +499,7 @@ int kbbq_pgz_prepare(kbbq_pgz* z, size_t* total_out)
         }
         before.emplace_back(std::move(w));                       // the window behind the last chunk: committed below, once the trailer agrees
     }
+    lap(2);
     z->total = total; z->end_bit = end_bit; z->member_ends = member_ends; z->nt = nt; z->ready = true;
     *total_out = total;
     return 1;
@@ -503,6 +511,7 @@ int kbbq_pgz_emit(kbbq_pgz* z, uint8_t* out)
 {
     if (z->failed || !z->ready) return -1;
     z->ready = false;
+    const auto t_emit = std::chrono::steady_clock::now();
     const uint8_t* src = z->src; const size_t n = z->n;
     std::vector<Chunk>& ch = z->chunks;
     const std::vector<size_t>& order = z->order; const std::vector<std::vector<uint8_t>>& before = z->before;
@@ -552,7 +561,10 @@ int kbbq_pgz_emit(kbbq_pgz* z, uint8_t* out)
     memcpy(z->win, w.data(), WIN);
     z->valid = std::min<size_t>(WIN, z->valid + total);
     z->crc = crc; z->isize = isize;
-    z->delivered += total; if (getenv("KBBQ_PGZ_TRACE")) fprintf(stderr, "[pgz] window: %zu chunks, %zu bytes\n", order.size(), total);
+    z->delivered += total;
+    if (z->trace)
+        fprintf(stderr, "[pgz] window: %zu chunks, %zu bytes; search %.1f decode %.1f chain %.1f emit %.1f ms\n", order.size(), total, z->ms[0], z->ms[1], z->ms[2],
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_emit).count());
     if (member_ends) { z->in_member = false; z->pos = next_pos; z->k_cap = order.size() <= 1 ? 1 : 2 * order.size(); }     // (short members one after the other: no search ahead)
     else { z->bit = end_bit; z->k_cap = std::max<size_t>(z->k_cap * 2, 2); }
     return 1;

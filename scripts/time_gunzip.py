@@ -56,6 +56,10 @@ for mode in ('mapped', 'stream'):
         out = r.stdout.decode().strip()
         secs = float(out.split()[-2]) if r.returncode == 0 and out else float('nan')
         print('%-7s %-32s %s = %.2f GB/s of text' % (mode, label, out or r.stderr.decode()[-300:], text_bytes / secs / 1e9), flush=True)
+        if os.environ.get('KBBQ_PGZ_TRACE'):                     # the decoder's own account of its windows (the last repetition's)
+            lines = [l for l in r.stderr.decode().splitlines() if l.startswith('[pgz]')]
+            for l in lines[-6:]:
+                print('        ' + l, flush=True)
 if '--cli' in sys.argv:
     out = os.path.join(tmp, 'kbbq_gz_%d_out.fq' % os.getpid())
     shas = []
