@@ -11,6 +11,11 @@
 
 #include "raw_vector.h"
 
+// Segment buffers of the sequential reader are kept for the next segment (fastq_stream.cpp): memory that has been touched once costs
+// nothing to fill again, fresh pages cost more than reading the file does.
+void kbbq_text_pool_give(raw_vector<uint8_t>&& v);
+raw_vector<uint8_t> kbbq_text_pool_take(size_t capacity);
+
 struct kbbq_fastq {
     const uint8_t* buf = nullptr; size_t size = 0; bool mapped = false;
     size_t range_end = 0;                  // end of the indexed byte range (the file size for a whole-file reader)
@@ -19,7 +24,7 @@ struct kbbq_fastq {
     std::vector<std::string> rg_names;     // first-appearance order (filled by scan / fill with infer_rg)
     kbbq_bytes owned;                      // the inflated text of a compressed file
     raw_vector<uint8_t> text;              // a segment of a sequentially read file (fastq_stream.cpp): uninitialised until read into
-    ~kbbq_fastq() { if (mapped && buf) munmap((void*)buf, size); }
+    ~kbbq_fastq() { if (mapped && buf) munmap((void*)buf, size); if (text.capacity()) kbbq_text_pool_give(std::move(text)); }
 };
 
 

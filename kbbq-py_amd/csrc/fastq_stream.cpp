@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -58,6 +59,37 @@ struct kbbq_fastq_stream {
     void drop_pgz() { if (pgz) kbbq_pgz_close(pgz); pgz = nullptr; if (map) munmap((void*)map, map_n); map = nullptr; kbbq_bytes().swap(pend); pend_at = 0; }
     ~kbbq_fastq_stream() { drop_pgz(); if (zs_open) inflateEnd(&zs); if (own_fd && fd >= 0) close(fd); }
 };
+
+// ---- the pool of segment buffers: kept while a stream is open (at most kPoolMax), dropped with the last one
+namespace {
+std::mutex g_pool_mutex;
+std::vector<raw_vector<uint8_t>> g_pool;
+int g_live_streams = 0;
+constexpr size_t kPoolMax = 6;
+}
+
+void kbbq_text_pool_give(raw_vector<uint8_t>&& v)
+{
+    raw_vector<uint8_t> mine(std::move(v));
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    if (g_live_streams > 0 && g_pool.size() < kPoolMax) g_pool.emplace_back(std::move(mine));
+}                                                                  // (else freed here)
+
+raw_vector<uint8_t> kbbq_text_pool_take(size_t capacity)
+{
+    raw_vector<uint8_t> out;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        size_t best = g_pool.size();
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i].capacity() >= capacity && (best == g_pool.size() || g_pool[i].capacity() < g_pool[best].capacity())) best = i;
+        if (best < g_pool.size()) { out = std::move(g_pool[best]); g_pool.erase(g_pool.begin() + (long)best); }
+        else if (!g_pool.empty()) g_pool.pop_back();                // none is large enough: one of the small ones makes room
+    }
+    out.clear();
+    if (out.capacity() < capacity) out.reserve(capacity);
+    return out;
+}
 
 namespace {
 
@@ -386,6 +418,7 @@ int kbbq_fastq_stream_open(const char* path, kbbq_fastq_stream** out)
             if (s->fd_eof) s->eof = true;
         }
     }
+    { std::lock_guard<std::mutex> lk(g_pool_mutex); ++g_live_streams; }
     *out = s;
     return KBBQ_OK;
 }
@@ -434,6 +467,7 @@ int kbbq_fastq_stream_next(kbbq_fastq_stream* s, size_t max_bytes, int64_t recor
     raw_vector<uint8_t>& buf = f->text;
     size_t have = s->carry.size();
     size_t cap = std::max(max_bytes, have) + (1 << 16);
+    buf = kbbq_text_pool_take(cap);
     buf.resize(cap);
     if (have) memcpy(buf.data(), s->carry.data(), have);
     s->carry.clear();
@@ -484,6 +518,14 @@ int kbbq_fastq_stream_next(kbbq_fastq_stream* s, size_t max_bytes, int64_t recor
     return KBBQ_OK;
 }
 
-int kbbq_fastq_stream_close(kbbq_fastq_stream* s) { delete s; return KBBQ_OK; }
+int kbbq_fastq_stream_close(kbbq_fastq_stream* s)
+{
+    if (s) {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        if (--g_live_streams <= 0) { g_live_streams = 0; g_pool.clear(); g_pool.shrink_to_fit(); }
+    }
+    delete s;
+    return KBBQ_OK;
+}
 
 } // extern "C"

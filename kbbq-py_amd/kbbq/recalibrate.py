@@ -417,7 +417,8 @@ def _pair_segments(sa, sb, seg_bytes):
             ahead = threading.Thread(target=_quietly, args=(sb.prefetch, seg_bytes), daemon=True)
             ahead.start()
         try:
-            a, _ = sa.next(seg_bytes)
+            with stage('read'):
+                a, _ = sa.next(seg_bytes)
         finally:
             if ahead is not None:
                 ahead.join()
@@ -425,7 +426,8 @@ def _pair_segments(sa, sb, seg_bytes):
             return
         b = None
         if not b_ended:
-            b, _ = sb.next(len_bytes(a) + (1 << 16), a.n)
+            with stage('read'):
+                b, _ = sb.next(len_bytes(a) + (1 << 16), a.n)
             if b is None or b.n < a.n:
                 b_ended = True
         yield a, b
