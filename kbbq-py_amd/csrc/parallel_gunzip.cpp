@@ -28,7 +28,6 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
-#include <thread>
 #include <vector>
 
 #include <zlib.h>
@@ -365,17 +364,6 @@ uint32_t crc_of(const uint8_t* p, size_t n)
 
 }  // namespace
 
-// One window of chunks between kbbq_pgz_prepare (searched, decoded, chained: the stream's position moves on) and kbbq_pgz_emit
-// (resolved, written, checked).  Two of them, so that the next window can be prepared while this one is emitted.
-struct Window {
-    std::vector<Chunk> chunks;
-    std::vector<size_t> order;                          // the chunks that carry text, in file order
-    std::vector<std::vector<uint8_t>> before;           // the WIN bytes before every chunk that has markers
-    size_t total = 0, end_bit = 0; bool member_ends = false; unsigned nt = 1;
-    bool ready = false;
-    double ms[3] = {0, 0, 0};
-};
-
 struct kbbq_pgz {
     const uint8_t* src; size_t n; unsigned threads;
     size_t chunk_bytes;
@@ -385,13 +373,15 @@ struct kbbq_pgz {
     uint8_t win[WIN]; size_t valid = 0;   // the member's last WIN bytes of text (the last `valid` of them exist)
     uint32_t crc = 0; uint64_t isize = 0;
     size_t delivered = 0;
-    std::atomic<bool> failed{false};       // (set by either step; a window may be emitted while the next is prepared)
+    bool failed = false;
     long calls = 0, fail_after = -1;      // KBBQ_PGZ_TEST_FAIL_AFTER: the (n + 1)-th window is "not taken" (the callers' way back to zlib, for the tests)
     size_t k_cap = ~(size_t)0 >> 2;       // chunks per window at most
-    Window w[2]; int prep = 0, emit = 0;  // the next window to prepare / to emit (they alternate)
-    bool ahead = false;                   // the caller prepares a window while the one before it is being emitted (kbbq_parallel_gunzip)
-    size_t windows = 0;                   // prepared so far
-    bool trace = false;                   // KBBQ_PGZ_TRACE: search / decode / chain / emit milliseconds of every window (stderr)
+    std::vector<Chunk> chunks;
+    // a decoded window waiting to be written out (kbbq_pgz_prepare -> kbbq_pgz_emit)
+    bool ready = false;
+    std::vector<size_t> order; std::vector<std::vector<uint8_t>> before;
+    size_t total = 0, end_bit = 0; bool member_ends = false; unsigned nt = 1;
+    bool trace = false; double ms[4] = {0, 0, 0, 0};      // KBBQ_PGZ_TRACE: search / decode / chain / emit milliseconds of the window (stderr)
 };
 
 kbbq_pgz* kbbq_pgz_open(const uint8_t* src, size_t n, unsigned threads)
@@ -426,9 +416,7 @@ static size_t gzip_header(const uint8_t* s, size_t n)
 int kbbq_pgz_prepare(kbbq_pgz* z, size_t* total_out)
 {
     if (z->failed) return -1;
-    if (!z->ahead && z->w[z->emit].ready) { *total_out = z->w[z->emit].total; return 1; }   // (prepared and not emitted yet)
-    Window& W = z->w[z->prep];
-    if (W.ready) return -1;                                       // both windows are waiting to be emitted
+    if (z->ready) { *total_out = z->total; return 1; }
     if (z->fail_after >= 0 && z->calls++ >= z->fail_after) { z->failed = true; return -1; }
     const uint8_t* src = z->src; const size_t n = z->n;
     if (!z->in_member) {
@@ -436,20 +424,20 @@ int kbbq_pgz_prepare(kbbq_pgz* z, size_t* total_out)
         if (z->pos >= n) return 0;
         const size_t h = gzip_header(src + z->pos, n - z->pos);
         if (!h) { z->failed = true; return -1; }
-        z->bit = (z->pos + h) * 8; z->in_member = true; z->valid = 0;
+        z->bit = (z->pos + h) * 8; z->in_member = true; z->valid = 0; z->crc = 0; z->isize = 0;
     }
     // this window's chunks: the first at the known position, the others cut every chunk_bytes behind it
     const size_t first_byte = z->bit >> 3, C = z->chunk_bytes;
     const size_t room = n - first_byte;
     size_t K = std::min<size_t>(std::max<size_t>(2 * z->threads, 2), (room + C - 1) / C);
     K = std::max<size_t>(std::min(K, z->k_cap), 1);              // (a file of many short members: no wider than the last ones were long)
-    W.chunks.resize(K);
-    std::vector<Chunk>& ch = W.chunks;
+    z->chunks.resize(K);
+    std::vector<Chunk>& ch = z->chunks;
     const size_t limit_bit = (first_byte + K * C) * 8;
     ch[0].start_bit = z->bit;
     const unsigned nt = (unsigned)std::min<size_t>(z->threads, K);
     auto t_prev = std::chrono::steady_clock::now();
-    auto lap = [&](int i) { if (!z->trace) return; const auto t = std::chrono::steady_clock::now(); W.ms[i] = std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; };
+    auto lap = [&](int i) { if (!z->trace) return; const auto t = std::chrono::steady_clock::now(); z->ms[i] = std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; };
     {
         std::atomic<size_t> nextk(1);
         kbbq_parallel(nt, [&](unsigned) {
@@ -472,7 +460,7 @@ int kbbq_pgz_prepare(kbbq_pgz* z, size_t* total_out)
     }
     lap(1);
     // the chain: every chunk must have ended where the next one began
-    std::vector<size_t>& order = W.order; order.clear();
+    std::vector<size_t>& order = z->order; order.clear();
     bool member_ends = false; size_t end_bit = 0;
     for (size_t k = 0; k < K;) {
         if (ch[k].end < 0) { z->failed = true; return -1; }
@@ -487,7 +475,7 @@ int kbbq_pgz_prepare(kbbq_pgz* z, size_t* total_out)
     // windows in file order: chunk j's markers point into the WIN bytes before it
     size_t total = 0;
     for (size_t k : order) total += ch[k].n;
-    std::vector<std::vector<uint8_t>>& before = W.before;        // the window before every chunk that has markers
+    std::vector<std::vector<uint8_t>>& before = z->before;       // the window before every chunk that has markers
     before.assign(order.size(), std::vector<uint8_t>());
     {
         std::vector<uint8_t> w(z->win, z->win + WIN); size_t valid = z->valid;
@@ -509,21 +497,10 @@ int kbbq_pgz_prepare(kbbq_pgz* z, size_t* total_out)
             w.swap(nw);
             valid = std::min(WIN, valid + c.n);
         }
-        // a FIRST member that is over within one chunk and is followed by more: a file of many short members (concatenated files,
-        // blocked formats other than BGZF) -- nothing to spread over threads, and a window's set-up per member costs more than zlib
-        if (z->windows == 0 && member_ends && order.size() <= 1 && ((end_bit + 7) >> 3) + 8 + 18 < n) { z->failed = true; return -1; }
-        // the stream moves on (what the window's text must still pass -- CRC-32 and size -- is emit's business)
-        memcpy(z->win, w.data(), WIN);
-        z->valid = valid;
+        before.emplace_back(std::move(w));                       // the window behind the last chunk: committed below, once the trailer agrees
     }
     lap(2);
-    if (member_ends) {
-        if (((end_bit + 7) >> 3) + 8 > n) { z->failed = true; return -1; }
-        z->in_member = false; z->pos = ((end_bit + 7) >> 3) + 8;
-        z->k_cap = order.size() <= 1 ? 1 : 2 * order.size();     // (short members one after the other: no search ahead)
-    } else { z->bit = end_bit; z->k_cap = std::max<size_t>(z->k_cap * 2, 2); }
-    W.total = total; W.end_bit = end_bit; W.member_ends = member_ends; W.nt = nt; W.ready = true;
-    ++z->windows; z->prep ^= 1;
+    z->total = total; z->end_bit = end_bit; z->member_ends = member_ends; z->nt = nt; z->ready = true;
     *total_out = total;
     return 1;
 }
@@ -532,13 +509,13 @@ int kbbq_pgz_prepare(kbbq_pgz* z, size_t* total_out)
 // 1 = written and committed; -1 = not taken (what was written is to be ignored).
 int kbbq_pgz_emit(kbbq_pgz* z, uint8_t* out)
 {
-    Window& W = z->w[z->emit];
-    if (z->failed || !W.ready) return -1;
+    if (z->failed || !z->ready) return -1;
+    z->ready = false;
     const auto t_emit = std::chrono::steady_clock::now();
     const uint8_t* src = z->src; const size_t n = z->n;
-    std::vector<Chunk>& ch = W.chunks;
-    const std::vector<size_t>& order = W.order; const std::vector<std::vector<uint8_t>>& before = W.before;
-    const size_t total = W.total, end_bit = W.end_bit; const bool member_ends = W.member_ends; const unsigned nt = W.nt;
+    std::vector<Chunk>& ch = z->chunks;
+    const std::vector<size_t>& order = z->order; const std::vector<std::vector<uint8_t>>& before = z->before;
+    const size_t total = z->total, end_bit = z->end_bit; const bool member_ends = z->member_ends; const unsigned nt = z->nt;
     std::vector<size_t> at(order.size() + 1, 0);
     for (size_t j = 0; j < order.size(); ++j) at[j + 1] = at[j] + ch[order[j]].n;
     {
@@ -567,19 +544,29 @@ int kbbq_pgz_emit(kbbq_pgz* z, uint8_t* out)
         crc = (uint32_t)crc32_combine(crc, c.crc, (z_off_t)c.n);
         isize += c.n;
     }
+    size_t next_pos = 0;
     if (member_ends) {
         const size_t p = (end_bit + 7) >> 3;
+        if (p + 8 > n) { z->failed = true; return -1; }
         const uint32_t want_crc = (uint32_t)src[p] | (uint32_t)src[p + 1] << 8 | (uint32_t)src[p + 2] << 16 | (uint32_t)src[p + 3] << 24;
         const uint32_t want_size = (uint32_t)src[p + 4] | (uint32_t)src[p + 5] << 8 | (uint32_t)src[p + 6] << 16 | (uint32_t)src[p + 7] << 24;
         if (want_crc != crc || want_size != (uint32_t)isize) { z->failed = true; return -1; }
-        crc = 0; isize = 0;                                       // (the next member starts its own)
+        next_pos = p + 8;
+        // a FIRST member that is over within one chunk and is followed by more: a file of many short members (concatenated files,
+        // blocked formats other than BGZF) -- nothing to spread over threads, and a window's set-up per member costs more than zlib
+        if (z->delivered == 0 && order.size() <= 1 && next_pos + 18 < n) { z->failed = true; return -1; }
     }
+    // commit
+    const std::vector<uint8_t>& w = before.back();
+    memcpy(z->win, w.data(), WIN);
+    z->valid = std::min<size_t>(WIN, z->valid + total);
     z->crc = crc; z->isize = isize;
     z->delivered += total;
     if (z->trace)
-        fprintf(stderr, "[pgz] window: %zu chunks, %zu bytes; search %.1f decode %.1f chain %.1f emit %.1f ms\n", order.size(), total, W.ms[0], W.ms[1], W.ms[2],
+        fprintf(stderr, "[pgz] window: %zu chunks, %zu bytes; search %.1f decode %.1f chain %.1f emit %.1f ms\n", order.size(), total, z->ms[0], z->ms[1], z->ms[2],
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_emit).count());
-    W.ready = false; z->emit ^= 1;
+    if (member_ends) { z->in_member = false; z->pos = next_pos; z->k_cap = order.size() <= 1 ? 1 : 2 * order.size(); }     // (short members one after the other: no search ahead)
+    else { z->bit = end_bit; z->k_cap = std::max<size_t>(z->k_cap * 2, 2); }
     return 1;
 }
 
@@ -603,23 +590,10 @@ size_t kbbq_pgz_min_bytes()
 
 bool kbbq_parallel_gunzip(const uint8_t* src, size_t n, kbbq_bytes& out, unsigned threads)
 {
-    // window w is emitted on a thread of its own while window w + 1 is prepared here (its search and decoding need nothing of w's text)
     kbbq_pgz* z = kbbq_pgz_open(src, n, threads);
-    z->ahead = true;
     const size_t old = out.size();
-    size_t total = 0;
-    int rc = kbbq_pgz_prepare(z, &total), emitted = 1;
-    while (rc == 1) {
-        const size_t at = out.size();
-        out.resize(at + total);                                   // (no emit is running: the vector may move)
-        uint8_t* dst = out.data() + at;
-        std::thread writer([&]() { emitted = kbbq_pgz_emit(z, dst); });
-        size_t next_total = 0;
-        rc = kbbq_pgz_prepare(z, &next_total);
-        writer.join();
-        if (emitted != 1) { rc = -1; break; }
-        total = next_total;
-    }
+    int rc;
+    while ((rc = kbbq_pgz_next(z, out)) == 1) {}
     kbbq_pgz_close(z);
     if (rc < 0) { out.resize(old); return false; }
     return true;
