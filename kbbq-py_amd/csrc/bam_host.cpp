@@ -90,6 +90,7 @@ bool inflate_serial(const uint8_t* src, size_t n, kbbq_bytes& out, std::string& 
         out.clear();
         const size_t hint = le32(src + n - 4);                                 // one member below 4 GB: its size; else the vector grows
         out.reserve(std::max<size_t>(hint >= n ? hint : 0, n * 3));
+        kbbq_advise_huge(out.data(), out.capacity());
         if (kbbq_parallel_gunzip(src, n, out, 0)) return true;
         out.clear();
     }

@@ -87,7 +87,7 @@ raw_vector<uint8_t> kbbq_text_pool_take(size_t capacity)
         else if (!g_pool.empty()) g_pool.pop_back();                // none is large enough: one of the small ones makes room
     }
     out.clear();
-    if (out.capacity() < capacity) out.reserve(capacity);
+    if (out.capacity() < capacity) { out.reserve(capacity); kbbq_advise_huge(out.data(), out.capacity()); }
     return out;
 }
 

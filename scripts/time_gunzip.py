@@ -46,7 +46,7 @@ code = ('import sys, time; sys.path.insert(0, %r)\n'
         '        s.close()\n'
         '    best = min(best, time.perf_counter() - t0)\n'
         'print("%%d records, best of three %%.3f s" %% (nrec, best))\n' % os.path.join(ROOT, 'kbbq-py_amd'))
-variants = (('all threads (parallel_gunzip)', {}), ('libdeflate, one thread', {'KBBQ_PGZ_MIN_BYTES': str(1 << 60)}),
+variants = (('all threads (parallel_gunzip)', {}), ('all threads, no huge pages asked', {'KBBQ_HUGE_PAGES': '0'}), ('libdeflate, one thread', {'KBBQ_PGZ_MIN_BYTES': str(1 << 60)}),
             ('zlib, one thread', {'KBBQ_PGZ_MIN_BYTES': str(1 << 60), 'KBBQ_LIBDEFLATE': '0'}))
 for mode in ('mapped', 'stream'):
     for label, env in variants:
