@@ -79,6 +79,9 @@ int         kbbq_device_count(int* count);
  * = -1 and nothing changed when the system names none.  The reference has no counterpart: it is single-threaded
  * (recalibrate.py:56-57,141-156 walk the reads in one Python loop).                                                    */
 int         kbbq_host_threads(size_t work_bytes);
+/* Ask for huge pages behind a large host buffer the caller is about to fill for the first time (madvise; a no-op where
+ * transparent huge pages are off or KBBQ_HUGE_PAGES=0): the egress pipeline's render buffers.  Always KBBQ_OK. */
+int         kbbq_host_advise_huge(void* p, size_t bytes);
 int         kbbq_bind_host_to_pci(const char* pci_bus_id, int* numa_node, int* ncpus);
 int         kbbq_bind_host_to_device(int device, int* numa_node, int* ncpus);
 int         kbbq_ctx_create(int device, kbbq_ctx** out);

@@ -239,7 +239,7 @@ bool kbbq_inflate_all(const uint8_t* src, size_t n, kbbq_bytes& out, std::string
     std::vector<Block> blocks;
     if (!index_bgzf(src, n, blocks)) return inflate_serial(src, n, out, err);   // plain gzip (or a damaged BGZF: zlib decides)
     const size_t total = blocks.empty() ? 0 : blocks.back().dst + blocks.back().isize;
-    out.resize(total);
+    kbbq_resize_fresh(out, total);
     std::atomic<int> bad(0);
     threads_over(blocks.size(), kbbq_threads_for(n), [&](size_t lo, size_t hi) {
         kbbq_block_inflater fast;

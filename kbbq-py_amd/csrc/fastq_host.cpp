@@ -135,7 +135,7 @@ int kbbq_fastq_index_range_(kbbq_fastq* f, size_t r0, size_t r1)
     if (nlines % 4 != 0) return 4;
     const int64_t n = (int64_t)(nlines / 4);
     f->range_end = r1;
-    f->h0.resize(n); f->s0.resize(n); f->q0.resize(n); f->hlen.resize(n); f->slen.resize(n);
+    kbbq_resize_fresh(f->h0, n); kbbq_resize_fresh(f->s0, n); kbbq_resize_fresh(f->q0, n); kbbq_resize_fresh(f->hlen, n); kbbq_resize_fresh(f->slen, n);
     raw_vector<uint32_t> qlen((size_t)n);
     std::atomic<int> bad(0);
     {

@@ -7,6 +7,7 @@
 // complex that uploads them.
 #include "../../include/kbbq_hip.h"
 #include "host_threads.h"
+#include "raw_vector.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -49,6 +50,8 @@ static bool read_text(const std::string& path, char* buf, size_t cap)
 extern "C" {
 
 int kbbq_host_threads(size_t work_bytes) { return (int)kbbq_threads_for(work_bytes); }
+
+int kbbq_host_advise_huge(void* p, size_t bytes) { if (p && bytes) kbbq_advise_huge(p, bytes); return KBBQ_OK; }
 
 // Bind the calling thread -- and so every thread it starts from now on: the library's readers, packers and writers are
 // started per call -- to the CPUs of the NUMA node of PCI device `pci_bus_id` ("0000:c1:00.0", as hipDeviceGetPCIBusId

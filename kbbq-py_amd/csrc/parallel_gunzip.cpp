@@ -265,7 +265,7 @@ void decode_chunk(const uint8_t* src, size_t nbytes, size_t stop_bit, size_t lim
     ch.end = -1; ch.n = 0;
     ch.markers = window == nullptr;
     ch.limit = std::max<size_t>(guess * 8, (size_t)32 << 20);      // (a chunk's share of the input inflating more than 40-fold: not sequencing text)
-    if (ch.sym.size() < WIN + std::max<size_t>(guess, 1 << 16)) ch.sym.resize(WIN + std::max<size_t>(guess, 1 << 16));   // (kept from window to window: fresh pages cost more than the decoding)
+    if (ch.sym.size() < WIN + std::max<size_t>(guess, 1 << 16)) kbbq_resize_fresh(ch.sym, WIN + std::max<size_t>(guess, 1 << 16));   // (kept from window to window: fresh pages cost more than the decoding)
     uint16_t* w = ch.sym.data();
     if (window) for (size_t i = 0; i < WIN; ++i) w[i] = window[i];
     else for (size_t i = 0; i < WIN; ++i) w[i] = (uint16_t)(MARK | i);

@@ -31,3 +31,14 @@ inline void kbbq_advise_huge(void* p, size_t bytes)
     (void)p; (void)bytes;
 #endif
 }
+
+
+// resize() of a vector that is about to be filled for the first time, huge pages asked for when it is large
+template <typename V> inline void kbbq_resize_fresh(V& v, size_t n)
+{
+    if (v.capacity() < n && n * sizeof(typename V::value_type) >= ((size_t)8 << 20)) {
+        v.reserve(n);
+        kbbq_advise_huge(v.data(), v.capacity() * sizeof(typename V::value_type));
+    }
+    v.resize(n);
+}

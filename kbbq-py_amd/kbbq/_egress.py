@@ -128,7 +128,11 @@ def emit_produced(text, base, produced, widest, slab=1 << 18, sink=None):
         made[0] += 1
         return dev.pinned('egress', made[0], max(nbytes, slab * widest))
     staging = Slots(4, page_locked)
-    rendered = Slots(4, lambda nbytes: np.empty(nbytes + (nbytes >> 3), dtype=np.uint8))
+    def fresh(nbytes):
+        buf = np.empty(nbytes + (nbytes >> 3), dtype=np.uint8)
+        dev.N.load().kbbq_host_advise_huge(buf.ctypes.data, buf.nbytes)      # 90 MB the rendering threads touch for the first time
+        return buf
+    rendered = Slots(4, fresh)
 
     def fetch(item):
         k, band, out, first, m = item

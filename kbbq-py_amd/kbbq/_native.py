@@ -37,6 +37,7 @@ PROTOTYPES = {
     'kbbq_last_error': (_c.c_char_p, []),
     'kbbq_device_count': (_i, [_c.POINTER(_i)]),
     'kbbq_host_threads': (_i, [_sz]),
+    'kbbq_host_advise_huge': (_i, [_vp, _sz]),
     'kbbq_bind_host_to_pci': (_i, [_c.c_char_p, _c.POINTER(_i), _c.POINTER(_i)]),
     'kbbq_bind_host_to_device': (_i, [_i, _c.POINTER(_i), _c.POINTER(_i)]),
     'kbbq_ctx_create': (_i, [_i, _c.POINTER(_vp)]),
