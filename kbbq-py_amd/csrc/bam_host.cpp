@@ -306,7 +306,7 @@ bool kbbq_bam_to_sam(const uint8_t* bam, size_t n, kbbq_bytes& text, std::string
         const size_t lo = std::min(nrec, t * per), hi = std::min(nrec, lo + per);
         if (lo >= hi) return;
         Sink& o = parts[t];
-        o.buf.resize((rec[hi] - rec[lo]) * 2 + 4096);
+        kbbq_resize_fresh(o.buf, (rec[hi] - rec[lo]) * 2 + 4096);
         for (size_t i = lo; i < hi; ++i)
             if (!format_record(bam + rec[i], rec[i + 1] - rec[i] - 4, refs, longest_ref, o)) {
                 long long cur = bad.load();
@@ -317,7 +317,7 @@ bool kbbq_bam_to_sam(const uint8_t* bam, size_t n, kbbq_bytes& text, std::string
     if (bad.load() >= 0) { err = "BAM: malformed alignment record " + std::to_string(bad.load()); return false; }
     std::vector<size_t> at_part(nt + 1, text.size());                          // the parts side by side into their places
     for (unsigned t = 0; t < nt; ++t) at_part[t + 1] = at_part[t] + parts[t].n;
-    text.resize(at_part[nt]);
+    kbbq_resize_fresh(text, at_part[nt]);
     kbbq_parallel(nt, [&](unsigned t) {
         if (parts[t].n) memcpy(text.data() + at_part[t], parts[t].buf.data(), parts[t].n);
         kbbq_bytes().swap(parts[t].buf);

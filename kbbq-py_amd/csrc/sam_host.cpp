@@ -211,13 +211,19 @@ int kbbq_sam_open(const char* path, kbbq_sam** out)
     std::vector<uint64_t> rname0, cig0; std::vector<uint32_t> rname_len, cig_len;
     {
         // 23 arrays of n entries (2 GB at 16 M alignments): sized and zeroed side by side instead of one after the other
+        // (huge pages asked for behind the large ones: raw_vector.h)
+        auto fresh = [](auto& v, size_t count, auto value) {
+            using T = typename std::remove_reference_t<decltype(v)>::value_type;
+            if (count * sizeof(T) >= ((size_t)8 << 20) && v.capacity() < count) { v.reserve(count); kbbq_advise_huge(v.data(), v.capacity() * sizeof(T)); }
+            v.assign(count, (T)value);
+        };
         const std::function<void()> fills[] = {
-            [&]() { f->name_len.assign(n, 0); }, [&]() { f->seq_len.assign(n, 0); }, [&]() { f->qual_len.assign(n, 0); }, [&]() { f->oq_len.assign(n, 0); },
-            [&]() { f->rgtag_len.assign(n, 0); }, [&]() { f->cig_n.assign(n, 0); }, [&]() { f->clip.assign(n, 0); }, [&]() { f->seq0.assign(n, 0); },
-            [&]() { f->qual0.assign(n, 0); }, [&]() { f->oq0.assign(n, 0); }, [&]() { f->rgtag0.assign(n, 0); }, [&]() { f->cig_off.assign(n + 1, 0); },
-            [&]() { f->flag.assign(n, 0); }, [&]() { f->contig.assign(n, -1); }, [&]() { f->ref_span.assign(n, 0); }, [&]() { f->rg.assign(n, -1); },
-            [&]() { f->pos.assign(n, 0); }, [&]() { f->pnext.assign(n, 0); }, [&]() { f->tlen.assign(n, 0); }, [&]() { rname0.assign(n, 0); },
-            [&]() { cig0.assign(n, 0); }, [&]() { rname_len.assign(n, 0); }, [&]() { cig_len.assign(n, 0); }};
+            [&]() { fresh(f->name_len, (size_t)(n), 0); }, [&]() { fresh(f->seq_len, (size_t)(n), 0); }, [&]() { fresh(f->qual_len, (size_t)(n), 0); }, [&]() { fresh(f->oq_len, (size_t)(n), 0); },
+            [&]() { fresh(f->rgtag_len, (size_t)(n), 0); }, [&]() { fresh(f->cig_n, (size_t)(n), 0); }, [&]() { fresh(f->clip, (size_t)(n), 0); }, [&]() { fresh(f->seq0, (size_t)(n), 0); },
+            [&]() { fresh(f->qual0, (size_t)(n), 0); }, [&]() { fresh(f->oq0, (size_t)(n), 0); }, [&]() { fresh(f->rgtag0, (size_t)(n), 0); }, [&]() { fresh(f->cig_off, (size_t)(n + 1), 0); },
+            [&]() { fresh(f->flag, (size_t)(n), 0); }, [&]() { fresh(f->contig, (size_t)(n), -1); }, [&]() { fresh(f->ref_span, (size_t)(n), 0); }, [&]() { fresh(f->rg, (size_t)(n), -1); },
+            [&]() { fresh(f->pos, (size_t)(n), 0); }, [&]() { fresh(f->pnext, (size_t)(n), 0); }, [&]() { fresh(f->tlen, (size_t)(n), 0); }, [&]() { fresh(rname0, (size_t)(n), 0); },
+            [&]() { fresh(cig0, (size_t)(n), 0); }, [&]() { fresh(rname_len, (size_t)(n), 0); }, [&]() { fresh(cig_len, (size_t)(n), 0); }};
         const unsigned nf = (unsigned)(sizeof fills / sizeof fills[0]);
         std::atomic<unsigned> next(0);
         kbbq_parallel(std::min(nt, nf), [&](unsigned) { for (unsigned k; (k = next.fetch_add(1)) < nf;) fills[k](); });
