@@ -388,7 +388,7 @@ kbbq_pgz* kbbq_pgz_open(const uint8_t* src, size_t n, unsigned threads)
 {
     kbbq_pgz* z = new kbbq_pgz();
     z->src = src; z->n = n;
-    z->threads = threads ? threads : kbbq_host_thread_ceiling();
+    z->threads = std::min(threads ? threads : kbbq_host_thread_ceiling(), 32u);     // (a window is 2 x threads chunks of ~25 MB of symbols: 1.6 GB at 32)
     const char* e = getenv("KBBQ_PGZ_CHUNK");                    // compressed bytes per chunk (tests: small chunks on small files)
     z->chunk_bytes = e && atoll(e) >= 64 ? (size_t)atoll(e) : (size_t)1 << 20;
     z->trace = getenv("KBBQ_PGZ_TRACE") != nullptr;
