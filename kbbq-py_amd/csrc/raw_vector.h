@@ -3,8 +3,11 @@
 // in parallel instead of in one zero-filling thread).
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <vector>
+
+#include <sys/mman.h>
 
 template <typename T> struct raw_alloc : std::allocator<T> {
     template <typename U> struct rebind { using other = raw_alloc<U>; };
@@ -18,8 +21,6 @@ using kbbq_bytes = raw_vector<uint8_t>;
 
 // Ask for huge pages behind a large buffer that is about to be filled for the first time (transparent huge pages in "madvise" mode):
 // 512 times fewer page faults for the threads that fill it.  KBBQ_HUGE_PAGES=0 turns it off.
-#include <cstdlib>
-#include <sys/mman.h>
 inline void kbbq_advise_huge(void* p, size_t bytes)
 {
 #ifdef MADV_HUGEPAGE
