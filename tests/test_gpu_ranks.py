@@ -72,6 +72,26 @@ def test_ranks_write_the_reference_output(dev, oracle, name, tmp_path):
     assert len(threads) == RANKS and sum(threads) <= max(_usable_cpus(), RANKS), err[-1500:]
 
 
+def test_ranks_read_a_compressed_pair(dev, oracle, tmp_path):
+    """The same on a `.fq.gz` pair: a compressed file cannot be cut into byte ranges, so every rank inflates it whole (here through
+    the chunked inflater, csrc/parallel_gunzip.cpp, with 4 KB chunks) and takes its shard of the records: the reference's bytes."""
+    import gzip
+    from test_gpu_parity import _files
+    info, _ = load_golden('c3cut_2k_8rg')
+    fa, fb = _files(oracle, info, tmp_path)
+    for p in (fa, fb):
+        with open(p, 'rb') as src, open(p + '.gz', 'wb') as dst:
+            dst.write(gzip.compress(src.read(), 6))
+    out = str(tmp_path / 'out.fq')
+    r = _run_ranks(RANKS, ['recalibrate', '-f', fa + '.gz', fb + '.gz', '-o', out, '--infer-rg'],
+                   env={'KBBQ_PGZ_MIN_BYTES': '0', 'KBBQ_PGZ_CHUNK': '4096'})
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    parts = sorted(glob.glob(out + '.rank*'))
+    assert len(parts) == RANKS
+    text = b''.join(open(p, 'rb').read() for p in parts).decode()
+    assert len(text) == info['output_len'] and oracle.sha256(text) == info['output_sha256']
+
+
 def test_ranks_print_in_rank_order(dev, oracle, tmp_path):
     """The same to a shared stdout (the ranks print in turn): BASELINE config 3's cut, 8 read groups."""
     from test_gpu_parity import _files
