@@ -77,6 +77,37 @@ class Slots:
         return b
 
 
+class _Reserve:
+    """The blocks of every slab are reserved (fallocate, without moving the file's end) just before the slab is written: on disk-backed
+    filesystems write(2) into the page cache then runs 15 % faster (0.27 -> 0.23 s per 2.5 GB; neutral on tmpfs: scripts/gpu_write_bench.sh).
+    Regular files only; the first refusal (a filesystem without fallocate) ends it.  KBBQ_FALLOCATE=0 turns it off."""
+
+    def __init__(self, raw):
+        import os
+        import stat
+        self.fd, self.at, self.call = None, 0, None
+        if os.environ.get('KBBQ_FALLOCATE') == '0':
+            return
+        try:
+            fd = raw.fileno()
+            if not stat.S_ISREG(os.fstat(fd).st_mode):
+                return
+            import ctypes
+            libc = ctypes.CDLL(None, use_errno=True)
+            libc.fallocate.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_longlong]
+            libc.fallocate.restype = ctypes.c_int
+            raw.flush()
+            self.at = os.lseek(fd, 0, os.SEEK_CUR)
+            self.fd, self.call = fd, libc.fallocate
+        except Exception:                    # noqa: BLE001 -- an optimisation: anything unusual about the sink and it stays out of the way
+            self.fd = None
+
+    def ahead(self, nbytes):
+        if self.fd is not None and self.call(self.fd, 1, self.at, nbytes) != 0:      # 1 = FALLOC_FL_KEEP_SIZE
+            self.fd = None
+        self.at += nbytes
+
+
 def _slabs(produced, step):
     """(serial number, band, its device plane of new qualities, first read, reads) for slabs of `step` reads (even, so
     that a slab of mate-pair rows starts at a first mate).  produced: (band, plane) pairs -- a list, or a generator that
@@ -152,8 +183,11 @@ def emit_produced(text, base, produced, widest, slab=1 << 18, sink=None):
         with stage('format'):
             return reader.format_rows_array(first, m, newq, flags, S2, out=lambda nbytes: rendered.get(k, nbytes))
 
+    reserve = _Reserve(raw)
+
     def write(buf):
         with stage('write'):
+            reserve.ahead(len(buf))
             raw.write(memoryview(buf))
 
     try:

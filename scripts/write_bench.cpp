@@ -6,6 +6,7 @@
 #include <thread>
 #include <vector>
 #include <fcntl.h>
+#include <linux/falloc.h>
 #include <sys/mman.h>
 #include <unistd.h>
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -16,12 +17,14 @@ int main(int argc, char** argv)
     std::vector<char> src(slab); for (size_t i = 0; i < slab; ++i) src[i] = (char)(i * 7);
     unlink(path);
     int fd = open(path, O_CREAT | O_WRONLY | O_TRUNC, 0644);
-    if (mode) { close(fd); fd = open(path, O_RDWR); }
+    if (mode == 1 || mode == 2) { close(fd); fd = open(path, O_RDWR); }
     const double t0 = now();
     size_t off = 0;
     while (off < total) {
         const size_t n = std::min(slab, total - off);
-        if (mode == 0) { size_t w = 0; while (w < n) { ssize_t k = write(fd, src.data() + w, n - w); if (k <= 0) { perror("write"); return 1; } w += k; } }
+        if (mode == 3 && posix_fallocate(fd, off, n)) { perror("fallocate"); return 1; }        // the slab's blocks reserved, then plain write(2)
+        if (mode == 4 && fallocate(fd, FALLOC_FL_KEEP_SIZE, (off_t)off, (off_t)n)) { perror("fallocate keep-size"); return 1; }   // ... without moving the file's end
+        if (mode == 0 || mode == 3 || mode == 4) { size_t w = 0; while (w < n) { ssize_t k = write(fd, src.data() + w, n - w); if (k <= 0) { perror("write"); return 1; } w += k; } }
         else {
             if (mode == 2) { if (posix_fallocate(fd, off, n)) { perror("fallocate"); return 1; } }
             else if (ftruncate(fd, off + n)) { perror("ftruncate"); return 1; }
