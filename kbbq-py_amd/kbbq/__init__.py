@@ -19,12 +19,12 @@ def _start_the_device_early():
     import sys
     if sys.argv[:2] != ['-m', 'recalibrate'] or 'RANK' in os.environ or os.environ.get('KBBQ_USE_TORCH') or os.environ.get('KBBQ_LATE_DEVICE'):
         return
-    import ctypes
     import threading
-    from . import _native                    # (here, not on the thread: an import from another thread would wait for THIS package's import to end)
 
     def run():
         try:
+            import ctypes
+            from . import _native
             _native.load().kbbq_device_count(ctypes.byref(ctypes.c_int(0)))
         except Exception:                    # noqa: BLE001 -- whatever is wrong is reported where the device is first needed
             pass
