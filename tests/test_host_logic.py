@@ -1195,3 +1195,67 @@ def test_gzip_members_inflate_on_many_threads(oracle, tmp_path):
     good = [l.split(' ', 2)[2] for l in lines if l.startswith(('a.fq ', 'l0', 'l1', 'l6', 'l9', 'two')) and ' mapped ' in l]   # ('l6' takes l6sync too)
     assert len(set(good)) == 1 and good[0].startswith('%d ' % n), lines
     assert all('ValueError' in l for l in lines if l.startswith(('bad', 'cut'))), lines
+
+
+def test_the_writer_reserves_blocks_without_moving_the_files_end(tmp_path):
+    """_egress._Reserve: fallocate(KEEP_SIZE) ahead of every slab's write -- the file holds exactly what was written, sinks that are not
+    regular files are left alone, KBBQ_FALLOCATE=0 turns it off, and a refusal ends it quietly."""
+    import io
+    from kbbq import _egress
+    p = tmp_path / 'out.bin'
+    with open(p, 'wb') as fh:
+        fh.write(b'head')
+        r = _egress._Reserve(fh)
+        assert r.fd is not None and r.at == 4
+        for blob in (b'x' * 100000, b'y' * 5):
+            r.ahead(len(blob)); fh.write(blob)
+        assert r.at == 4 + 100005
+    assert p.read_bytes() == b'head' + b'x' * 100000 + b'y' * 5
+    assert _egress._Reserve(io.BytesIO()).fd is None
+    rd, wr = os.pipe()
+    with os.fdopen(wr, 'wb') as w:
+        assert _egress._Reserve(w).fd is None
+    os.close(rd)
+    os.environ['KBBQ_FALLOCATE'] = '0'
+    try:
+        with open(p, 'wb') as fh:
+            assert _egress._Reserve(fh).fd is None
+    finally:
+        del os.environ['KBBQ_FALLOCATE']
+    with open(p, 'wb') as fh:
+        r = _egress._Reserve(fh)
+        r.call = lambda *a: -1                                    # a filesystem that refuses
+        r.ahead(10)
+        assert r.fd is None and r.at == 10
+        r.ahead(10)                                               # stays off
+        assert r.at == 20
+
+
+def test_segment_buffers_are_kept_between_segments_and_dropped_with_the_last_stream(oracle, tmp_path):
+    """csrc/fastq_stream.cpp kbbq_text_pool_*: a closed segment's buffer serves the next segment (same memory), and nothing is kept once
+    no stream is open."""
+    n = 3000
+    seq, cseq, qual, meta = oracle.synth(0, n, n, 9, 100, 100, 1)
+    fa = str(tmp_path / 'a.fq')
+    oracle.write_fastq(fa, oracle.synth_names(0, n, 1, with_rg=False), seq, qual, meta)
+    s = fastx.FastqStream(fa)
+    seg, _ = s.next(100000)
+    where = seg.record_offset(seg.first)                              # offsets are relative: ask the library where the text lives
+    lib = _native.load()
+    p1 = ctypes.c_void_p(); ln = ctypes.c_int(0)
+    lib.kbbq_fastq_name(seg._h, 0, ctypes.byref(p1), ctypes.byref(ln))
+    first_addr = p1.value
+    total = seg.n
+    seg.close()
+    seg2, _ = s.next(100000)
+    lib.kbbq_fastq_name(seg2._h, 0, ctypes.byref(p1), ctypes.byref(ln))
+    assert p1.value == first_addr                                     # the same buffer, filled again
+    total += seg2.n
+    while True:
+        seg2.close()
+        seg2, _ = s.next(100000)
+        if seg2 is None:
+            break
+        total += seg2.n
+    assert total == n
+    s.close()
