@@ -525,6 +525,12 @@ int kbbq_sam_cigar(const kbbq_sam* f, uint32_t* ops);
 /* trim[i] = lo | hi << 16: query positions [lo, hi) of alignment i lie past its adaptor boundary (0: none) -- the reference's
  * bamread_adaptor_boundary + trim_bamread (gatk/bqsr.py:131-206) for every alignment of the file, by CIGAR walk. */
 int kbbq_sam_adaptor_trim(const kbbq_sam* f, uint32_t* trim);
+/* A whole regular file as bytes, inflated when it is gzip / bgzip (bgzip blocks side by side, gzip members chunk-wise on all host threads):
+ * where kbbq/aln.py's FASTA / VCF / BED readers (the reference reads those through pysam: benchmark.py:9-55) take their text from.
+ * *data stays valid until kbbq_text_close. */
+typedef struct kbbq_text kbbq_text;
+int kbbq_text_open(const char* path, kbbq_text** out, const uint8_t** data, size_t* n);
+int kbbq_text_close(kbbq_text* t);
 int kbbq_sam_fill(const kbbq_sam* f, int64_t first, int64_t n, int pitch, int which, uint8_t* plane);
 int kbbq_sam_text(const kbbq_sam* f, int what, int64_t i, const char** p, int64_t* len);
 

@@ -321,6 +321,39 @@ int kbbq_sam_open(const char* path, kbbq_sam** out)
 
 int kbbq_sam_close(kbbq_sam* f) { delete f; return KBBQ_OK; }
 
+// ---- a whole text file, inflated if it is gzip / bgzip: what the Python-side readers of FASTA / VCF / BED files take their bytes from
+// (bgzip blocks side by side, gzip members chunk-wise: bam_host.cpp kbbq_inflate_all) instead of Python's gzip module on one thread
+struct kbbq_text { const uint8_t* buf = nullptr; size_t size = 0; bool mapped = false; kbbq_bytes owned;
+                   ~kbbq_text() { if (mapped && buf) munmap((void*)buf, size); } };
+
+int kbbq_text_open(const char* path, kbbq_text** out, const uint8_t** data, size_t* n)
+{
+    if (!path || !out || !data || !n) return kbbq_set_error_(KBBQ_E_ARG, "kbbq_text_open: NULL argument");
+    *out = nullptr; *data = nullptr; *n = 0;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return kbbq_set_error_(KBBQ_E_ARG, (std::string("cannot open ") + path).c_str());
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": not a regular file").c_str()); }
+    kbbq_text* t = new kbbq_text();
+    t->size = (size_t)st.st_size;
+    if (t->size) {
+        void* m = mmap(nullptr, t->size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); delete t; return kbbq_set_error_(KBBQ_E_ARG, "mmap failed"); }
+        t->buf = (const uint8_t*)m; t->mapped = true;
+    }
+    close(fd);
+    if (t->size >= 2 && t->buf[0] == 0x1f && t->buf[1] == 0x8b) {
+        std::string err;
+        if (!kbbq_inflate_all(t->buf, t->size, t->owned, err)) { delete t; return kbbq_set_error_(KBBQ_E_ARG, (std::string(path) + ": " + err).c_str()); }
+        munmap((void*)t->buf, t->size);
+        t->mapped = false; t->buf = t->owned.data(); t->size = t->owned.size();
+    }
+    *out = t; *data = t->buf; *n = t->size;
+    return KBBQ_OK;
+}
+
+int kbbq_text_close(kbbq_text* t) { delete t; return KBBQ_OK; }
+
 // info = { alignments, CIGAR operations in total, longest SEQ, contigs seen, @RG lines, header lines }
 int kbbq_sam_info(const kbbq_sam* f, int64_t* info6)
 {

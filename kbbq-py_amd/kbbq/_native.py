@@ -118,6 +118,8 @@ PROTOTYPES = {
     'kbbq_sam_fields': (_i, [_vp] * 13),
     'kbbq_sam_cigar': (_i, [_vp, _vp]),
     'kbbq_sam_adaptor_trim': (_i, [_vp, _vp]),
+    'kbbq_text_open': (_i, [_c.c_char_p, _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_sz)]),
+    'kbbq_text_close': (_i, [_vp]),
     'kbbq_sam_fill': (_i, [_vp, _i64, _i64, _i, _i, _vp]),
     'kbbq_sam_text': (_i, [_vp, _i, _i64, _vp, _vp]),
     'kbbq_sam_match_fastq': (_i, [_vp, _vp, _vp]),

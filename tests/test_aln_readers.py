@@ -218,3 +218,34 @@ def test_bam_records_round_trip_property(tmp_path):
             return
         assert [b.line(i) for i in range(b.n)] == recs
     check()
+
+
+def test_compressed_fasta_vcf_bed_come_through_the_librarys_inflater(tmp_path):
+    """aln._read_bytes (kbbq_text_open): .gz FASTA / VCF / BED -- plain gzip and bgzip -- read like the plain files; a missing file is
+    open()'s FileNotFoundError, a damaged one a ValueError."""
+    import gzip
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bamwriter
+    from kbbq import aln
+    fa = b'>c1 first\nACGTNNAC\nGT\n>c2\n\nTTTT\r\nGG\n'
+    vcf = b'##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\n' + b''.join(b'c1\t%d\t.\tAC\tA\n' % i for i in range(1, 3000))
+    bed = b'track x\nc1 1 5\nc2\t0\t3\n'
+    (tmp_path / 'g.fa').write_bytes(fa)
+    plain = aln.FastaFile(str(tmp_path / 'g.fa'))
+    for tag, pack in (('gz', lambda b: gzip.compress(b, 6)), ('bgz', lambda b: bamwriter.bgzf(b, block=700))):
+        for name, blob in (('g.fa', fa), ('v.vcf', vcf), ('b.bed', bed)):
+            (tmp_path / ('%s.%s.gz' % (name, tag))).write_bytes(pack(blob))
+        z = aln.FastaFile(str(tmp_path / ('g.fa.%s.gz' % tag)))
+        assert z.references == plain.references == ['c1', 'c2'] and all(z.fetch(r) == plain.fetch(r) for r in plain.references)
+        recs = list(aln.read_vcf(str(tmp_path / ('v.vcf.%s.gz' % tag))))
+        assert len(recs) == 2999 and (recs[0].chrom, recs[0].start, recs[0].stop) == ('c1', 0, 2)
+        with aln._open(str(tmp_path / ('b.bed.%s.gz' % tag))) as fh:
+            assert [(r.contig, r.start, r.end) for r in aln.read_bed(fh)] == [('c1', 1, 5), ('c2', 0, 3)]
+    with pytest.raises(FileNotFoundError):
+        aln.FastaFile(str(tmp_path / 'missing.fa.gz'))
+    whole = gzip.compress(fa * 2000, 6)
+    (tmp_path / 'cut.fa.gz').write_bytes(whole[:len(whole) // 2])
+    with pytest.raises(ValueError):
+        aln.FastaFile(str(tmp_path / 'cut.fa.gz'))
